@@ -1,0 +1,165 @@
+"""Torch-tensor front of the C ABI: one :class:`GppContext` per GPU owns the library handle, follows PyTorch's
+current HIP stream and keeps the scratch workspace.  PyTorch is used for device memory and streams only; every
+number is produced by the kernels in ``csrc/``.
+
+Reference boundary this replaces: the gpytorch/ATen operators reached from ``optim/mll_torch.py:112-117`` and
+``models/gpregression.py:122-149``.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib
+from ._lib import GppError, check
+
+KIND_RBF, KIND_MATERN32, KIND_MATERN52 = 0, 1, 2
+UPLO_FULL, UPLO_LOWER = 0, 1
+OP_MLL_EVAL, OP_PREDICT = 0, 1
+
+_contexts: Dict[int, "GppContext"] = {}
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _need(t: torch.Tensor, dtype, name: str) -> None:
+    if not t.is_cuda:
+        raise GppError(f"{name} must live on the GPU (got {t.device}); libgpp_hip has no CPU path")
+    if t.dtype != dtype:
+        raise GppError(f"{name} must be {dtype} (got {t.dtype})")
+    if not t.is_contiguous() and t.dim() == 1:
+        raise GppError(f"{name} must be contiguous")
+
+
+def square_buffer(n: int, device) -> torch.Tensor:
+    """Uninitialised n x n fp64 matrix whose rows are padded to a multiple of 16 doubles (128-byte lines)."""
+    ld = max(16, (n + 15) // 16 * 16)
+    return torch.empty((n, ld), dtype=torch.float64, device=device)[:, :n]
+
+
+def _ld(m: torch.Tensor) -> int:
+    if m.dim() != 2 or m.stride(1) != 1:
+        raise GppError("matrix must be 2-D with unit column stride")
+    return m.stride(0) if m.shape[0] > 1 else max(m.shape[1], m.stride(0))
+
+
+class GppContext:
+    def __init__(self, device: torch.device):
+        if device.type != "cuda":
+            raise GppError("GppContext needs a cuda (HIP) device; there is no CPU fallback")
+        if not torch.cuda.is_available():
+            raise GppError("no GPU visible to PyTorch: the HIP path cannot run")
+        self.lib = _lib.load()
+        self.device = device
+        self.index = device.index if device.index is not None else torch.cuda.current_device()
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.index):
+            check(self.lib.gpp_create(ctypes.byref(h), self.index), "gpp_create")
+        self.h = h
+        self._ws: Optional[torch.Tensor] = None
+
+    # -- plumbing --------------------------------------------------------------------------------
+    def _stream(self) -> None:
+        s = torch.cuda.current_stream(self.index).cuda_stream
+        check(self.lib.gpp_set_stream(self.h, ctypes.c_void_p(s)), "gpp_set_stream")
+
+    def ensure_workspace(self, op: int, N: int, M: int, D: int, S: int) -> None:
+        need = int(self.lib.gpp_workspace_bytes(self.h, op, N, M, D, S))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            check(self.lib.gpp_set_workspace(self.h, self._ws.data_ptr(), self._ws.numel()), "gpp_set_workspace")
+
+    # -- operators -------------------------------------------------------------------------------
+    def kernel_build(self, U, w, sf2, tau, grp, out, *, jitter=0.0, kind=KIND_RBF, d_split=0, uplo=UPLO_FULL,
+                     row0=0, nrows=None):
+        N, D = U.shape
+        for t, n in ((U, "U"), (w, "w"), (sf2, "sf2"), (out, "Ky")):
+            _need(t, torch.float64, n)
+        if tau is not None:
+            _need(tau, torch.float64, "tau")
+        if grp is not None:
+            _need(grp, torch.int32, "grp")
+        if not U.is_contiguous():
+            raise GppError("U must be contiguous")
+        S = 0 if tau is None else tau.numel()
+        self._stream()
+        check(self.lib.gpp_kernel_build(self.h, U.data_ptr(), N, D, w.data_ptr(), sf2.data_ptr(), _ptr(tau), _ptr(grp), S,
+                                        float(jitter), kind, d_split, uplo, out.data_ptr(), _ld(out), row0,
+                                        N - row0 if nrows is None else nrows), "gpp_kernel_build")
+        return out
+
+    def cross_kernel(self, Ua, Ub, w, sf2, out, *, kind=KIND_RBF, d_split=0):
+        for t, n in ((Ua, "Ua"), (Ub, "Ub"), (w, "w"), (sf2, "sf2"), (out, "Kab")):
+            _need(t, torch.float64, n)
+        if not (Ua.is_contiguous() and Ub.is_contiguous()):
+            raise GppError("Ua/Ub must be contiguous")
+        self._stream()
+        check(self.lib.gpp_cross_kernel(self.h, Ua.data_ptr(), Ua.shape[0], Ub.data_ptr(), Ub.shape[0], Ua.shape[1],
+                                        w.data_ptr(), sf2.data_ptr(), kind, d_split, out.data_ptr(), _ld(out)),
+              "gpp_cross_kernel")
+        return out
+
+    def potrf(self, A, Linv, info):
+        _need(A, torch.float64, "A"); _need(Linv, torch.float64, "Linv"); _need(info, torch.int32, "info")
+        self._stream()
+        check(self.lib.gpp_potrf(self.h, A.data_ptr(), A.shape[0], _ld(A), Linv.data_ptr(), _ld(Linv), info.data_ptr()),
+              "gpp_potrf")
+
+    def trtri(self, L, Linv, T):
+        self._stream()
+        check(self.lib.gpp_trtri(self.h, L.data_ptr(), L.shape[0], _ld(L), Linv.data_ptr(), _ld(Linv), T.data_ptr(), _ld(T)),
+              "gpp_trtri")
+
+    def lauum(self, Linv, Kinv):
+        self._stream()
+        check(self.lib.gpp_lauum(self.h, Linv.data_ptr(), Linv.shape[0], _ld(Linv), Kinv.data_ptr(), _ld(Kinv)), "gpp_lauum")
+
+    def mll_reduce(self, L, Linv, r, z, out3):
+        for t, n in ((r, "r"), (z, "z"), (out3, "out3")):
+            _need(t, torch.float64, n)
+        self._stream()
+        check(self.lib.gpp_mll_reduce(self.h, L.data_ptr(), _ld(L), Linv.data_ptr(), _ld(Linv), L.shape[0], r.data_ptr(),
+                                      z.data_ptr(), out3.data_ptr()), "gpp_mll_reduce")
+
+    def alpha(self, Linv, z, alpha):
+        N = Linv.shape[0]
+        self.ensure_workspace(OP_MLL_EVAL, N, 0, 1, 1)
+        self._stream()
+        check(self.lib.gpp_alpha(self.h, Linv.data_ptr(), _ld(Linv), N, z.data_ptr(), alpha.data_ptr()), "gpp_alpha")
+
+    def grad_reduce(self, U, w, sf2, grp, S, alpha, Kinv, dU, g_w, g_sf2, g_tau, g_U, *, kind=KIND_RBF, d_split=0):
+        N, D = U.shape
+        self.ensure_workspace(OP_MLL_EVAL, N, 0, D, S)
+        self._stream()
+        check(self.lib.gpp_grad_reduce(self.h, U.data_ptr(), N, D, w.data_ptr(), sf2.data_ptr(), _ptr(grp), S, kind,
+                                       d_split, alpha.data_ptr(), Kinv.data_ptr(), _ld(Kinv), dU, g_w.data_ptr(),
+                                       g_sf2.data_ptr(), g_tau.data_ptr(), _ptr(g_U)), "gpp_grad_reduce")
+
+    def predict(self, Linv, alpha, Ksn, kss, V, mean_out, var_out):
+        self._stream()
+        check(self.lib.gpp_predict(self.h, Linv.data_ptr(), _ld(Linv), Linv.shape[0], alpha.data_ptr(), Ksn.data_ptr(),
+                                   _ld(Ksn), Ksn.shape[0], _ptr(kss), _ptr(V), 0 if V is None else _ld(V),
+                                   mean_out.data_ptr(), _ptr(var_out)), "gpp_predict")
+
+    def gemm(self, transA, transB, M, N, K, alpha, A, B, beta, C, *, a_mask=0, b_mask=0, klo_mode=0, khi_mode=0,
+             c_lower=0):
+        self._stream()
+        check(self.lib.gpp_gemm(self.h, transA, transB, M, N, K, float(alpha), A.data_ptr(), _ld(A), B.data_ptr(), _ld(B),
+                                float(beta), C.data_ptr(), _ld(C), a_mask, b_mask, klo_mode, khi_mode, c_lower), "gpp_gemm")
+
+
+def get_context(device) -> GppContext:
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise GppError(
+            f"the exact-GP hot path runs only on an MI355X through libgpp_hip (device={device}); no CPU fallback exists")
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    ctx = _contexts.get(idx)
+    if ctx is None:
+        ctx = GppContext(torch.device("cuda", idx))
+        _contexts[idx] = ctx
+    return ctx

@@ -1,0 +1,350 @@
+// gpp_api.hip — C ABI of libgpp_hip.so (declared in include/gpp.h) and the host-side orchestration of the blocked
+// dense algorithms.  No reference code corresponds to this file: the reference delegates the whole path to
+// gpytorch/ATen (optim/mll_torch.py:112-117); the algorithms here are the MI355X-native replacement.
+//
+// Cholesky (gpp_potrf): recursive lower factorisation
+//     potrf(A)  = potrf(A11); A21 <- A21 L11^-T (trsm); A22 -= A21 A21^T (syrk); potrf(A22)
+//     trsm(B,L) = trsm(B1,L11); B2 -= X1 L21^T (gemm); trsm(B2,L22)        -- splits at multiples of 128
+// so that every flop above the 128x128 leaves is a call of the MFMA GEMM kernel with a large K, and the leaves
+// (factor + inverse of a 128 block in LDS) also leave inv(L_bb) on the diagonal of Linv.
+// Inverse (gpp_trtri): bottom-up pair merging, for s = 128, 256, ...:
+//     Linv21 = -Linv22 (L21 Linv11)   for all aligned pairs of s-blocks at once (batched launches).
+// gpp_lauum: Kinv = Linv^T Linv in one lower-triangular TN launch (k >= max(i,j) tile ranges).
+#include "../../include/gpp.h"
+#include "gpp_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <new>
+
+namespace {
+
+constexpr int NBLK = GPP_TILE;
+
+inline int rc(hipError_t e) { return e == hipSuccess ? 0 : 1000 + (int)e; }
+#define GPP_TRY(expr)                   \
+  do {                                  \
+    hipError_t _e = (expr);             \
+    if (_e != hipSuccess) return rc(_e); \
+  } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+GemmArgs mk(const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc, int64_t M, int64_t N,
+            int64_t K, double alpha, double beta) {
+  GemmArgs g{};
+  g.A = A; g.B = B; g.C = C;
+  g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.M = (int)M; g.N = (int)N; g.K = (int)K;
+  g.alpha = alpha; g.beta = beta;
+  return g;
+}
+
+// split point: multiple of 128 closest to n/2 (from above)
+inline int64_t split(int64_t n) {
+  int64_t h = ((n / 2 + NBLK - 1) / NBLK) * NBLK;
+  if (h >= n) h -= NBLK;
+  return h;
+}
+
+struct Ctx {
+  hipStream_t s;
+  double* A; int64_t ld;       // matrix being factored (L on exit)
+  double* Li; int64_t ldi;     // Linv (diagonal leaves written here)
+  int32_t* info;
+};
+
+// X L^T = B for the n x n lower block L at (o,o); B is m x n at rows r0.., columns o..; in place.
+hipError_t trsm_rec(const Ctx& c, int64_t r0, int64_t m, int64_t o, int64_t n) {
+  if (m <= 0 || n <= 0) return hipSuccess;
+  if (n <= NBLK) {
+    // X = B * inv(L_leaf)^T : NT product with the leaf inverse (lower), in place (single column tile)
+    double* Bp = c.A + r0 * c.ld + o;
+    GemmArgs g = mk(Bp, c.ld, c.Li + o * c.ldi + o, c.ldi, Bp, c.ld, m, n, n, 1.0, 0.0);
+    g.b_mask = 1;
+    return gpp_launch_gemm(c.s, 0, g, 1, NBLK);  // in place: the whole panel width must sit in ONE column tile
+  }
+  const int64_t n1 = split(n), n2 = n - n1;
+  hipError_t e = trsm_rec(c, r0, m, o, n1);
+  if (e != hipSuccess) return e;
+  // B2 -= X1 * L21^T
+  GemmArgs g = mk(c.A + r0 * c.ld + o, c.ld, c.A + (o + n1) * c.ld + o, c.ld, c.A + r0 * c.ld + o + n1, c.ld, m, n2, n1,
+                  -1.0, 1.0);
+  e = gpp_launch_gemm(c.s, 0, g, 1);
+  if (e != hipSuccess) return e;
+  return trsm_rec(c, r0, m, o + n1, n2);
+}
+
+hipError_t potrf_rec(const Ctx& c, int64_t o, int64_t n) {
+  if (n <= 0) return hipSuccess;
+  if (n <= NBLK)
+    return gpp_launch_leaf(c.s, c.A + o * c.ld + o, c.ld, c.Li + o * c.ldi + o, c.ldi, (int)n, c.info, (int)o);
+  const int64_t n1 = split(n), n2 = n - n1;
+  hipError_t e = potrf_rec(c, o, n1);
+  if (e != hipSuccess) return e;
+  e = trsm_rec(c, o + n1, n2, o, n1);
+  if (e != hipSuccess) return e;
+  // A22 -= A21 A21^T (lower)
+  const double* A21 = c.A + (o + n1) * c.ld + o;
+  GemmArgs g = mk(A21, c.ld, A21, c.ld, c.A + (o + n1) * c.ld + (o + n1), c.ld, n2, n2, n1, -1.0, 1.0);
+  g.c_lower = 1;
+  e = gpp_launch_gemm(c.s, 0, g, 1);
+  if (e != hipSuccess) return e;
+  return potrf_rec(c, o + n1, n2);
+}
+
+int check_mat(const void* p, int64_t ld, int64_t n, int argi) {
+  if (!p) return -argi;
+  if (!aligned16(p) || (ld & 1) || ld < n) return -(argi + 1);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gpp_version(void) { return "gpp_hip 0.1 (gfx950, fp64 MFMA)"; }
+
+int gpp_create(gpp_handle_t* out, int device) {
+  if (!out) return -1;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess) return rc(e);
+  if (device < 0 || device >= ndev) return -2;
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return rc(e);
+  gpp_handle_s* h = new (std::nothrow) gpp_handle_s();
+  if (!h) return rc(hipErrorOutOfMemory);
+  h->device = device;
+  h->stream = nullptr;
+  h->ws = nullptr;
+  h->ws_bytes = 0;
+  *out = h;
+  return 0;
+}
+
+int gpp_destroy(gpp_handle_t h) {
+  if (!h) return -1;
+  delete h;
+  return 0;
+}
+
+int gpp_set_stream(gpp_handle_t h, void* stream) {
+  if (!h) return -1;
+  h->stream = reinterpret_cast<hipStream_t>(stream);
+  return 0;
+}
+
+size_t gpp_workspace_bytes(gpp_handle_t h, int op, int64_t N, int64_t M, int D, int S) {
+  (void)h;
+  (void)M;
+  if (op == GPP_OP_MLL_EVAL) {
+    const size_t trmv_part = (size_t)((N + 1023) / 1024) * (size_t)N * sizeof(double);
+    const size_t grad = gpp_grad_ws_bytes(N, D, S, D);
+    return std::max(trmv_part, grad) + 256;
+  }
+  if (op == GPP_OP_PREDICT) return 256;
+  return 0;
+}
+
+int gpp_set_workspace(gpp_handle_t h, void* ws, size_t bytes) {
+  if (!h) return -1;
+  if (ws && !aligned16(ws)) return -2;
+  h->ws = ws;
+  h->ws_bytes = bytes;
+  return 0;
+}
+
+int gpp_kernel_build(gpp_handle_t h, const double* U, int64_t N, int D, const double* w, const double* sf2,
+                     const double* tau, const int32_t* grp, int S, double jitter, int kind, int d_split, int uplo,
+                     double* Ky, int64_t ld, int64_t row0, int64_t nrows) {
+  if (!h) return -1;
+  if (!U) return -2;
+  if (N < 0) return -3;
+  if (D < 1 || D > 64) return -4;
+  if (!w) return -5;
+  if (!sf2) return -6;
+  if (tau && S < 1) return -9;
+  if (kind < 0 || kind > 2) return -11;
+  if (d_split < 0 || d_split > D) return -12;
+  if (uplo != GPP_UPLO_FULL && uplo != GPP_UPLO_LOWER) return -13;
+  if (!Ky) return -14;
+  if (ld < N) return -15;
+  if (row0 < 0 || nrows < 0 || row0 + nrows > N || (row0 % 64) != 0) return -16;
+  GPP_TRY(gpp_launch_kernel_build(h->stream, U, N, D, w, sf2, tau, grp, S, jitter, kind, d_split, uplo, Ky, ld, row0, nrows));
+  return 0;
+}
+
+int gpp_cross_kernel(gpp_handle_t h, const double* Ua, int64_t Ma, const double* Ub, int64_t Nb, int D, const double* w,
+                     const double* sf2, int kind, int d_split, double* Kab, int64_t ld) {
+  if (!h) return -1;
+  if (!Ua) return -2;
+  if (Ma < 0) return -3;
+  if (!Ub) return -4;
+  if (Nb < 0) return -5;
+  if (D < 1 || D > 64) return -6;
+  if (!w) return -7;
+  if (!sf2) return -8;
+  if (kind < 0 || kind > 2) return -9;
+  if (d_split < 0 || d_split > D) return -10;
+  if (!Kab) return -11;
+  if (ld < Nb) return -12;
+  GPP_TRY(gpp_launch_cross_kernel(h->stream, Ua, Ma, Ub, Nb, D, w, sf2, kind, d_split, Kab, ld));
+  return 0;
+}
+
+int gpp_potrf(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, int64_t ldi, int32_t* info_dev) {
+  if (!h) return -1;
+  if (N < 0) return -3;
+  if (int r = check_mat(A, ld, N, 2)) return r;
+  if (int r = check_mat(Linv, ldi, N, 5)) return r;
+  if (!info_dev) return -7;
+  GPP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int32_t), h->stream));
+  Ctx c{h->stream, A, ld, Linv, ldi, info_dev};
+  GPP_TRY(potrf_rec(c, 0, N));
+  return 0;
+}
+
+int gpp_trtri(gpp_handle_t h, const double* L, int64_t N, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt) {
+  if (!h) return -1;
+  if (N < 0) return -3;
+  if (int r = check_mat(L, ld, N, 2)) return r;
+  if (int r = check_mat(Linv, ldi, N, 5)) return r;
+  if (int r = check_mat(T, ldt, N, 7)) return r;
+  for (int64_t s = NBLK; s < N; s *= 2) {
+    // pairs p: blocks [2ps, 2ps+s) and [2ps+s, min(2ps+2s, N)); full pairs batched, a ragged last pair on its own.
+    const int64_t npairs_full = N / (2 * s);
+    const int64_t rem = N - npairs_full * 2 * s;  // leftover rows after the full pairs
+    for (int pass = 0; pass < 2; ++pass) {
+      int64_t o, m2;
+      int batch;
+      if (pass == 0) {
+        if (npairs_full == 0) continue;
+        o = 0; m2 = s; batch = (int)npairs_full;
+      } else {
+        if (rem <= s) continue;  // no second block in the ragged pair
+        o = npairs_full * 2 * s; m2 = rem - s; batch = 1;
+      }
+      const int64_t pstride_L = 2 * s * (ld + 1), pstride_I = 2 * s * (ldi + 1), pstride_T = 2 * s * (ldt + 1);
+      // T21 = L21 * Linv11      (NN; Linv11 lower: k >= n)
+      GemmArgs g1 = mk(L + (o + s) * ld + o, ld, Linv + o * ldi + o, ldi, T + (o + s) * ldt + o, ldt, m2, s, s, 1.0, 0.0);
+      g1.b_mask = 2; g1.klo_mode = 2;
+      g1.sA = pstride_L; g1.sB = pstride_I; g1.sC = pstride_T;
+      GPP_TRY(gpp_launch_gemm(h->stream, 1, g1, batch));
+      // Linv21 = -Linv22 * T21  (NN; Linv22 lower: k <= m)
+      GemmArgs g2 = mk(Linv + (o + s) * ldi + (o + s), ldi, T + (o + s) * ldt + o, ldt, Linv + (o + s) * ldi + o, ldi, m2,
+                       s, m2, -1.0, 0.0);
+      g2.a_mask = 1; g2.khi_mode = 1;
+      g2.sA = pstride_I; g2.sB = pstride_T; g2.sC = pstride_I;
+      GPP_TRY(gpp_launch_gemm(h->stream, 1, g2, batch));
+    }
+  }
+  return 0;
+}
+
+int gpp_lauum(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double* Kinv, int64_t ldk) {
+  if (!h) return -1;
+  if (N < 0) return -3;
+  if (int r = check_mat(Linv, ldi, N, 2)) return r;
+  if (int r = check_mat(Kinv, ldk, N, 5)) return r;
+  GemmArgs g = mk(Linv, ldi, Linv, ldi, Kinv, ldk, N, N, N, 1.0, 0.0);
+  g.a_mask = 2; g.b_mask = 2; g.klo_mode = 3; g.c_lower = 1;
+  GPP_TRY(gpp_launch_gemm(h->stream, 2, g, 1));
+  return 0;
+}
+
+int gpp_mll_reduce(gpp_handle_t h, const double* L, int64_t ld, const double* Linv, int64_t ldi, int64_t N,
+                   const double* r, double* z, double* out3) {
+  if (!h) return -1;
+  if (N < 0) return -6;
+  if (int q = check_mat(L, ld, N, 2)) return q;
+  if (int q = check_mat(Linv, ldi, N, 4)) return q;
+  if (!r || !aligned16(r)) return -7;
+  if (!z) return -8;
+  if (!out3) return -9;
+  GPP_TRY(gpp_launch_trmv_lower(h->stream, Linv, ldi, N, r, z));
+  GPP_TRY(gpp_launch_mll_scalars(h->stream, L, ld, N, z, out3));
+  return 0;
+}
+
+int gpp_alpha(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, const double* z, double* alpha) {
+  if (!h) return -1;
+  if (N < 0) return -4;
+  if (int q = check_mat(Linv, ldi, N, 2)) return q;
+  if (!z) return -5;
+  if (!alpha) return -6;
+  const size_t need = (size_t)((N + 1023) / 1024) * (size_t)N * sizeof(double);
+  if (!h->ws || h->ws_bytes < need) return -1;
+  GPP_TRY(gpp_launch_trmv_lower_t(h->stream, Linv, ldi, N, z, alpha, reinterpret_cast<double*>(h->ws)));
+  return 0;
+}
+
+int gpp_grad_reduce(gpp_handle_t h, const double* U, int64_t N, int D, const double* w, const double* sf2,
+                    const int32_t* grp, int S, int kind, int d_split, const double* alpha, const double* Kinv,
+                    int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau, double* g_U) {
+  if (!h) return -1;
+  if (!U) return -2;
+  if (N < 0) return -3;
+  if (D < 1 || D > 64) return -4;
+  if (!w) return -5;
+  if (!sf2) return -6;
+  if (S < 1 || S > 64) return -8;
+  if (kind != GPP_KIND_RBF) return -9;
+  if (!alpha) return -11;
+  if (int q = check_mat(Kinv, ldk, N, 12)) return q;
+  if (dU < 0 || dU > D) return -14;
+  if (!g_w) return -15;
+  if (!g_sf2) return -16;
+  if (!g_tau) return -17;
+  if (dU > 0 && !g_U) return -18;
+  if (!h->ws || h->ws_bytes < gpp_grad_ws_bytes(N, D, S, dU)) return -1;
+  GPP_TRY(gpp_launch_grad_reduce(h->stream, U, N, D, w, sf2, grp, S, kind, d_split, alpha, Kinv, ldk, dU, g_w, g_sf2, g_tau,
+                                 g_U, h->ws, h->ws_bytes));
+  return 0;
+}
+
+int gpp_predict(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, const double* alpha, const double* Ksn,
+                int64_t lds, int64_t M, const double* kss, double* V, int64_t ldv, double* mean_out, double* var_out) {
+  if (!h) return -1;
+  if (N < 0) return -4;
+  if (int q = check_mat(Linv, ldi, N, 2)) return q;
+  if (!alpha) return -5;
+  if (!Ksn || !aligned16(Ksn) || (lds & 1) || lds < N) return -6;
+  if (M < 0) return -8;
+  if (!mean_out) return -12;
+  if (V) {
+    if (!aligned16(V) || (ldv & 1) || ldv < N) return -10;
+    if (!kss) return -9;
+    if (!var_out) return -13;
+    // V = Ksn * Linv^T  (NT; Linv lower: k <= n)
+    GemmArgs g = mk(Ksn, lds, Linv, ldi, V, ldv, M, N, N, 1.0, 0.0);
+    g.b_mask = 1; g.khi_mode = 2;
+    GPP_TRY(gpp_launch_gemm(h->stream, 0, g, 1));
+  }
+  GPP_TRY(gpp_launch_predict_reduce(h->stream, Ksn, lds, V, ldv, M, N, alpha, kss, mean_out, var_out));
+  return 0;
+}
+
+int gpp_gemm(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+             int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int a_mask, int b_mask,
+             int klo_mode, int khi_mode, int c_lower) {
+  if (!h) return -1;
+  int variant;
+  if (transA == 0 && transB == 1) variant = 0;
+  else if (transA == 0 && transB == 0) variant = 1;
+  else if (transA == 1 && transB == 0) variant = 2;
+  else return -2;
+  if (M < 0 || N < 0 || K < 0) return -4;
+  if (!A || !aligned16(A) || (lda & 1)) return -8;
+  if (!B || !aligned16(B) || (ldb & 1)) return -10;
+  if (!C || !aligned16(C) || (ldc & 1)) return -13;
+  if (a_mask < 0 || a_mask > 2 || b_mask < 0 || b_mask > 2) return -15;
+  if (klo_mode < 0 || klo_mode > 3 || khi_mode < 0 || khi_mode > 2) return -17;
+  if (c_lower && M != N) return -19;
+  GemmArgs g = mk(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta);
+  g.a_mask = a_mask; g.b_mask = b_mask; g.klo_mode = klo_mode; g.khi_mode = khi_mode; g.c_lower = c_lower ? 1 : 0;
+  GPP_TRY(gpp_launch_gemm(h->stream, variant, g, 1));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,276 @@
+// gpp_gemm.hip — fp64 MFMA GEMM for gfx950 (MI355X): C = beta*C + alpha*op(A)*op(B) with triangular operand
+// masks, per-tile K ranges and lower-only output.  It carries every O(N^3) flop of the exact-GP path:
+//   - TRSM / SYRK / GEMM updates of the recursive Cholesky  (replaces torch.linalg.cholesky_ex reached from
+//     gpytorch psd_safe_cholesky, reference call site optim/mll_torch.py:116)
+//   - TRMM pair products of the bottom-up triangular inverse and the LAUUM product Linv^T Linv
+//     (replace ATen cholesky_backward, reference call site optim/mll_torch.py:117)
+//   - V = K_*N Linv^T of the prediction path (models/gpregression.py:122-149).
+//
+// Design (CDNA4, measured on MI355X — tools/mfma_probe.hip): v_mfma_f64_16x16x4_f64 issues only every ~105-140
+// cycles per SIMD (<= 48 TFLOP/s chip-wide), while v_mfma_f64_4x4x4_4b_f64 issues every 16 cycles (512 flop:
+// 32 flop/clk/SIMD, the 78.6 TFLOP/s fp64 peak).  Its cbsz/abid broadcast is ignored for f64, so the kernel
+// broadcasts in the LDS read instead: the A fragment of a 4-row block is loaded with the same address in the four
+// 4-lane column groups, the B fragment is a plain 16-column x 4-k fragment, and one MFMA yields a 4 x 16 slab of C
+// (lane l: row l>>4, col l&15).  A (2*WT)^2 output tile per 256-thread work-group, 2x2 waves; each wave owns
+// WT x WT = (WT/4) x (WT/16) such slabs (WT=64: 64 accumulator doubles per lane).  K is consumed in chunks of 16;
+// both operand chunks are staged in LDS in [k][row] order (padded strides, see ldt_*), double-buffered: the global
+// loads of chunk c+1 are issued before the MFMAs of chunk c and written to the other buffer afterwards, one barrier
+// per chunk.  WT = 32 / 16 variants (64^2 / 32^2 tiles) serve the small sub-problems of the recursions, where the
+// grid of 128^2 tiles would leave most of the 256 CUs idle.
+#include "gpp_internal.h"
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int BK = 16;
+// LDS row strides (doubles) for a tile edge T.  [k][row]-stored chunks of row-contiguous operands use T+16: 16-byte
+// aligned rows for ds_write_b128.  Chunks transposed on the fly from k-contiguous operands use T+17: the 16 lanes of
+// a ds_write_b64 group hold (row r, k = 0,2,..,14) and (row r+1, same k), so an odd stride spreads them over all 16
+// 8-byte bank slots.
+constexpr int ldt_mc(int T) { return T + 16; }
+constexpr int ldt_kc(int T) { return T + 17; }
+
+// Staging is split in two so that the global loads of chunk c+1 stay in flight across the MFMAs of chunk c:
+//   load_*  : computes the keep-predicates (range + triangular mask; no loaded data involved) and issues one
+//             branch-free 16-byte load per vector (from P itself when the element is out of range).  Reading one
+//             double past kend/R stays inside the allocation: ld is even and >= the extent (gpp.h).
+//   store_* : after the MFMAs, zeroes the dropped elements by select and writes the chunk to LDS.
+__device__ __forceinline__ bool keep_elem(int mask, int k, int row) {
+  return mask == 0 || (mask == 1 ? k <= row : k >= row);
+}
+
+// Operand stored [row][k] (k contiguous): T rows x 16 k per chunk, T/32 16-byte vectors per thread.
+template <int T>
+__device__ __forceinline__ unsigned load_kc(const double* __restrict__ P, int64_t ld, int R, int r0, int kb, int kend,
+                                            int mask, int tid, v2d (&reg)[T / 32]) {
+  unsigned keep = 0;
+#pragma unroll
+  for (int i = 0; i < T / 32; ++i) {
+    const int v = tid + 256 * i;
+    const int gr = r0 + (v >> 3);
+    const int gk = kb + ((v & 7) << 1);
+    const bool v0 = (gr < R) && (gk < kend);
+    const bool k0 = v0 && keep_elem(mask, gk, gr);
+    const bool k1 = v0 && (gk + 1 < kend) && keep_elem(mask, gk + 1, gr);
+    keep |= (k0 ? 1u : 0u) << (2 * i);
+    keep |= (k1 ? 1u : 0u) << (2 * i + 1);
+    const double* p = v0 ? P + (int64_t)gr * ld + gk : P;
+    reg[i] = *reinterpret_cast<const v2d*>(p);
+  }
+  return keep;
+}
+template <int T>
+__device__ __forceinline__ void store_kc(double* __restrict__ s, int tid, const v2d (&reg)[T / 32], unsigned keep) {
+#pragma unroll
+  for (int i = 0; i < T / 32; ++i) {
+    const int v = tid + 256 * i;
+    const int r = v >> 3;
+    const int kv = (v & 7) << 1;
+    s[kv * ldt_kc(T) + r] = ((keep >> (2 * i)) & 1u) ? reg[i].x : 0.0;
+    s[(kv + 1) * ldt_kc(T) + r] = ((keep >> (2 * i + 1)) & 1u) ? reg[i].y : 0.0;
+  }
+}
+
+// Operand stored [k][row] (row contiguous): 16 k x T rows per chunk.
+template <int T>
+__device__ __forceinline__ unsigned load_mc(const double* __restrict__ P, int64_t ld, int R, int r0, int kb, int kend,
+                                            int mask, int tid, v2d (&reg)[T / 32]) {
+  unsigned keep = 0;
+#pragma unroll
+  for (int i = 0; i < T / 32; ++i) {
+    const int v = tid + 256 * i;
+    const int gk = kb + v / (T / 2);
+    const int gr = r0 + ((v % (T / 2)) << 1);
+    const bool v0 = (gk < kend) && (gr < R);
+    const bool k0 = v0 && keep_elem(mask, gk, gr);
+    const bool k1 = v0 && (gr + 1 < R) && keep_elem(mask, gk, gr + 1);
+    keep |= (k0 ? 1u : 0u) << (2 * i);
+    keep |= (k1 ? 1u : 0u) << (2 * i + 1);
+    const double* p = v0 ? P + (int64_t)gk * ld + gr : P;
+    reg[i] = *reinterpret_cast<const v2d*>(p);
+  }
+  return keep;
+}
+template <int T>
+__device__ __forceinline__ void store_mc(double* __restrict__ s, int tid, const v2d (&reg)[T / 32], unsigned keep) {
+#pragma unroll
+  for (int i = 0; i < T / 32; ++i) {
+    const int v = tid + 256 * i;
+    const int k = v / (T / 2);
+    const int rv = (v % (T / 2)) << 1;
+    v2d t;
+    t.x = ((keep >> (2 * i)) & 1u) ? reg[i].x : 0.0;
+    t.y = ((keep >> (2 * i + 1)) & 1u) ? reg[i].y : 0.0;
+    *reinterpret_cast<v2d*>(s + k * ldt_mc(T) + rv) = t;
+  }
+}
+
+template <int VAR, int WT>
+__global__ __launch_bounds__(256, 2) void gpp_gemm_f64(GemmArgs p) {
+  constexpr bool A_KC = (VAR != 2);
+  constexpr bool B_KC = (VAR == 0);
+  constexpr int T = 2 * WT;  // work-group tile edge
+  constexpr int LDA = A_KC ? ldt_kc(T) : ldt_mc(T);
+  constexpr int LDB = B_KC ? ldt_kc(T) : ldt_mc(T);
+  constexpr int OPSZ = BK * ldt_kc(T);  // doubles per staged operand chunk (max of both strides)
+  constexpr int RB = WT / 4, CB = WT / 16;
+  __shared__ __attribute__((aligned(16))) double smem[2 * 2 * OPSZ];
+
+  int tm, tn;
+  {
+    const int t = blockIdx.x;
+    if (p.c_lower) {
+      tm = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+      while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
+      while (tm * (tm + 1) / 2 > t) --tm;
+      tn = t - tm * (tm + 1) / 2;
+    } else {
+      tm = t / p.tiles_n;
+      tn = t - tm * p.tiles_n;
+    }
+  }
+  const double* __restrict__ A = p.A + (int64_t)blockIdx.y * p.sA;
+  const double* __restrict__ B = p.B + (int64_t)blockIdx.y * p.sB;
+  double* __restrict__ C = p.C + (int64_t)blockIdx.y * p.sC;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = (wave >> 1) * WT, wn = (wave & 1) * WT;
+  const int li = lane & 15, lk = lane >> 4;
+  const int row0 = tm * T, col0 = tn * T;
+
+  int klo = 0;
+  if (p.klo_mode == 1) klo = row0;
+  else if (p.klo_mode == 2) klo = col0;
+  else if (p.klo_mode == 3) klo = row0 > col0 ? row0 : col0;
+  int khi = p.K;
+  if (p.khi_mode == 1) khi = min(p.K, row0 + T);
+  else if (p.khi_mode == 2) khi = min(p.K, col0 + T);
+  const int nch = khi > klo ? (khi - klo + BK - 1) / BK : 0;
+
+  double acc[RB][CB];
+#pragma unroll
+  for (int a = 0; a < RB; ++a)
+#pragma unroll
+    for (int b = 0; b < CB; ++b) acc[a][b] = 0.0;
+
+  v2d ra[T / 32], rb[T / 32];
+  unsigned ka = 0, kb_ = 0;
+  if (nch > 0) {
+    ka = A_KC ? load_kc<T>(A, p.lda, p.M, row0, klo, khi, p.a_mask, tid, ra)
+              : load_mc<T>(A, p.lda, p.M, row0, klo, khi, p.a_mask, tid, ra);
+    kb_ = B_KC ? load_kc<T>(B, p.ldb, p.N, col0, klo, khi, p.b_mask, tid, rb)
+               : load_mc<T>(B, p.ldb, p.N, col0, klo, khi, p.b_mask, tid, rb);
+    if (A_KC) store_kc<T>(smem, tid, ra, ka); else store_mc<T>(smem, tid, ra, ka);
+    if (B_KC) store_kc<T>(smem + OPSZ, tid, rb, kb_); else store_mc<T>(smem + OPSZ, tid, rb, kb_);
+  }
+  __syncthreads();
+
+  for (int c = 0; c < nch; ++c) {
+    const int cur = c & 1;
+    const bool more = (c + 1 < nch);
+    if (more) {
+      const int kb = klo + (c + 1) * BK;
+      ka = A_KC ? load_kc<T>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra)
+                : load_mc<T>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra);
+      kb_ = B_KC ? load_kc<T>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb)
+                 : load_mc<T>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb);
+    }
+    // A fragment: lane (i = l&3, k = l>>4), same address in the 4 column groups (l>>2)&3 -> LDS broadcast
+    const double* sa = smem + (cur * 2 + 0) * OPSZ + wm + (lane & 3);
+    const double* sb = smem + (cur * 2 + 1) * OPSZ + wn + li;
+#pragma unroll
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      double af[RB], bf[CB];
+#pragma unroll
+      for (int a = 0; a < RB; ++a) af[a] = sa[(kk * 4 + lk) * LDA + 4 * a];
+#pragma unroll
+      for (int b = 0; b < CB; ++b) bf[b] = sb[(kk * 4 + lk) * LDB + 16 * b];
+#pragma unroll
+      for (int a = 0; a < RB; ++a)
+#pragma unroll
+        for (int b = 0; b < CB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+    }
+    if (more) {
+      double* da = smem + ((cur ^ 1) * 2 + 0) * OPSZ;
+      double* db = smem + ((cur ^ 1) * 2 + 1) * OPSZ;
+      if (A_KC) store_kc<T>(da, tid, ra, ka); else store_mc<T>(da, tid, ra, ka);
+      if (B_KC) store_kc<T>(db, tid, rb, kb_); else store_mc<T>(db, tid, rb, kb_);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: slab (a,b) holds C[row0+wm+4a+(l>>4)][col0+wn+16b+(l&15)].  The beta path first issues all C loads of a
+  // group of slabs (clamped addresses, no branches around loads) and only then combines and stores.
+  const double alpha = p.alpha, beta = p.beta;
+  constexpr int GA = RB < 4 ? RB : 4;  // slab rows per group
+#pragma unroll
+  for (int a0 = 0; a0 < RB; a0 += GA) {
+    double cold[GA][CB];
+    if (beta != 0.0) {
+#pragma unroll
+      for (int a = 0; a < GA; ++a) {
+        const int m = row0 + wm + 4 * (a0 + a) + lk;
+#pragma unroll
+        for (int b = 0; b < CB; ++b) {
+          const int n = col0 + wn + 16 * b + li;
+          const bool ok = (m < p.M) && (n < p.N) && (!p.c_lower || n <= m);
+          const double* src = ok ? C + (int64_t)m * p.ldc + n : C;
+          cold[a][b] = *src;
+        }
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < GA; ++a) {
+      const int m = row0 + wm + 4 * (a0 + a) + lk;
+#pragma unroll
+      for (int b = 0; b < CB; ++b) {
+        const int n = col0 + wn + 16 * b + li;
+        const bool ok = (m < p.M) && (n < p.N) && (!p.c_lower || n <= m);
+        double v = alpha * acc[a0 + a][b];
+        if (beta != 0.0) v = fma(beta, cold[a][b], v);
+        if (ok) C[(int64_t)m * p.ldc + n] = v;
+      }
+    }
+  }
+}
+
+template <int VAR>
+hipError_t launch_var(hipStream_t s, int wt, dim3 grid, const GemmArgs& a) {
+  switch (wt) {
+    case 64: hipLaunchKernelGGL((gpp_gemm_f64<VAR, 64>), grid, dim3(256), 0, s, a); break;
+    case 32: hipLaunchKernelGGL((gpp_gemm_f64<VAR, 32>), grid, dim3(256), 0, s, a); break;
+    case 16: hipLaunchKernelGGL((gpp_gemm_f64<VAR, 16>), grid, dim3(256), 0, s, a); break;
+    default: return hipErrorInvalidValue;
+  }
+  return hipGetLastError();
+}
+
+}  // namespace
+
+// tile: 0 = pick by grid size, else the work-group tile edge (128 / 64 / 32).
+hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int batch, int tile) {
+  GemmArgs a = a_in;
+  if (a.M <= 0 || a.N <= 0 || batch <= 0) return hipSuccess;
+  auto ntiles = [&](int T) -> int64_t {
+    const int64_t tm = (a.M + T - 1) / T, tn = (a.N + T - 1) / T;
+    return (a.c_lower ? tm * (tm + 1) / 2 : tm * tn) * batch;
+  };
+  if (tile == 0) {
+    // enough 128^2 tiles to give every CU a work-group -> big tile; otherwise shrink until the chip is covered
+    if (ntiles(128) >= 256) tile = 128;
+    else if (ntiles(64) >= 192) tile = 64;
+    else tile = 32;
+  }
+  a.tiles_m = (a.M + tile - 1) / tile;
+  a.tiles_n = (a.N + tile - 1) / tile;
+  const int64_t nt = a.c_lower ? (int64_t)a.tiles_m * (a.tiles_m + 1) / 2 : (int64_t)a.tiles_m * a.tiles_n;
+  dim3 grid((unsigned)nt, (unsigned)batch, 1);
+  switch (variant) {
+    case 0: return launch_var<0>(s, tile / 2, grid, a);
+    case 1: return launch_var<1>(s, tile / 2, grid, a);
+    case 2: return launch_var<2>(s, tile / 2, grid, a);
+    default: return hipErrorInvalidValue;
+  }
+}

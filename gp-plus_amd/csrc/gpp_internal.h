@@ -1,0 +1,57 @@
+// gpp_internal.h — declarations shared by the HIP translation units of libgpp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define GPP_TILE 128 /* GEMM work-group tile edge and Cholesky leaf size */
+
+struct gpp_handle_s {
+  int device;
+  hipStream_t stream;
+  void* ws;
+  size_t ws_bytes;
+};
+
+// ---- fp64 MFMA GEMM (gpp_gemm.hip) ------------------------------------------------------------
+struct GemmArgs {
+  const double* A;
+  const double* B;
+  double* C;
+  int64_t lda, ldb, ldc;
+  int M, N, K;
+  double alpha, beta;
+  int a_mask, b_mask;      // 0 none, 1 keep k<=row, 2 keep k>=row
+  int klo_mode, khi_mode;  // see gpp.h
+  int c_lower;
+  int64_t sA, sB, sC;      // batch strides in elements (grid.y = batch)
+  int tiles_m, tiles_n;
+};
+// variant: 0 = NT (A[m][k], B[n][k]), 1 = NN (A[m][k], B[k][n]), 2 = TN (A[k][m], B[k][n])
+// tile: 0 = choose from the grid size, or force the work-group tile edge 128 / 64 / 32
+hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a, int batch, int tile = 0);
+
+// ---- 128x128 diagonal leaf: Cholesky + triangular inverse in LDS (gpp_leaf.hip) ---------------
+hipError_t gpp_launch_leaf(hipStream_t s, double* A, int64_t lda, double* Linv, int64_t ldi, int n, int32_t* info,
+                           int row_offset);
+
+// ---- covariance tiles (gpp_build.hip) ---------------------------------------------------------
+hipError_t gpp_launch_kernel_build(hipStream_t s, const double* U, int64_t N, int D, const double* w, const double* sf2,
+                                   const double* tau, const int32_t* grp, int S, double jitter, int kind, int d_split,
+                                   int uplo, double* Ky, int64_t ld, int64_t row0, int64_t nrows);
+hipError_t gpp_launch_cross_kernel(hipStream_t s, const double* Ua, int64_t Ma, const double* Ub, int64_t Nb, int D,
+                                   const double* w, const double* sf2, int kind, int d_split, double* Kab, int64_t ld);
+
+// ---- reductions (gpp_reduce.hip) --------------------------------------------------------------
+hipError_t gpp_launch_trmv_lower(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y);
+hipError_t gpp_launch_trmv_lower_t(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
+                                   double* part /* ceil(N/1024) x N */);
+hipError_t gpp_launch_mll_scalars(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* z, double* out3);
+size_t gpp_grad_ws_bytes(int64_t N, int D, int S, int dU);
+hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int D, const double* w, const double* sf2,
+                                  const int32_t* grp, int S, int kind, int d_split, const double* alpha,
+                                  const double* Kinv, int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau,
+                                  double* g_U, void* ws, size_t ws_bytes);
+hipError_t gpp_launch_predict_reduce(hipStream_t s, const double* Ksn, int64_t lds, const double* V, int64_t ldv,
+                                     int64_t M, int64_t N, const double* alpha, const double* kss, double* mean_out,
+                                     double* var_out);

@@ -1,0 +1,382 @@
+// gpp_reduce.hip — the O(N^2), HBM-bound reductions of the exact-GP path.
+//
+// Reference call sites replaced:
+//   optim/mll_torch.py:116  MultivariateNormal.log_prob -> gpytorch inv_quad_logdet (triangular solve, diag log-sum)
+//   optim/mll_torch.py:117  loss.backward(): the backward of exp / distance / outputscale / noise-add, i.e.
+//                           dMLL/dtheta = sum_ij W_ij dKy_ij/dtheta with W = 0.5 (alpha alpha' - Ky^-1)
+//   models/gpregression.py:142-147  predictive mean and variance
+// Every matrix is streamed exactly once; all reductions are two-stage and deterministic (no float atomics).
+#include "gpp_internal.h"
+
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// y_i = sum_{k<=i} T[i][k] x_k : one wave per row, rows interleaved over waves so long and short rows mix.
+__global__ __launch_bounds__(256) void gpp_trmv_lower(const double* __restrict__ T, int64_t ldt, int64_t N,
+                                                      const double* __restrict__ x, double* __restrict__ y) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= N) return;
+  const double* row = T + i * ldt;
+  double acc = 0.0;
+  const int64_t len = i + 1;
+  const int64_t len2 = len & ~(int64_t)1;
+  for (int64_t k = 2 * lane; k < len2; k += 128) {
+    const v2d t = *reinterpret_cast<const v2d*>(row + k);
+    const v2d xx = *reinterpret_cast<const v2d*>(x + k);
+    acc = fma(t.x, xx.x, acc);
+    acc = fma(t.y, xx.y, acc);
+  }
+  if (lane == 0 && (len & 1)) acc = fma(row[len - 1], x[len - 1], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) y[i] = acc;
+}
+
+// stage 1 of y_j = sum_{i>=j} T[i][j] x_i : block (cb, rb) sums rows [rb*1024, rb*1024+1024) for columns cb*256+tx.
+constexpr int TR_ROWS = 1024;
+__global__ __launch_bounds__(256) void gpp_trmv_lower_t_part(const double* __restrict__ T, int64_t ldt, int64_t N,
+                                                             const double* __restrict__ x, double* __restrict__ part) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t rb = blockIdx.y;
+  const int64_t r0 = rb * TR_ROWS;
+  int64_t r1 = r0 + TR_ROWS;
+  if (r1 > N) r1 = N;
+  double acc = 0.0;
+  if (j < N && r1 > (int64_t)blockIdx.x * 256) {
+    int64_t i = r0 > j ? r0 : j;
+    for (; i < r1; ++i) acc = fma(T[i * ldt + j], x[i], acc);
+  }
+  if (j < N) part[rb * N + j] = acc;
+}
+__global__ __launch_bounds__(256) void gpp_colsum_parts(const double* __restrict__ part, int64_t N, int nparts,
+                                                        double* __restrict__ y) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= N) return;
+  double acc = 0.0;
+  for (int p = 0; p < nparts; ++p) acc += part[(int64_t)p * N + j];
+  y[j] = acc;
+}
+
+// out3 = { quad = z'z, logdet = 2 sum log L_ii, mll = -0.5 (quad + logdet + N log 2pi) } : one work-group.
+__global__ __launch_bounds__(1024) void gpp_mll_scalars(const double* __restrict__ L, int64_t ld, int64_t N,
+                                                        const double* __restrict__ z, double* __restrict__ out3) {
+  __shared__ double sq[16], sl[16];
+  double q = 0.0, l = 0.0;
+  for (int64_t i = threadIdx.x; i < N; i += 1024) {
+    const double zi = z[i];
+    q = fma(zi, zi, q);
+    l += log(L[i * ld + i]);
+  }
+  q = wave_sum(q);
+  l = wave_sum(l);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) {
+    sq[wave] = q;
+    sl[wave] = l;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double qq = 0.0, ll = 0.0;
+    for (int w = 0; w < 16; ++w) {
+      qq += sq[w];
+      ll += sl[w];
+    }
+    ll *= 2.0;
+    out3[0] = qq;
+    out3[1] = ll;
+    out3[2] = -0.5 * (qq + ll + (double)N * 1.8378770664093454835606594728112);  // log(2 pi)
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gradient reduction.  Tiles of 64x64 over the lower triangle of Kinv; 256 threads, 4x4 per thread.
+// Per tile the kernel forms G_ij = mult * W_ij * sf2*k_ij  (W = 0.5(alpha_i alpha_j - Kinv_ij), mult = 2 for the
+// strictly-lower entries, which stand for (i,j) and (j,i), 1 on the diagonal) and accumulates
+//    g_w[d]  += G_ij * (-(u_id-u_jd)^2)          g_sf2 += mult * W_ij * k_ij          wdiag[i] = W_ii
+//    g_U[i,d] += G_ij (-2 w_d)(u_id-u_jd)   and   g_U[j,d] += G_ij (-2 w_d)(u_jd-u_id)      (d < dU)
+// Work-groups grid-stride over tiles; scalar sums go to one record per work-group, g_U row/column sums to the
+// slot [partner tile][row] of a partial buffer (every slot is written exactly once).  Finish kernels sum both.
+constexpr int GT = 64;
+constexpr int GD_MAX = 64;
+constexpr int GS_MAX = 64;
+constexpr int G_WGS = 2048;
+
+__device__ __forceinline__ void tile_from_index(int64_t t, int64_t& ti, int64_t& tj) {
+  int64_t r = (int64_t)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((r + 1) * (r + 2) / 2 <= t) ++r;
+  while (r * (r + 1) / 2 > t) --r;
+  ti = r;
+  tj = t - r * (r + 1) / 2;
+}
+
+template <int DT>
+__global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__ U, int64_t N, int D,
+                                                      const double* __restrict__ w, const double* __restrict__ sf2p,
+                                                      const double* __restrict__ alpha, const double* __restrict__ Kinv,
+                                                      int64_t ldk, int dU, int64_t ntiles,
+                                                      double* __restrict__ rec /* [gridDim.x][D+1] */,
+                                                      double* __restrict__ wdiag /* [N] */,
+                                                      double* __restrict__ gUpart /* [T][N][dU] */) {
+  __shared__ double sa[DT * GT];  // raw U rows of tile-row ti, [d][r]
+  __shared__ double sb[DT * GT];
+  __shared__ double sal_a[GT], sal_b[GT];
+  __shared__ double sw[DT];
+  __shared__ double red[256];
+  __shared__ double rowpart[GT * 16];
+  const int tid = threadIdx.x;
+  const int ty = tid >> 4, tx = tid & 15;
+  const double sf2 = *sf2p;
+  if (tid < DT) sw[tid] = (tid < D) ? w[tid] : 0.0;
+
+  double my_sf2 = 0.0;
+  double my_w[DT];
+#pragma unroll
+  for (int d = 0; d < DT; ++d) my_w[d] = 0.0;
+
+  for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    int64_t ti, tj;
+    tile_from_index(t, ti, tj);
+    const int64_t i0 = ti * GT, j0 = tj * GT;
+    const bool diag_tile = (ti == tj);
+    __syncthreads();
+    for (int e = tid; e < DT * GT; e += 256) {
+      const int d = e / GT, r = e - d * GT;
+      sa[e] = (d < D && i0 + r < N) ? U[(i0 + r) * D + d] : 0.0;
+      sb[e] = (d < D && j0 + r < N) ? U[(j0 + r) * D + d] : 0.0;
+    }
+    if (tid < GT) {
+      sal_a[tid] = (i0 + tid < N) ? alpha[i0 + tid] : 0.0;
+      sal_b[tid] = (j0 + tid < N) ? alpha[j0 + tid] : 0.0;
+    }
+    __syncthreads();
+
+    double G[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int64_t i = i0 + 4 * ty + a;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int64_t j = j0 + 4 * tx + b;
+        double g = 0.0;
+        if (i < N && j <= i) {
+          double r2 = 0.0;
+#pragma unroll
+          for (int d = 0; d < DT; ++d) {
+            const double df = sa[d * GT + 4 * ty + a] - sb[d * GT + 4 * tx + b];
+            r2 = fma(sw[d] * df, df, r2);
+          }
+          const double kv = exp(-r2);
+          const double Wij = 0.5 * (sal_a[4 * ty + a] * sal_b[4 * tx + b] - Kinv[i * ldk + j]);
+          const double mult = (i == j) ? 1.0 : 2.0;
+          my_sf2 = fma(mult * Wij, kv, my_sf2);
+          g = mult * Wij * sf2 * kv;
+          if (i == j) wdiag[i] = Wij;
+        }
+        G[a][b] = g;
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DT; ++d) {
+      double s = 0.0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const double df = sa[d * GT + 4 * ty + a] - sb[d * GT + 4 * tx + b];
+          s = fma(-G[a][b] * df, df, s);
+        }
+      my_w[d] += s;
+    }
+    for (int d = 0; d < dU; ++d) {
+      const double m2w = -2.0 * sw[d];
+      double rs[4], cs[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        double s = 0.0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) s = fma(G[a][b], sa[d * GT + 4 * ty + a] - sb[d * GT + 4 * tx + b], s);
+        rs[a] = s;
+      }
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) s = fma(G[a][b], sb[d * GT + 4 * tx + b] - sa[d * GT + 4 * ty + a], s);
+        cs[b] = s;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int a = 0; a < 4; ++a) rowpart[(4 * ty + a) * 16 + tx] = rs[a];
+      __syncthreads();
+      double rsum = 0.0;
+      if (tid < GT)
+        for (int q = 0; q < 16; ++q) rsum += rowpart[tid * 16 + q];
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < 4; ++b) rowpart[(4 * tx + b) * 16 + ty] = cs[b];
+      __syncthreads();
+      if (tid < GT) {
+        double csum = 0.0;
+        for (int q = 0; q < 16; ++q) csum += rowpart[tid * 16 + q];
+        if (diag_tile) {
+          if (i0 + tid < N) gUpart[((int64_t)ti * N + (i0 + tid)) * dU + d] = m2w * (rsum + csum);
+        } else {
+          if (i0 + tid < N) gUpart[((int64_t)tj * N + (i0 + tid)) * dU + d] = m2w * rsum;
+          if (j0 + tid < N) gUpart[((int64_t)ti * N + (j0 + tid)) * dU + d] = m2w * csum;
+        }
+      }
+    }
+  }
+
+  const int nrec = D + 1;
+  for (int q = 0; q < nrec; ++q) {
+    double v = my_sf2;
+    if (q < D) {
+#pragma unroll
+      for (int d = 0; d < DT; ++d)
+        if (q == d) v = my_w[d];
+    }
+    __syncthreads();
+    red[tid] = v;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    if (tid == 0) rec[(int64_t)blockIdx.x * nrec + q] = red[0];
+  }
+}
+
+// q < D: g_w[q]; q == D: g_sf2; q > D: g_tau[q-D-1] = sum_{i in group} wdiag[i]
+__global__ __launch_bounds__(256) void gpp_grad_finish(const double* __restrict__ rec, int nwg, int D, int S,
+                                                       const double* __restrict__ wdiag, const int32_t* __restrict__ grp,
+                                                       int64_t N, double* __restrict__ g_w, double* __restrict__ g_sf2,
+                                                       double* __restrict__ g_tau) {
+  __shared__ double red[256];
+  const int q = blockIdx.x, nrec = D + 1, tid = threadIdx.x;
+  double v = 0.0;
+  if (q <= D) {
+    for (int b = tid; b < nwg; b += 256) v += rec[(int64_t)b * nrec + q];
+  } else {
+    const int s = q - D - 1;
+    for (int64_t i = tid; i < N; i += 256)
+      if ((grp ? grp[i] : 0) == s) v += wdiag[i];
+  }
+  red[tid] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (q < D) g_w[q] = red[0];
+    else if (q == D) g_sf2[0] = red[0];
+    else g_tau[q - D - 1] = red[0];
+  }
+}
+
+__global__ __launch_bounds__(256) void gpp_gU_finish(const double* __restrict__ gUpart, int64_t N, int dU, int T,
+                                                     double* __restrict__ g_U) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= N * dU) return;
+  double s = 0.0;
+  for (int t = 0; t < T; ++t) s += gUpart[(int64_t)t * N * dU + e];
+  g_U[e] = s;
+}
+
+// mean_a = sum_j Ksn[a][j] alpha_j ; var_a = kss_a - sum_j V[a][j]^2 : one wave per test row.
+__global__ __launch_bounds__(256) void gpp_predict_rows(const double* __restrict__ Ksn, int64_t lds, const double* __restrict__ V,
+                                                        int64_t ldv, int64_t M, int64_t N, const double* __restrict__ alpha,
+                                                        const double* __restrict__ kss, double* __restrict__ mean_out,
+                                                        double* __restrict__ var_out) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t a = (int64_t)blockIdx.x * 4 + wave;
+  if (a >= M) return;
+  double m = 0.0, q = 0.0;
+  const double* kr = Ksn + a * lds;
+  for (int64_t j = lane; j < N; j += 64) m = fma(kr[j], alpha[j], m);
+  if (V) {
+    const double* vr = V + a * ldv;
+    for (int64_t j = lane; j < N; j += 64) q = fma(vr[j], vr[j], q);
+  }
+  m = wave_sum(m);
+  q = wave_sum(q);
+  if (lane == 0) {
+    mean_out[a] = m;
+    if (V && var_out) var_out[a] = kss[a] - q;
+  }
+}
+
+}  // namespace
+
+hipError_t gpp_launch_trmv_lower(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y) {
+  if (N <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gpp_trmv_lower, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, T, ldt, N, x, y);
+  return hipGetLastError();
+}
+
+hipError_t gpp_launch_trmv_lower_t(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
+                                   double* part) {
+  if (N <= 0) return hipSuccess;
+  const int nparts = (int)((N + TR_ROWS - 1) / TR_ROWS);
+  hipLaunchKernelGGL(gpp_trmv_lower_t_part, dim3((unsigned)((N + 255) / 256), (unsigned)nparts), dim3(256), 0, s, T, ldt, N,
+                     x, part);
+  hipLaunchKernelGGL(gpp_colsum_parts, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, part, N, nparts, y);
+  return hipGetLastError();
+}
+
+hipError_t gpp_launch_mll_scalars(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* z, double* out3) {
+  hipLaunchKernelGGL(gpp_mll_scalars, dim3(1), dim3(1024), 0, s, L, ld, N, z, out3);
+  return hipGetLastError();
+}
+
+size_t gpp_grad_ws_bytes(int64_t N, int D, int S, int dU) {
+  (void)S;
+  const int64_t T = (N + GT - 1) / GT;
+  return (size_t)G_WGS * (D + 1) * sizeof(double) + (size_t)N * sizeof(double) +
+         (size_t)T * N * (dU > 0 ? dU : 0) * sizeof(double) + 256;
+}
+
+hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int D, const double* w, const double* sf2,
+                                  const int32_t* grp, int S, int kind, int d_split, const double* alpha,
+                                  const double* Kinv, int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau,
+                                  double* g_U, void* ws, size_t ws_bytes) {
+  (void)d_split;
+  if (kind != 0) return hipErrorInvalidValue;  // Matern gradients: SURVEY.md §8(f2), not on the round-1 path
+  if (D > GD_MAX || D < 1 || S > GS_MAX || S < 1 || dU > D || dU < 0) return hipErrorInvalidValue;
+  if (ws_bytes < gpp_grad_ws_bytes(N, D, S, dU)) return hipErrorInvalidValue;
+  const int T = (int)((N + GT - 1) / GT);
+  const int64_t ntiles = (int64_t)T * (T + 1) / 2;
+  const int nwg = (int)(ntiles < G_WGS ? ntiles : G_WGS);
+  double* rec = reinterpret_cast<double*>(ws);
+  double* wdiag = rec + (size_t)G_WGS * (D + 1);
+  double* gUpart = wdiag + N;
+#define GPP_GRAD_LAUNCH(DT)                                                                                              \
+  hipLaunchKernelGGL(gpp_grad_tiles<DT>, dim3(nwg), dim3(256), 0, s, U, N, D, w, sf2, alpha, Kinv, ldk, dU, ntiles, rec, \
+                     wdiag, gUpart)
+  if (D <= 8) GPP_GRAD_LAUNCH(8);
+  else if (D <= 16) GPP_GRAD_LAUNCH(16);
+  else if (D <= 32) GPP_GRAD_LAUNCH(32);
+  else GPP_GRAD_LAUNCH(64);
+#undef GPP_GRAD_LAUNCH
+  hipLaunchKernelGGL(gpp_grad_finish, dim3(D + 1 + S), dim3(256), 0, s, rec, nwg, D, S, wdiag, grp, N, g_w, g_sf2, g_tau);
+  if (dU > 0)
+    hipLaunchKernelGGL(gpp_gU_finish, dim3((unsigned)((N * dU + 255) / 256)), dim3(256), 0, s, gUpart, N, dU, T, g_U);
+  return hipGetLastError();
+}
+
+hipError_t gpp_launch_predict_reduce(hipStream_t s, const double* Ksn, int64_t lds, const double* V, int64_t ldv,
+                                     int64_t M, int64_t N, const double* alpha, const double* kss, double* mean_out,
+                                     double* var_out) {
+  if (M <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gpp_predict_rows, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, s, Ksn, lds, V, ldv, M, N, alpha, kss,
+                     mean_out, var_out);
+  return hipGetLastError();
+}

@@ -1,0 +1,129 @@
+/*
+ * gpp.h — C ABI of libgpp_hip.so, the MI355X (gfx950) native back end of the GP+ exact-GP hot path.
+ *
+ * The reference (Bostanabad-Research-Group/GP-Plus @ 2024_08_07) has no FFI of its own: the path
+ *   optim/mll_torch.py:112-117   output = model(*train_inputs); loss = -mll(output, y); loss.backward()
+ * runs entirely inside gpytorch/ATen.  Each entry point below replaces the ATen/gpytorch operator(s)
+ * that the named reference call site reaches (SURVEY.md §2.1 "implicit device-op inventory", rows K1-K8).
+ * The Python host in gp-plus_amd/ binds these with ctypes (gp-plus_amd/_lib.py); INTEGRATION.md shows the
+ * stub a GP+ maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors), except where noted "host";
+ *  - matrices are row-major fp64 with an explicit leading dimension `ld` (elements); N x N factors keep
+ *    the LOWER triangle authoritative, the strict upper triangle is never read;
+ *  - N x N matrix pointers must be 16-byte aligned and `ld` even (the kernels use 16-byte accesses);
+ *  - all work is enqueued on the handle's stream (gpp_set_stream) and is asynchronous to the host;
+ *  - return value: 0 ok, <0 bad argument (-(index of the argument)), >0 HIP runtime error code + 1000;
+ *    numerical failure of the factorisation is reported LAPACK-style through `info_dev` (device int32:
+ *    0 = ok, k>0 = leading minor k not positive definite), which the caller reads after syncing;
+ *  - the library never allocates or frees user-visible memory; scratch comes from the workspace the caller
+ *    attaches with gpp_set_workspace (size from gpp_workspace_bytes).
+ */
+#ifndef GPP_H
+#define GPP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpp_handle_s* gpp_handle_t;
+
+/* kernel family of gpp_kernel_build / gpp_cross_kernel / gpp_grad_reduce (`kind`) */
+#define GPP_KIND_RBF      0 /* sf2*exp(-sum_d w_d (u_id-u_jd)^2): gpytorch RBFKernel (models/gp_plus.py:223-253),
+                               kernels/Rough_RBF.py:27-32, product of RBFs (models/gp_plus.py:297-303) */
+#define GPP_KIND_MATERN32 1 /* kernels/matern.py:4-5 on the dims >= d_split, RBF on dims < d_split */
+#define GPP_KIND_MATERN52 2 /* kernels/matern.py:7-8 */
+
+#define GPP_UPLO_FULL  0
+#define GPP_UPLO_LOWER 1    /* only tiles that intersect the lower triangle are written */
+
+/* operation ids for gpp_workspace_bytes */
+#define GPP_OP_MLL_EVAL 0   /* potrf + trtri + lauum + mll_reduce + grad_reduce for an N-point model */
+#define GPP_OP_PREDICT  1   /* gpp_predict with M test points */
+
+const char* gpp_version(void);
+
+int gpp_create(gpp_handle_t* out, int device);
+int gpp_destroy(gpp_handle_t h);
+/* `stream` is a hipStream_t (passed as void* so this header needs no HIP include). */
+int gpp_set_stream(gpp_handle_t h, void* stream);
+size_t gpp_workspace_bytes(gpp_handle_t h, int op, int64_t N, int64_t M, int D, int S);
+int gpp_set_workspace(gpp_handle_t h, void* ws, size_t bytes);
+
+/*
+ * K1-K4 fused (models/gp_plus.py:472-474 covar_module(x_new).evaluate();
+ * gpytorch RBFKernel/ProductKernel/ScaleKernel; likelihoods_noise/multifidelity.py:63-67 K + diag(noise)):
+ *   Ky[i,j] = sf2 * k(U_i, U_j; w) + (i==j) * (tau[grp[i]] + jitter)      for row0 <= i < row0+nrows
+ * U: N x D row-major; w: D weights; sf2: 1 double (device); tau: S doubles or NULL; grp: N int32 or NULL
+ * (NULL => group 0); d_split: number of leading dims that stay RBF when kind != RBF.
+ */
+int gpp_kernel_build(gpp_handle_t h, const double* U, int64_t N, int D, const double* w, const double* sf2,
+                     const double* tau, const int32_t* grp, int S, double jitter, int kind, int d_split,
+                     int uplo, double* Ky, int64_t ld, int64_t row0, int64_t nrows);
+
+/* K8 cross block (models/gpregression.py:126 self(x) -> test/train covariance): Kab[a,b] = sf2*k(Ua_a, Ub_b; w) */
+int gpp_cross_kernel(gpp_handle_t h, const double* Ua, int64_t Ma, const double* Ub, int64_t Nb, int D,
+                     const double* w, const double* sf2, int kind, int d_split, double* Kab, int64_t ld);
+
+/*
+ * K5 (gpytorch psd_safe_cholesky -> torch.linalg.cholesky_ex reached from optim/mll_torch.py:116):
+ * in-place lower Cholesky of A (N x N).  Recursive blocked factorisation; every product runs on the
+ * fp64 MFMA GEMM kernel, 128 x 128 diagonal leaves are factored AND inverted in LDS.  On return the lower
+ * triangle of A holds L and the 128-aligned diagonal blocks of Linv hold inv(L_bb) (needed by gpp_trtri).
+ */
+int gpp_potrf(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, int64_t ldi, int32_t* info_dev);
+
+/* Completes Linv = inv(L) (lower) from the diagonal-block inverses left by gpp_potrf.  T (N x N) is scratch. */
+int gpp_trtri(gpp_handle_t h, const double* L, int64_t N, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt);
+
+/* Kinv(lower) = Linv^T Linv.  With gpp_trtri this is K7's "K_y^-1" (ATen cholesky_backward, optim/mll_torch.py:117). */
+int gpp_lauum(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double* Kinv, int64_t ldk);
+
+/*
+ * K6 (gpytorch MultivariateNormal.log_prob -> inv_quad_logdet, optim/mll_torch.py:116):
+ *   z = Linv r;  out3 = { quad = z'z, logdet = 2 sum log L_ii, mll = -0.5*(quad + logdet + N log 2pi) }
+ */
+int gpp_mll_reduce(gpp_handle_t h, const double* L, int64_t ld, const double* Linv, int64_t ldi, int64_t N,
+                   const double* r, double* z, double* out3);
+
+/* alpha = Linv^T z = Ky^-1 r (gpytorch prediction_strategy mean_cache; dMLL/dmean) */
+int gpp_alpha(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, const double* z, double* alpha);
+
+/*
+ * K7 reduction (autograd backward of K1-K4, optim/mll_torch.py:117), with W = 0.5*(alpha alpha' - Kinv):
+ *   g_w[d]   = sum_ij W_ij dKy_ij/dw_d        g_sf2 = sum_ij W_ij K_ij / sf2
+ *   g_tau[s] = sum_{i in s} W_ii              g_U[i,d] = dMLL/dU_id for d < dU (dU may be 0)
+ * K_ij is recomputed from U in registers; only the lower triangle of Kinv is read.
+ */
+int gpp_grad_reduce(gpp_handle_t h, const double* U, int64_t N, int D, const double* w, const double* sf2,
+                    const int32_t* grp, int S, int kind, int d_split, const double* alpha, const double* Kinv,
+                    int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau, double* g_U);
+
+/*
+ * K8 (models/gpregression.py:122-149 predict): V = Ksn Linv^T (M x N, scratch, may be NULL to skip var),
+ *   mean_out[a] = sum_j Ksn[a,j] alpha[j],   var_out[a] = kss[a] - sum_j V[a,j]^2
+ */
+int gpp_predict(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, const double* alpha, const double* Ksn,
+                int64_t lds, int64_t M, const double* kss, double* V, int64_t ldv, double* mean_out, double* var_out);
+
+/*
+ * The fp64 MFMA GEMM behind all of the above, exported for the parity tests:
+ *   C = beta*C + alpha*op(A)*op(B),  op(A): M x K, op(B): K x N, all row-major.
+ * transA: 0 = A stored M x K, 1 = A stored K x M;  transB: 0 = B stored K x N, 1 = B stored N x K.
+ * Supported (transA,transB): (0,1) "NT", (0,0) "NN", (1,0) "TN".
+ * a_mask/b_mask: 0 none, 1 keep entries with k <= row, 2 keep entries with k >= row (row = m for A, n for B);
+ * klo_mode: 0 -> 0, 1 -> tile_m*128, 2 -> tile_n*128, 3 -> max of both;  khi_mode: 0 -> K, 1 -> (tile_m+1)*128,
+ * 2 -> (tile_n+1)*128;  c_lower: compute/write only entries with n <= m (M == N).
+ */
+int gpp_gemm(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+             int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int a_mask, int b_mask,
+             int klo_mode, int khi_mode, int c_lower);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPP_H */

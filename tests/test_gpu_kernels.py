@@ -1,0 +1,223 @@
+"""GPU parity of the individual HIP kernels (called through the C ABI) against numpy/scipy fp64."""
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+
+
+def _sq(n, fill=None):
+    from gpplus_amd.backend import square_buffer
+
+    m = square_buffer(n, "cuda")
+    m.fill_(float("nan") if fill is None else fill)
+    return m
+
+
+def _spd(n, d=6, seed=0, noise=1e-3):
+    rng = np.random.default_rng(seed)
+    U = rng.standard_normal((n, d))
+    w = rng.uniform(0.05, 0.5, d)
+    d2 = ((U[:, None, :] - U[None, :, :]) ** 2 * w).sum(-1)
+    K = 0.8 * np.exp(-d2) + noise * np.eye(n)
+    return U, w, K
+
+
+@pytest.mark.parametrize("variant", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("shape", [(128, 128, 16), (200, 333, 77), (513, 130, 1000), (64, 700, 5)])
+def test_gemm_plain(gpu_ctx, variant, shape):
+    M, N, K = shape
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((M, K))
+    B = rng.standard_normal((K, N))
+    C0 = rng.standard_normal((M, N))
+    ld = lambda n: (n + 15) // 16 * 16
+    tA, tB = {"NT": (0, 1), "NN": (0, 0), "TN": (1, 0)}[variant]
+    As = A.T if tA else A
+    Bs = B.T if tB else B
+    dA = torch.zeros(As.shape[0], ld(As.shape[1]), dtype=torch.float64, device="cuda")
+    dA[:, : As.shape[1]] = _dev(As)
+    dB = torch.zeros(Bs.shape[0], ld(Bs.shape[1]), dtype=torch.float64, device="cuda")
+    dB[:, : Bs.shape[1]] = _dev(Bs)
+    dC = torch.zeros(M, ld(N), dtype=torch.float64, device="cuda")
+    dC[:, :N] = _dev(C0)
+    gpu_ctx.gemm(tA, tB, M, N, K, 0.7, dA[:, : As.shape[1]], dB[:, : Bs.shape[1]], -1.3, dC[:, :N])
+    ref = 0.7 * A @ B - 1.3 * C0
+    np.testing.assert_allclose(dC[:, :N].cpu().numpy(), ref, rtol=1e-12, atol=1e-11)
+
+
+def test_gemm_masks_and_lower(gpu_ctx):
+    n = 300
+    rng = np.random.default_rng(2)
+    Lo = np.tril(rng.standard_normal((n, n)))
+    junk = rng.standard_normal((n, n)) * 1e6
+    Lj = Lo + np.triu(junk, 1)  # garbage above the diagonal must be ignored
+    X = rng.standard_normal((n, n))
+    dL, dX = _sq(n), _sq(n)
+    dL.copy_(_dev(Lj)); dX.copy_(_dev(X))
+    # NT, B lower [n][k] keep k<=n: X @ Lo^T with khi limited per column tile
+    out = _sq(n)
+    gpu_ctx.gemm(0, 1, n, n, n, 1.0, dX, dL, 0.0, out, b_mask=1, khi_mode=2)
+    np.testing.assert_allclose(out.cpu().numpy(), X @ Lo.T, rtol=1e-12, atol=1e-10)
+    # NN, B lower [k][n] keep k>=n: X @ Lo
+    gpu_ctx.gemm(0, 0, n, n, n, 1.0, dX, dL, 0.0, out, b_mask=2, klo_mode=2)
+    np.testing.assert_allclose(out.cpu().numpy(), X @ Lo, rtol=1e-12, atol=1e-10)
+    # NN, A lower [m][k] keep k<=m: Lo @ X
+    gpu_ctx.gemm(0, 0, n, n, n, 1.0, dL, dX, 0.0, out, a_mask=1, khi_mode=1)
+    np.testing.assert_allclose(out.cpu().numpy(), Lo @ X, rtol=1e-12, atol=1e-10)
+    # TN lauum: Lo^T Lo, lower part only; upper part of `out` must stay untouched
+    out.fill_(7.0)
+    gpu_ctx.gemm(1, 0, n, n, n, 1.0, dL, dL, 0.0, out, a_mask=2, b_mask=2, klo_mode=3, c_lower=1)
+    got = out.cpu().numpy()
+    ref = Lo.T @ Lo
+    np.testing.assert_allclose(np.tril(got), np.tril(ref), rtol=1e-12, atol=1e-10)
+    assert np.all(np.triu(got, 1) == np.triu(np.full((n, n), 7.0), 1))
+
+
+@pytest.mark.parametrize("n,d", [(1, 3), (64, 8), (130, 2), (500, 8), (1000, 12)])
+def test_kernel_build_and_cross(gpu_ctx, n, d):
+    rng = np.random.default_rng(3)
+    U = rng.standard_normal((n, d))
+    w = rng.uniform(0.05, 2.0, d)
+    sf2 = 0.77
+    tau = np.array([1e-3, 2e-2, 0.3])
+    grp = rng.integers(0, 3, n).astype(np.int32)
+    d2 = ((U[:, None, :] - U[None, :, :]) ** 2 * w).sum(-1)
+    ref = sf2 * np.exp(-d2) + np.diag(tau[grp] + 1e-6)
+    dU, dw = _dev(U), _dev(w)
+    dsf2 = torch.tensor([sf2], dtype=torch.float64, device="cuda")
+    out = _sq(n)
+    gpu_ctx.kernel_build(dU, dw, dsf2, _dev(tau), _dev(grp), out, jitter=1e-6)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-13, atol=1e-15)
+    out2 = _sq(n, fill=-5.0)
+    gpu_ctx.kernel_build(dU, dw, dsf2, _dev(tau), _dev(grp), out2, jitter=1e-6, uplo=1)
+    np.testing.assert_allclose(np.tril(out2.cpu().numpy()), np.tril(ref), rtol=1e-13, atol=1e-15)
+    # cross block against a different point set
+    m = 77
+    Ua = rng.standard_normal((m, d))
+    cross = torch.empty(m, (n + 15) // 16 * 16, dtype=torch.float64, device="cuda")[:, :n]
+    gpu_ctx.cross_kernel(_dev(Ua), dU, dw, dsf2, cross)
+    d2c = ((Ua[:, None, :] - U[None, :, :]) ** 2 * w).sum(-1)
+    np.testing.assert_allclose(cross.cpu().numpy(), sf2 * np.exp(-d2c), rtol=1e-13, atol=1e-15)
+
+
+@pytest.mark.parametrize("n", [1, 5, 128, 129, 300, 777, 2048, 4097])
+def test_potrf_trtri_lauum(gpu_ctx, n):
+    U, w, K = _spd(n, seed=n)
+    A, Li, T, Ki = _sq(n), _sq(n), _sq(n), _sq(n)
+    A.copy_(_dev(np.tril(K) + np.triu(np.full((n, n), np.nan), 1)))  # upper triangle must never be read
+    info = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    gpu_ctx.potrf(A, Li, info)
+    assert int(info.item()) == 0
+    Lref = np.linalg.cholesky(K)
+    L = np.tril(A.cpu().numpy())
+    np.testing.assert_allclose(L, Lref, rtol=0, atol=1e-10 * np.abs(Lref).max())
+    gpu_ctx.trtri(A, Li, T)
+    Linv = np.tril(Li.cpu().numpy())
+    np.testing.assert_allclose(Linv @ Lref, np.eye(n), rtol=0, atol=1e-8)
+    gpu_ctx.lauum(Li, Ki)
+    Kinv = np.tril(Ki.cpu().numpy())
+    Kinv = Kinv + np.tril(Kinv, -1).T
+    np.testing.assert_allclose(Kinv @ K, np.eye(n), rtol=0, atol=1e-6)
+
+
+def test_potrf_reports_failing_minor(gpu_ctx):
+    n = 400
+    _, _, K = _spd(n, seed=9)
+    K[250, 250] = -1.0  # leading minor 251 is not positive definite
+    A, Li = _sq(n), _sq(n)
+    A.copy_(_dev(K))
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gpu_ctx.potrf(A, Li, info)
+    assert int(info.item()) == 251
+
+
+@pytest.mark.parametrize("n,d,S,dU", [(300, 5, 1, 0), (777, 8, 3, 2), (1500, 12, 3, 12)])
+def test_mll_and_grad_reduce(gpu_ctx, n, d, S, dU):
+    rng = np.random.default_rng(n)
+    U = rng.standard_normal((n, d))
+    w = rng.uniform(0.05, 0.6, d)
+    sf2 = 0.9
+    tau = rng.uniform(1e-3, 1e-2, S)
+    grp = rng.integers(0, S, n).astype(np.int32)
+    r = rng.standard_normal(n)
+    diff = U[:, None, :] - U[None, :, :]
+    d2 = (diff**2 * w).sum(-1)
+    Kc = sf2 * np.exp(-d2)
+    Ky = Kc + np.diag(tau[grp])
+    cf = sla.cho_factor(Ky, lower=True)
+    alpha = sla.cho_solve(cf, r)
+    quad = r @ alpha
+    logdet = 2 * np.log(np.diag(cf[0])).sum()
+    mll = -0.5 * (quad + logdet + n * np.log(2 * np.pi))
+    Kinv = sla.cho_solve(cf, np.eye(n))
+    W = 0.5 * (np.outer(alpha, alpha) - Kinv)
+    g_w = np.array([(W * Kc * (-(diff[:, :, k] ** 2))).sum() for k in range(d)])
+    g_sf2 = (W * Kc).sum() / sf2
+    g_tau = np.array([np.diag(W)[grp == s].sum() for s in range(S)])
+    g_U = np.stack([2 * (W * Kc * (-2 * w[k]) * diff[:, :, k]).sum(1) for k in range(dU)], 1) if dU else None
+
+    dUm, dw = _dev(U), _dev(w)
+    dsf2 = torch.tensor([sf2], dtype=torch.float64, device="cuda")
+    dgrp = _dev(grp)
+    A, Li, T, Ki = _sq(n), _sq(n), _sq(n), _sq(n)
+    gpu_ctx.kernel_build(dUm, dw, dsf2, _dev(tau), dgrp, A, uplo=1)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gpu_ctx.potrf(A, Li, info)
+    assert int(info.item()) == 0
+    gpu_ctx.trtri(A, Li, T)
+    z = torch.empty(n, dtype=torch.float64, device="cuda")
+    out3 = torch.empty(3, dtype=torch.float64, device="cuda")
+    gpu_ctx.mll_reduce(A, Li, _dev(r), z, out3)
+    o = out3.cpu().numpy()
+    np.testing.assert_allclose(o, [quad, logdet, mll], rtol=1e-9)
+    al = torch.empty(n, dtype=torch.float64, device="cuda")
+    gpu_ctx.alpha(Li, z, al)
+    np.testing.assert_allclose(al.cpu().numpy(), alpha, rtol=1e-7, atol=1e-9 * np.abs(alpha).max())
+    gpu_ctx.lauum(Li, Ki)
+    gw = torch.empty(d, dtype=torch.float64, device="cuda")
+    gs = torch.empty(1, dtype=torch.float64, device="cuda")
+    gt = torch.empty(S, dtype=torch.float64, device="cuda")
+    gU = torch.empty(n, dU, dtype=torch.float64, device="cuda") if dU else None
+    gpu_ctx.grad_reduce(dUm, dw, dsf2, dgrp, S, al, Ki, dU, gw, gs, gt, gU)
+    sc = lambda x: 1e-7 * np.abs(x).max() + 1e-12
+    np.testing.assert_allclose(gw.cpu().numpy(), g_w, rtol=1e-6, atol=sc(g_w))
+    np.testing.assert_allclose(gs.cpu().numpy()[0], g_sf2, rtol=1e-6, atol=sc(g_sf2))
+    np.testing.assert_allclose(gt.cpu().numpy(), g_tau, rtol=1e-6, atol=sc(g_tau))
+    if dU:
+        np.testing.assert_allclose(gU.cpu().numpy(), g_U, rtol=1e-6, atol=sc(g_U))
+
+
+def test_predict(gpu_ctx):
+    n, m, d = 600, 130, 7
+    rng = np.random.default_rng(5)
+    U, w, K = _spd(n, d=d, seed=4)
+    Us = rng.standard_normal((m, d))
+    r = rng.standard_normal(n)
+    d2c = ((Us[:, None, :] - U[None, :, :]) ** 2 * w).sum(-1)
+    Ks = 0.8 * np.exp(-d2c)
+    cf = sla.cho_factor(K, lower=True)
+    alpha = sla.cho_solve(cf, r)
+    mean = Ks @ alpha
+    V = sla.solve_triangular(cf[0], Ks.T, lower=True)
+    var = 0.8 - (V**2).sum(0)
+    A, Li, T = _sq(n), _sq(n), _sq(n)
+    A.copy_(_dev(K))
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gpu_ctx.potrf(A, Li, info)
+    gpu_ctx.trtri(A, Li, T)
+    ldn = (n + 15) // 16 * 16
+    dKs = torch.empty(m, ldn, dtype=torch.float64, device="cuda")[:, :n]
+    dKs.copy_(_dev(Ks))
+    dV = torch.empty(m, ldn, dtype=torch.float64, device="cuda")[:, :n]
+    mo = torch.empty(m, dtype=torch.float64, device="cuda")
+    vo = torch.empty(m, dtype=torch.float64, device="cuda")
+    kss = torch.full((m,), 0.8, dtype=torch.float64, device="cuda")
+    gpu_ctx.predict(Li, _dev(alpha), dKs, kss, dV, mo, vo)
+    np.testing.assert_allclose(mo.cpu().numpy(), mean, rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(vo.cpu().numpy(), var, rtol=1e-6, atol=1e-9)
