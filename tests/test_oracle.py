@@ -1,0 +1,203 @@
+"""Pins the CPU oracle (oracle/gp_oracle.py).  The reference pins nothing for this path (no tests, no stored outputs,
+gpytorch absent), so the oracle is held by: closed forms, an independent numpy/scipy evaluation of the same formulas,
+the analytic-gradient identity, central finite differences, torch.distributions for the priors, and the committed
+golden fixtures whose INPUTS come from the reference's own data pipeline (tests/golden/make_golden.py)."""
+import math
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as sla
+import torch
+
+from oracle import gp_oracle as G
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+def model_from_fixture(fx, tag, **kw):
+    xkey = "Xtrain" if "Xtrain" in fx else "Utrain"
+    o = G.OracleGP(fx[xkey], fx["ytrain"], **kw)
+    for k in list(o.params):
+        o.params[k] = torch.as_tensor(fx[f"{tag}::param::{k}"], dtype=torch.float64)
+    return o
+
+
+def numpy_mll(o: G.OracleGP):
+    """Independent evaluation: direct-difference kernel + scipy Cholesky (no torch, no skinny-GEMM distance)."""
+    p = {k: v.numpy() for k, v in o.params.items()}
+    X = o.train_x.numpy()
+    U = X[:, o.quant_index]
+    if o.kclass == "Rough_RBF":
+        w = 10.0 ** p[o.ls_key].reshape(-1)
+    else:
+        w = 1.0 / (2 * np.exp(2 * p[o.ls_key].reshape(-1)))
+    if o.qual_cols:
+        z = o.zeta.numpy()[o.cat_index.numpy()] @ p[o.latent_key].T
+        U = np.hstack([z, U])
+        w = np.concatenate([np.full(o.dz, 0.5), w])
+    d2 = ((U[:, None, :] - U[None, :, :]) ** 2 * w).sum(-1)
+    sf2 = np.log1p(np.exp(p["covar_module.raw_outputscale"]))
+    tau = np.exp(p["likelihood.noise_covar.raw_noise"]) + o.lb_noise
+    if o.noise_indices:
+        tau_i = tau[X[:, -1].astype(int)]
+    else:
+        tau_i = np.full(len(X), tau[0])
+    m = o.mean(o.train_x).numpy()
+    Ky = sf2 * np.exp(-d2) + np.diag(tau_i)
+    cf = sla.cho_factor(Ky, lower=True)
+    r = o.y_sc.numpy() - m
+    alpha = sla.cho_solve(cf, r)
+    mll = -0.5 * (r @ alpha + 2 * np.log(np.diag(cf[0])).sum() + len(r) * math.log(2 * math.pi))
+    return mll, Ky, alpha, U, w, sf2
+
+
+def test_closed_form_n1():
+    o = G.OracleGP(np.array([[0.3, -1.0]]), np.array([2.0]))
+    # y-scaling with one point divides by zero in the reference too (gpregression.py:67-69); bypass with explicit y_sc
+    o.y_sc = torch.tensor([0.7], dtype=torch.float64)
+    o.params["mean_module.constant"] = torch.tensor([0.2], dtype=torch.float64)
+    sf2, tau = math.log(2.0), 1.0 + 1e-8
+    r = 0.7 - 0.2
+    ref = -0.5 * (r * r / (sf2 + tau) + math.log(sf2 + tau) + math.log(2 * math.pi))
+    assert abs(o.mll().item() - ref) < 1e-14
+
+
+def test_closed_form_duplicate_rows():
+    # two identical rows: K = sf2 * ones(2,2); PD only through the noise
+    X = np.array([[0.5, 1.0, -0.2], [0.5, 1.0, -0.2], [0.1, 0.0, 0.3]])
+    o = G.OracleGP(X[:2], np.array([1.0, 3.0]))
+    o.params["likelihood.noise_covar.raw_noise"] = torch.tensor([-3.0], dtype=torch.float64)
+    s, t = math.log(2.0), math.exp(-3.0) + 1e-8
+    y = np.array([0.0, 1.0])
+    det = (s + t) ** 2 - s * s
+    Kinv = np.array([[s + t, -s], [-s, s + t]]) / det
+    ref = -0.5 * (y @ Kinv @ y + math.log(det) + 2 * math.log(2 * math.pi))
+    assert abs(o.mll().item() - ref) < 1e-12
+
+
+def test_w_to_zero_sherman_morrison():
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((40, 3))
+    o = G.OracleGP(X, rng.standard_normal(40), m_gp="single_zero")
+    o.params[o.ls_key] = torch.full((1, 3), -40.0, dtype=torch.float64)  # w = 1e-40 -> K = sf2 * 11^T
+    s, t, n = math.log(2.0), 1.0 + 1e-8, 40
+    y = o.y_sc.numpy()
+    quad = (y @ y) / t - s * y.sum() ** 2 / (t * (t + n * s))
+    logdet = (n - 1) * math.log(t) + math.log(t + n * s)
+    ref = -0.5 * (quad + logdet + n * math.log(2 * math.pi))
+    assert abs(o.mll().item() - ref) < 1e-9 * abs(ref)
+
+
+@pytest.mark.parametrize("fixture,tag,kw", [
+    ("c1_borehole_n500.npz", "theta0", {}),
+    ("c1_borehole_n500.npz", "theta1", {}),
+    ("c3_borehole_mixed_n100.npz", "theta1", {"qual_dict": {0: 5, 5: 5}}),
+    ("c4_wing_mf_n300.npz", "theta1", {"qual_dict": {10: 3}, "multiple_noise": True, "m_gp": "multiple_constant"}),
+])
+def test_against_numpy_scipy_and_golden(fixture, tag, kw):
+    fx = load(fixture)
+    o = model_from_fixture(fx, tag, **kw)
+    mll_np, Ky, alpha, U, w, sf2 = numpy_mll(o)
+    mll = o.mll().item()
+    assert abs(mll - mll_np) <= 1e-10 * abs(mll_np)            # GEMM-distance vs direct-difference, torch vs scipy
+    assert abs(mll - fx[f"{tag}::mll"]) <= 1e-12 * abs(mll)     # committed fixture
+    loss, grads = o.loss_and_grad()
+    assert abs(loss.item() - fx[f"{tag}::loss"]) <= 1e-12 * abs(loss.item())
+    for k, g in grads.items():
+        np.testing.assert_allclose(g.numpy(), fx[f"{tag}::grad::{k}"], rtol=1e-9, atol=1e-13)
+    # analytic identity dMLL/dtheta = sum W * dKy/dtheta, W = 0.5 (alpha alpha^T - Ky^-1), for the kernel weights
+    Kinv = sla.cho_solve(sla.cho_factor(Ky, lower=True), np.eye(len(Ky)))
+    W = 0.5 * (np.outer(alpha, alpha) - Kinv)
+    Kc = Ky - np.diag(np.diag(Ky)) + np.diag(np.full(len(Ky), sf2))
+    dq = len(o.quant_index)
+    g_omega = np.array([(W * Kc * (-(U[:, None, o.dz + d] - U[None, :, o.dz + d]) ** 2)).sum() * math.log(10) * w[o.dz + d]
+                        for d in range(dq)])
+    prior_g = -(o.params[o.ls_key].numpy().reshape(-1) + 3.0) / 9.0  # d/domega log N(-3, 3)
+    expect = -(g_omega + prior_g) / o.N
+    np.testing.assert_allclose(grads[o.ls_key].numpy().reshape(-1), expect, rtol=1e-7, atol=1e-12)
+
+
+def test_finite_differences_every_parameter():
+    fx = load("c4_wing_mf_n300.npz")
+    o = model_from_fixture(fx, "theta1", qual_dict={10: 3}, multiple_noise=True, m_gp="multiple_constant")
+    _, grads = o.loss_and_grad()
+    h = 1e-5
+    for k in o.trainable:
+        flat = o.params[k].reshape(-1)
+        g = grads[k].reshape(-1)
+        for i in range(flat.numel()):
+            old = flat[i].item()
+            flat[i] = old + h
+            fp = o.loss().item()
+            flat[i] = old - h
+            fm = o.loss().item()
+            flat[i] = old
+            fd = (fp - fm) / (2 * h)
+            assert abs(fd - g[i].item()) <= 2e-6 * max(1.0, abs(fd)), (k, i, fd, g[i].item())
+
+
+def test_priors_against_torch_distributions():
+    x = torch.linspace(-4, 3, 11, dtype=torch.float64)
+    np.testing.assert_allclose(G.normal_log_prob(x, -3.0, 3.0), torch.distributions.Normal(torch.tensor(-3.0, dtype=torch.float64), torch.tensor(3.0, dtype=torch.float64)).log_prob(x), rtol=1e-13)
+    xp = x.exp()
+    np.testing.assert_allclose(G.lognormal_log_prob(xp, 1e-6, 1.0), torch.distributions.LogNormal(torch.tensor(1e-6, dtype=torch.float64), torch.tensor(1.0, dtype=torch.float64)).log_prob(xp), rtol=1e-13)
+    a, b = math.log(0.1), math.log(10)
+    inside = G.mollified_uniform_log_prob(torch.tensor([0.0], dtype=torch.float64), a, b)
+    expect_in = torch.distributions.Normal(torch.tensor(0.0, dtype=torch.float64), torch.tensor(0.1, dtype=torch.float64)).log_prob(torch.tensor(0.0, dtype=torch.float64)) - math.log(1 + (b - a) / (math.sqrt(2 * math.pi) * 0.1))
+    assert abs(inside.item() - expect_in.item()) < 1e-13
+    outside = G.mollified_uniform_log_prob(torch.tensor([b + 0.25], dtype=torch.float64), a, b)
+    assert abs((inside - outside).item() - 0.5 * (0.25 / 0.1) ** 2) < 1e-12
+    raw = torch.tensor([-6.0, 0.0, 2.0], dtype=torch.float64)
+    hs = G.log_half_horseshoe_log_prob(raw, 0.01, 1e-8)
+    np.testing.assert_allclose(hs, np.log(np.log(1 + 3 * (0.01 / (1e-8 + np.exp(raw.numpy()))) ** 2)) + raw.numpy(), rtol=1e-13)
+
+
+def test_transforms():
+    x = torch.tensor([-3.0, 0.0, 2.5], dtype=torch.float64)
+    np.testing.assert_allclose(G.inv_softplus(G.softplus(x)), x, rtol=1e-12)
+    assert abs(G.softplus(torch.tensor(0.0, dtype=torch.float64)).item() - math.log(2)) < 1e-15
+    # Rough lengthscale <-> weight: 1/(2 l^2) = 10^omega  
+    om = torch.tensor([-1.0, 0.0, 1.5], dtype=torch.float64)
+    np.testing.assert_allclose(1 / (2 * G.rough_lengthscale(om) ** 2), 10.0 ** om.numpy(), rtol=1e-13)
+
+
+def test_literal_moment_matching_is_a_noop():
+    fx = load("c1_borehole_n500.npz")
+    o = model_from_fixture(fx, "theta1")
+    a, b = o.mll().item(), o.mll(literal_moment_matching=True).item()
+    assert abs(a - b) <= 1e-9 * abs(a)
+
+
+def test_jitter_retry_and_errors():
+    A = torch.tensor([[1.0, 1.0], [1.0, 1.0 - 1e-12]], dtype=torch.float64)
+    with pytest.warns(RuntimeWarning):
+        L, jit = G.psd_safe_cholesky(A)
+    assert jit == 1e-8
+    with pytest.raises(G.NotPSDError):
+        G.psd_safe_cholesky(torch.tensor([[1.0, 2.0], [2.0, 1.0]], dtype=torch.float64))
+    with pytest.raises(G.NanError):
+        G.psd_safe_cholesky(torch.tensor([[float("nan"), 0.0], [0.0, 1.0]], dtype=torch.float64))
+
+
+def test_predict_matches_numpy():
+    fx = load("c1_borehole_n500.npz")
+    o = model_from_fixture(fx, "theta1")
+    mean, std = o.predict(fx["Xtest"], return_std=True, include_noise=True)
+    np.testing.assert_allclose(mean.numpy(), fx["theta1::pred_mean"], rtol=1e-11)
+    np.testing.assert_allclose(std.numpy(), fx["theta1::pred_std"], rtol=1e-9)
+    _, Ky, alpha, U, w, sf2 = numpy_mll(o)
+    Xs = fx["Xtest"]
+    d2 = ((Xs[:, None, :] - U[None, :, :]) ** 2 * w).sum(-1)
+    Ks = sf2 * np.exp(-d2)
+    m = o.params["mean_module.constant"].item()
+    mu = o.y_min.item() + o.y_std.item() * (m + Ks @ alpha)
+    np.testing.assert_allclose(mean.numpy(), mu, rtol=1e-8)
+    V = sla.solve_triangular(np.linalg.cholesky(Ky), Ks.T, lower=True)
+    tau = math.exp(o.params["likelihood.noise_covar.raw_noise"].item()) + o.lb_noise
+    sd = np.sqrt(np.maximum(sf2 - (V**2).sum(0) + tau, 1e-10)) * o.y_std.item()
+    np.testing.assert_allclose(std.numpy(), sd, rtol=1e-6)
