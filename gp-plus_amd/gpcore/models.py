@@ -1,0 +1,76 @@
+"""``ExactGP`` (gpytorch.models.ExactGP subset): train-mode call returns the prior at the training inputs, eval-mode
+call returns the exact predictive distribution through a cached factorisation (gpytorch's prediction strategy),
+computed by the HIP back end (linalg.factorize / predict_from_cache)."""
+from __future__ import annotations
+
+import warnings
+
+import torch
+
+from .distributions import DenseCovariance, MultivariateNormal
+from .kernels import LazyKernelMatrix
+from .module import Module
+
+
+class GP(Module):
+    pass
+
+
+class ExactGP(GP):
+    def __init__(self, train_inputs, train_targets, likelihood):
+        if train_inputs is not None and torch.is_tensor(train_inputs):
+            train_inputs = (train_inputs,)
+        super().__init__()
+        self.train_inputs = None if train_inputs is None else tuple(
+            (i.unsqueeze(-1) if i.ndimension() == 1 else i) for i in train_inputs)
+        self.train_targets = train_targets
+        self.likelihood = likelihood
+        self.prediction_strategy = None
+
+    def _apply(self, fn, *args, **kwargs):
+        if self.train_inputs is not None:
+            self.train_inputs = tuple(fn(t) for t in self.train_inputs)
+            self.train_targets = fn(self.train_targets)
+        return super()._apply(fn, *args, **kwargs)
+
+    def train(self, mode: bool = True):
+        if mode:
+            self.prediction_strategy = None
+        return super().train(mode)
+
+    def __call__(self, *args, **kwargs):
+        inputs = [a.unsqueeze(-1) if torch.is_tensor(a) and a.ndimension() == 1 else a for a in args]
+        if self.training:
+            if self.train_inputs is None:
+                raise RuntimeError("train_inputs, train_targets cannot be None in training mode.")
+            if not all(torch.equal(ti, x) for ti, x in zip(self.train_inputs, inputs)):
+                raise RuntimeError("You must train on the training inputs!")
+            return Module.__call__(self, *inputs, **kwargs)
+        # ---- posterior mode -----------------------------------------------------------------------
+        from ..linalg import factorize, predict_from_cache, cross_kernel
+
+        with torch.no_grad():
+            if self.prediction_strategy is None:
+                train_out = Module.__call__(self, *self.train_inputs, **kwargs)
+                cov = train_out.lazy_covariance_matrix
+                if not isinstance(cov, LazyKernelMatrix):
+                    raise RuntimeError("exact prediction needs the model's forward to return a lazy kernel covariance")
+                noisy = self.likelihood(train_out).lazy_covariance_matrix
+                self.prediction_strategy = factorize(cov.U1, cov.spec, noisy.tau, noisy.grp, train_out.mean, self.train_targets)
+            cache = self.prediction_strategy
+            test_out = Module.__call__(self, *inputs, **kwargs)
+            tcov = test_out.lazy_covariance_matrix
+            Us = tcov.U1.to(torch.float64).contiguous()
+            mean_c, var, V = predict_from_cache(cache, Us, need_var=True, need_V=True)
+            pred_mean = test_out.mean.to(torch.float64) + mean_c
+
+            def full_cov(Us=Us, V=V, spec=cache.spec, gctx=cache.gctx):
+                from ..backend import square_buffer
+
+                M = Us.shape[0]
+                Kss = LazyKernelMatrix(Us, None, spec).evaluate()
+                # Kss - V V^T through the MFMA GEMM (NT, lower + mirrored by symmetry)
+                gctx.gemm(0, 1, M, M, V.shape[1], -1.0, V, V, 1.0, Kss)
+                return Kss
+
+            return MultivariateNormal(pred_mean, DenseCovariance(var, full_cov))

@@ -1,0 +1,35 @@
+"""The handful of gpytorch.settings the path touches.  ``fast_computations`` is accepted and ignored: this back end is
+always the exact Cholesky path (the reference forces it with ``fast_computations(log_prob=False)`` at
+models/gpregression.py:127,161 and optim/mll_scipy.py:217; optim/mll_torch.py does not, SURVEY.md hazard B-2)."""
+from contextlib import contextmanager
+
+
+class _Value:
+    def __init__(self, default):
+        self._v = default
+
+    def value(self, *_):
+        return self._v
+
+    @contextmanager
+    def __call__(self, v):
+        old, self._v = self._v, v
+        try:
+            yield
+        finally:
+            self._v = old
+
+
+cholesky_jitter = _Value(1e-8)      # gpytorch.settings.cholesky_jitter (double)
+cholesky_max_tries = _Value(3)      # gpytorch.settings.cholesky_max_tries
+min_variance = _Value(1e-10)        # gpytorch.settings.min_variance (double)
+
+
+@contextmanager
+def fast_computations(covar_root_decomposition=True, log_prob=True, solves=True):
+    yield
+
+
+@contextmanager
+def max_cholesky_size(_n):
+    yield

@@ -1,0 +1,266 @@
+"""Exact-GP linear algebra on the MI355X: one ``torch.autograd.Function`` whose forward and backward are sequences
+of libgpp_hip calls (no ATen linear algebra, no CPU fallback).
+
+Replaces, for the path ``optim/mll_torch.py:114-117``:
+  forward  = gpytorch ``MultivariateNormal.log_prob`` -> ``inv_quad_logdet`` -> ``psd_safe_cholesky``
+             (kernel build K1-K4, Cholesky K5, solve + logdet + quadratic form K6)
+  backward = ATen ``cholesky_backward`` + the backward of every N^2 kernel op (K7): Ky^-1 by trtri + lauum, then ONE
+             tiled reduction of W = (alpha alpha^T - Ky^-1)/2 against dKy/dtheta.
+Jitter policy restates gpytorch.utils.cholesky.psd_safe_cholesky [3P]: 1e-8 * 10^i, i = 0..2 (fp64), warn, then
+``NotPSDError``; NaN inputs raise ``NanError``.
+"""
+from __future__ import annotations
+
+import warnings
+from dataclasses import dataclass
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .backend import (KIND_RBF, OP_MLL_EVAL, UPLO_FULL, UPLO_LOWER, GppContext, get_context, square_buffer)
+from .gpcore.errors import NanError, NotPSDError
+from .gpcore import settings
+
+__all__ = ["KernelSpec", "exact_mll", "ExactMLLFunction", "EvalWorkspace", "dense_kernel", "cross_kernel",
+           "FactorCache", "factorize", "dense_log_prob"]
+
+
+@dataclass
+class KernelSpec:
+    """What the fused tile kernel needs: K_ij = sf2 * k(sum_d w_d (u_id-u_jd)^2).  All tensors live on the GPU."""
+    w: torch.Tensor            # (D,) weights, autograd-connected to the raw lengthscales
+    sf2: torch.Tensor          # () outputscale, autograd-connected
+    kind: int = KIND_RBF
+    d_split: int = 0
+
+
+class EvalWorkspace:
+    """Device buffers of one N-point evaluation, reused across evaluations (3 N x N fp64 matrices: Ky->L, Linv,
+    scratch/Kinv).  ``epoch`` increments on every forward so a stale backward can tell its factors were overwritten."""
+
+    def __init__(self, ctx: GppContext, N: int):
+        dev = ctx.device
+        self.N = N
+        self.A = square_buffer(N, dev)
+        self.Li = square_buffer(N, dev)
+        self.Ki = square_buffer(N, dev)
+        self.z = torch.empty(N, dtype=torch.float64, device=dev)
+        self.alpha = torch.empty(N, dtype=torch.float64, device=dev)
+        self.r = torch.empty(N, dtype=torch.float64, device=dev)
+        self.out3 = torch.empty(3, dtype=torch.float64, device=dev)
+        self.info = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.epoch = 0
+
+
+_workspaces: Dict[Tuple[int, int, int], EvalWorkspace] = {}
+
+
+def get_workspace(ctx: GppContext, N: int, slot: int = 0) -> EvalWorkspace:
+    key = (ctx.index, N, slot)
+    ws = _workspaces.get(key)
+    if ws is None:
+        # keep at most one size per (device, slot): drop others so 3 x 8 N^2 bytes are not held per historical N
+        for k in [k for k in _workspaces if k[0] == ctx.index and k[2] == slot]:
+            del _workspaces[k]
+        ws = EvalWorkspace(ctx, N)
+        _workspaces[key] = ws
+    return ws
+
+
+def _as_f64(t: torch.Tensor, device) -> torch.Tensor:
+    return t.to(device=device, dtype=torch.float64).contiguous()
+
+
+def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_split) -> float:
+    """Build Ky (lower) and factor it, with gpytorch's jitter-retry policy.  Returns the jitter that was needed."""
+    jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
+    for jit in jitters:
+        ctx.kernel_build(U, w, sf2, tau, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_LOWER)
+        ctx.potrf(ws.A, ws.Li, ws.info)
+        info = int(ws.info.item())  # the one host sync of an evaluation (the reference syncs on loss.item() too)
+        if info == 0:
+            if jit > 0:
+                warnings.warn(f"A not p.d., added jitter of {jit:.1e} to the diagonal", RuntimeWarning)
+            return jit
+        if jit == 0.0:
+            bad = [n for n, t in (("inputs", U), ("weights", w), ("outputscale", sf2), ("noise", tau)) if not torch.isfinite(t).all()]
+            if bad:
+                raise NanError(f"cholesky: NaN/Inf in {', '.join(bad)} of the covariance")
+    raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitters[-1]:.1e} "
+                      f"(leading minor {info}).")
+
+
+class ExactMLLFunction(torch.autograd.Function):
+    """mll = log N(y | mean, sf2*k(U,U;w) + diag(tau[grp]))  with gradients for U[:, :dU], w, sf2, tau, mean, y."""
+
+    @staticmethod
+    def forward(ctx, U, w, sf2, tau, mean, y, grp, kind, d_split, dU, slot):
+        dev = U.device
+        gctx = get_context(dev)
+        N, D = U.shape
+        Ud, wd, sd, td = _as_f64(U.detach(), dev), _as_f64(w.detach(), dev), _as_f64(sf2.detach().reshape(1), dev), \
+            _as_f64(tau.detach().reshape(-1), dev)
+        S = td.numel()
+        if grp is not None and grp.dtype != torch.int32:
+            grp = grp.to(torch.int32)
+        ws = get_workspace(gctx, N, slot)
+        ws.epoch += 1
+        jit = _factor(gctx, ws, Ud, wd, sd, td, grp, kind, d_split)
+        gctx.trtri(ws.A, ws.Li, ws.Ki)
+        torch.sub(_as_f64(y.detach(), dev), _as_f64(mean.detach(), dev), out=ws.r)
+        gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
+        ctx.saved = (gctx, ws, ws.epoch, Ud, wd, sd, td, grp, S, kind, d_split, dU, jit, ws.r.clone())
+        ctx.in_dtypes = (U.dtype, w.dtype, sf2.dtype, tau.dtype, mean.dtype, y.dtype)
+        ctx.shapes = (sf2.shape, tau.shape)
+        return ws.out3[2].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        gctx, ws, epoch, Ud, wd, sd, td, grp, S, kind, d_split, dU, jit, r_saved = ctx.saved
+        N, D = Ud.shape
+        dev = Ud.device
+        if ws.epoch != epoch:
+            # another forward reused the buffers: rebuild this evaluation's factors (correct, costs one extra potrf)
+            ws.epoch += 1
+            gctx.kernel_build(Ud, wd, sd, td, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_LOWER)
+            gctx.potrf(ws.A, ws.Li, ws.info)
+            gctx.trtri(ws.A, ws.Li, ws.Ki)
+            ws.r.copy_(r_saved)
+            gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
+        gctx.alpha(ws.Li, ws.z, ws.alpha)
+        gctx.lauum(ws.Li, ws.Ki)
+        g_w = torch.empty(D, dtype=torch.float64, device=dev)
+        g_s = torch.empty(1, dtype=torch.float64, device=dev)
+        g_t = torch.empty(S, dtype=torch.float64, device=dev)
+        need_U = ctx.needs_input_grad[0] and dU > 0
+        g_U = torch.zeros(N, D, dtype=torch.float64, device=dev) if ctx.needs_input_grad[0] else None
+        g_Ud = torch.empty(N, dU, dtype=torch.float64, device=dev) if need_U else None
+        gctx.grad_reduce(Ud, wd, sd, grp, S, ws.alpha, ws.Ki, dU if need_U else 0, g_w, g_s, g_t, g_Ud, kind=kind,
+                         d_split=d_split)
+        if need_U:
+            g_U[:, :dU] = g_Ud
+        go = grad_out.to(torch.float64)
+        dt = ctx.in_dtypes
+        sf2_shape, tau_shape = ctx.shapes
+        alpha = ws.alpha
+        return (None if g_U is None else (go * g_U).to(dt[0]),
+                (go * g_w).to(dt[1]) if ctx.needs_input_grad[1] else None,
+                (go * g_s).reshape(sf2_shape).to(dt[2]) if ctx.needs_input_grad[2] else None,
+                (go * g_t).reshape(tau_shape).to(dt[3]) if ctx.needs_input_grad[3] else None,
+                (go * alpha).to(dt[4]) if ctx.needs_input_grad[4] else None,
+                (-go * alpha).to(dt[5]) if ctx.needs_input_grad[5] else None,
+                None, None, None, None, None)
+
+
+def exact_mll(U: torch.Tensor, spec: KernelSpec, tau: torch.Tensor, mean: torch.Tensor, y: torch.Tensor,
+              grp: Optional[torch.Tensor] = None, n_grad_dims: Optional[int] = None, slot: int = 0) -> torch.Tensor:
+    """log N(y | mean, Ky) on the GPU; differentiable w.r.t. U[:, :n_grad_dims], spec.w, spec.sf2, tau, mean, y."""
+    if n_grad_dims is None:
+        n_grad_dims = U.shape[1] if U.requires_grad else 0
+    return ExactMLLFunction.apply(U, spec.w, spec.sf2, tau, mean, y, grp, spec.kind, spec.d_split, int(n_grad_dims), slot)
+
+
+# ---------------------------------------------------------------------------------------------------
+# dense evaluations (no autograd): .evaluate(), cross covariances, prediction
+# ---------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def dense_kernel(U: torch.Tensor, spec: KernelSpec, tau: Optional[torch.Tensor] = None,
+                 grp: Optional[torch.Tensor] = None, jitter: float = 0.0) -> torch.Tensor:
+    """Dense N x N covariance (full symmetric) — what ``lazy.evaluate()`` returns (models/gp_plus.py:474)."""
+    dev = U.device
+    gctx = get_context(dev)
+    N = U.shape[0]
+    out = square_buffer(N, dev)
+    gctx.kernel_build(_as_f64(U, dev), _as_f64(spec.w, dev), _as_f64(spec.sf2.reshape(1), dev),
+                      None if tau is None else _as_f64(tau.reshape(-1), dev),
+                      None if grp is None else grp.to(torch.int32), out, jitter=jitter, kind=spec.kind,
+                      d_split=spec.d_split, uplo=UPLO_FULL)
+    return out
+
+
+@torch.no_grad()
+def cross_kernel(Ua: torch.Tensor, Ub: torch.Tensor, spec: KernelSpec) -> torch.Tensor:
+    dev = Ua.device
+    gctx = get_context(dev)
+    M, N = Ua.shape[0], Ub.shape[0]
+    ld = max(16, (N + 15) // 16 * 16)
+    out = torch.empty((M, ld), dtype=torch.float64, device=dev)[:, :N]
+    gctx.cross_kernel(_as_f64(Ua, dev), _as_f64(Ub, dev), _as_f64(spec.w, dev), _as_f64(spec.sf2.reshape(1), dev), out,
+                      kind=spec.kind, d_split=spec.d_split)
+    return out
+
+
+class FactorCache:
+    """Cholesky factor, its inverse and alpha = Ky^-1 (y - m) of the training covariance: the analogue of gpytorch's
+    prediction strategy caches (mean_cache / covar_cache) used by models/gpregression.py:122-149."""
+
+    def __init__(self, gctx, L, Linv, alpha, U, spec, jitter):
+        self.gctx, self.L, self.Linv, self.alpha, self.U, self.spec, self.jitter = gctx, L, Linv, alpha, U, spec, jitter
+
+
+@torch.no_grad()
+def factorize(U, spec: KernelSpec, tau, grp, mean, y) -> FactorCache:
+    dev = U.device
+    gctx = get_context(dev)
+    N = U.shape[0]
+    Ud, wd = _as_f64(U, dev), _as_f64(spec.w, dev)
+    sd, td = _as_f64(spec.sf2.reshape(1), dev), _as_f64(tau.reshape(-1), dev)
+    if grp is not None:
+        grp = grp.to(torch.int32)
+    ws = get_workspace(gctx, N, slot=-1)
+    ws.epoch += 1
+    jit = _factor(gctx, ws, Ud, wd, sd, td, grp, spec.kind, spec.d_split)
+    gctx.trtri(ws.A, ws.Li, ws.Ki)
+    torch.sub(_as_f64(y, dev), _as_f64(mean, dev), out=ws.r)
+    gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
+    gctx.alpha(ws.Li, ws.z, ws.alpha)
+    return FactorCache(gctx, ws.A, ws.Li, ws.alpha.clone(), Ud, KernelSpec(wd, sd.reshape(()), spec.kind, spec.d_split), jit)
+
+
+@torch.no_grad()
+def predict_from_cache(cache: FactorCache, Us: torch.Tensor, need_var: bool = True, need_V: bool = False):
+    """K8: mean contribution K_*N alpha and prior-minus-explained variance; optionally V = K_*N Linv^T."""
+    dev = Us.device
+    gctx = cache.gctx
+    Ksn = cross_kernel(Us, cache.U, cache.spec)
+    M, N = Ksn.shape
+    mean = torch.empty(M, dtype=torch.float64, device=dev)
+    var = torch.empty(M, dtype=torch.float64, device=dev) if need_var else None
+    V = None
+    kss = None
+    if need_var or need_V:
+        V = torch.empty((M, Ksn.stride(0)), dtype=torch.float64, device=dev)[:, :N]
+        kss = cache.spec.sf2.reshape(1).expand(M).contiguous()
+        if var is None:
+            var = torch.empty(M, dtype=torch.float64, device=dev)
+    gctx.predict(cache.Linv, cache.alpha, Ksn, kss, V, mean, var)
+    return mean, var, V
+
+
+@torch.no_grad()
+def dense_log_prob(cov: torch.Tensor, diff: torch.Tensor) -> torch.Tensor:
+    """log N(diff | 0, cov) for a dense covariance (used by ``evaluation``'s joint NLPD, models/gp_plus.py:900-903)."""
+    dev = cov.device
+    gctx = get_context(dev)
+    N = cov.shape[0]
+    A = square_buffer(N, dev)
+    A.copy_(cov)
+    Li, T = square_buffer(N, dev), square_buffer(N, dev)
+    info = torch.zeros(1, dtype=torch.int32, device=dev)
+    jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
+    prev = 0.0
+    for jit in jitters:
+        if jit > 0:
+            A.copy_(cov)
+            A.diagonal().add_(jit)
+        gctx.potrf(A, Li, info)
+        if int(info.item()) == 0:
+            break
+        prev = jit
+    else:
+        raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {prev:.1e}.")
+    gctx.trtri(A, Li, T)
+    z = torch.empty(N, dtype=torch.float64, device=dev)
+    out3 = torch.empty(3, dtype=torch.float64, device=dev)
+    gctx.mll_reduce(A, Li, _as_f64(diff, dev), z, out3)
+    return out3[2].clone()

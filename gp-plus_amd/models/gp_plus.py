@@ -1,0 +1,475 @@
+"""``GP_Plus``: GP+'s model class (reference: models/gp_plus.py:46-1461) for the deterministic exact-GP path, on the
+HIP back end.  Same constructor signature, ``fit`` / ``predict`` / ``evaluation`` / ``score`` / ``get_params`` API,
+buffers and state_dict keys.
+
+What runs differently from the reference, by design:
+  * ``forward`` returns a LAZY covariance (features U, weights w, outputscale): nothing N x N is allocated in Python;
+    the reference's per-pass ``Sigma_sum`` moment matching (gp_plus.py:396,474-482) is the identity for the single
+    deterministic pass and is dropped;
+  * the two O(N) interpreter loops per forward (``transform_categorical`` gp_plus.py:1085, ``multi_mean``
+    gp_plus.py:532-534) become one cached integer index + gather;
+  * the model is placed on ``device`` at construction (the reference moves it in ``fit``, gp_plus.py:562).
+Out of scope (raise ``NotImplementedError``): probabilistic embedding / calibration (stochastic multi-pass
+ensembles), neural-network and polynomial mean functions, plotting, Sobol indices, botorch glue.
+"""
+import math
+import warnings
+from itertools import product
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import kernels
+from ..gpcore import ConstantMean, MultivariateNormal, NormalPrior, Positive, ZeroMean
+from ..gpcore import metrics as gpmetrics
+from ..optim import fit_model_torch
+from ..preprocessing import setlevels
+from ..priors import MollifiedUniformPrior
+from ..utils import data_type_check, set_seed  # noqa: F401
+from .gpregression import GPR
+
+_QUANT_CLASSES = ['Rough_RBF', 'RBFKernel', 'Matern32Kernel', 'Matern12Kernel', 'Matern52Kernel']
+
+
+def _rough_transform(x):
+    return 2.0 ** (-0.5) * torch.pow(10, -x / 2)
+
+
+def _rough_inv_transform(x):
+    # the reference registers -2 log10(x/2) (gp_plus.py:252), which is NOT the inverse of the transform; kept as is
+    return -2.0 * torch.log10(x / 2.0)
+
+
+class GP_Plus(GPR):
+    def __init__(self, train_x: torch.Tensor, train_y: torch.Tensor, dtype=torch.float, device="cpu", qual_dict={},
+                 multiple_noise=False, lb_noise: float = 1e-8, fix_noise: bool = False, fix_noise_val: float = 1e-5,
+                 quant_correlation_class: str = 'Rough_RBF', fixed_length_scale: bool = False,
+                 fixed_length_scale_val=torch.tensor([1.0]), encoding_type='one-hot', embedding_dim: int = 2,
+                 separate_embedding=[], embedding_type='deterministic', NN_layers_embedding: list = [],
+                 m_gp='single_constant', m_gp_ref='zero', NN_layers_m_gp=[], calibration_type='deterministic',
+                 calibration_id=[], mean_prior_cal=None, std_prior_cal=None, interval_score=False, num_pass_train=1,
+                 num_pass_pred=1, seed_number=1) -> None:
+        self.mean_prior_cal = [0 for _ in calibration_id] if mean_prior_cal is None else mean_prior_cal
+        self.std_prior_cal = [1 for _ in calibration_id] if std_prior_cal is None else std_prior_cal
+        self.interval_score = interval_score
+        self.tkwargs = {'dtype': dtype, 'device': torch.device(device)}
+        self.fixed_length_scale_val = fixed_length_scale_val.to(**self.tkwargs) if fixed_length_scale else None
+
+        train_x = data_type_check(train_x)
+        train_y = data_type_check(train_y)
+        # argument validation: gp_plus.py:141-182
+        if not isinstance(qual_dict, dict):
+            raise ValueError("qual_dict should be a dictionary.")
+        if multiple_noise not in [True, False]:
+            raise ValueError("multiple_noise should be either True or False.")
+        if not isinstance(embedding_dim, int):
+            raise ValueError("embedding_dim should be an integer.")
+        if quant_correlation_class not in _QUANT_CLASSES:
+            raise ValueError("quant_correlation_class should be 'Rough_RBF', 'RBFKernel', 'Matern32Kernel', 'Matern12Kernel','Matern52Kernel'.")
+        if fix_noise not in [True, False]:
+            raise ValueError("fix_noise should be either True or False.")
+        if not isinstance(NN_layers_embedding, list) or not all(isinstance(i, int) for i in NN_layers_embedding):
+            raise ValueError("NN_layers_embedding should be a list of integers representing the number of neurons in each layer.")
+        if encoding_type != 'one-hot':
+            raise ValueError("encoding_type should be 'one-hot'.")
+        if embedding_type not in ['deterministic', 'probabilistic']:
+            raise ValueError("embedding_type should be either 'deterministic' or 'probabilistic'.")
+        if not isinstance(separate_embedding, list) or not all(isinstance(i, int) for i in separate_embedding):
+            raise ValueError("separate_embedding should be a list with integers showing the number of categorical inputs to be considered in a separate manifold in each layer.")
+        if not isinstance(NN_layers_m_gp, list) or not all(isinstance(i, int) for i in NN_layers_m_gp):
+            raise ValueError("NN_layers_m_gp should be a list with integers representing the number of neurons in each layer for the mean function.")
+        if not isinstance(calibration_id, list) or not all(isinstance(i, int) for i in calibration_id):
+            raise ValueError("calibration_id should be a list where each entry shows the column number in the dataset that the calibration parameters are assigned to.")
+        # scope of this build
+        if embedding_type == 'probabilistic' or calibration_type in ('probabilistic', 'probabelistic'):
+            raise NotImplementedError("probabilistic embedding/calibration (stochastic multi-pass ensembles, "
+                                      "gp_plus.py:387-392,414-461) is outside the exact-GP hot path of this build")
+        if len(calibration_id) > 0:
+            raise NotImplementedError("calibration parameters (gp_plus.py:311-320,440-461) are outside this build's scope")
+        if len(separate_embedding) > 0:
+            raise NotImplementedError("separate_embedding is effectively broken in the reference (SURVEY.md B-5)")
+        if m_gp not in ('single_constant', 'single_zero', 'multiple_constant'):
+            raise NotImplementedError(f"mean function '{m_gp}' is outside this build's scope "
+                                      "(single_constant, single_zero, multiple_constant are supported)")
+
+        train_x = self.fill_nan_with_mean(train_x, calibration_id)
+        self.seed = seed_number
+        self.calibration_id = calibration_id
+        self.calibration_source_index = 0
+        self.calibration_type = calibration_type
+        # index bookkeeping: gp_plus.py:190-217
+        qual_dict_list = list(qual_dict.keys())
+        all_index = set(range(train_x.shape[-1]))
+        quant_index = sorted(all_index.difference(qual_dict_list))
+        num_levels_per_var = list(qual_dict.values())
+        lm_columns = list(set(qual_dict_list).difference(separate_embedding))
+        qual_kernel_columns = [*separate_embedding, lm_columns] if len(lm_columns) > 0 else separate_embedding
+        train_y = train_y.reshape(-1)
+        noise_indices = list(range(0, num_levels_per_var[-1])) if multiple_noise else []
+        if len(qual_dict_list) == 1 and num_levels_per_var[0] < 2:
+            quant_index = quant_index + [qual_dict_list[0]]
+            qual_dict_list = []
+            qual_kernel_columns = []
+            embedding_dim = 0
+        elif len(qual_dict_list) == 0:
+            embedding_dim = 0
+
+        # kernel assembly: gp_plus.py:219-303
+        qual_kernels = []
+        if len(qual_dict_list) > 0:
+            for i in range(len(qual_kernel_columns)):
+                k = kernels.RBFKernel(active_dims=torch.arange(embedding_dim) + embedding_dim * i)
+                k.initialize(**{'lengthscale': 1.0})
+                k.raw_lengthscale.requires_grad_(False)
+                qual_kernels.append(k)
+        quant_correlation_class_name = quant_correlation_class
+        if quant_correlation_class_name == 'Rough_RBF':
+            quant_correlation_class = 'RBFKernel'  # gp_plus.py:229-230
+        if len(quant_index) == 0:
+            correlation_kernel = qual_kernels[0]
+            for i in range(1, len(qual_kernels)):
+                correlation_kernel *= qual_kernels[i]
+        else:
+            try:
+                quant_cls = getattr(kernels, quant_correlation_class)
+            except AttributeError:
+                raise RuntimeError("%s not an allowed kernel" % quant_correlation_class)
+            active = len(qual_kernel_columns) * embedding_dim + torch.arange(len(quant_index))
+            if quant_correlation_class_name == 'RBFKernel':
+                constraint = Positive(transform=torch.exp, inv_transform=torch.log)
+                prior = MollifiedUniformPrior(math.log(0.1), math.log(10))
+            else:
+                constraint = Positive(transform=_rough_transform, inv_transform=_rough_inv_transform)
+                prior = NormalPrior(-3.0, 3.0)
+            quant_kernel = quant_cls(ard_num_dims=len(quant_index), active_dims=active, lengthscale_constraint=constraint)
+            quant_kernel.register_prior('lengthscale_prior', prior, 'raw_lengthscale')
+            if len(qual_dict_list) > 0:
+                temp = qual_kernels[0]
+                for i in range(1, len(qual_kernels)):
+                    temp *= qual_kernels[i]
+                correlation_kernel = temp * quant_kernel
+            else:
+                correlation_kernel = quant_kernel
+
+        super(GP_Plus, self).__init__(train_x=train_x, train_y=train_y, noise_indices=noise_indices,
+                                      correlation_kernel=correlation_kernel, fix_noise=fix_noise,
+                                      fix_noise_val=fix_noise_val, lb_noise=lb_noise)
+
+        self.register_buffer('quant_index', torch.tensor(quant_index, dtype=torch.long))
+        self.register_buffer('qual_dict_list', torch.tensor(qual_dict_list, dtype=torch.long))
+        self.qual_kernel_columns = qual_kernel_columns
+        self.num_levels_per_var = num_levels_per_var
+        self.embedding_dim = embedding_dim
+        self.encoding_type = encoding_type
+        self.embedding_type = embedding_type
+        self.perm, self.zeta, self.perm_dict, self.A_matrix = [], [], [], []
+        self.count = train_x.size()[0]
+        self.num_pass_train, self.num_pass_pred = num_pass_train, num_pass_pred
+        self._cat_cache = {}
+        if len(qual_kernel_columns) > 0:
+            for i in range(len(qual_kernel_columns)):
+                if type(qual_kernel_columns[i]) == int:
+                    cat = [self.num_levels_per_var[qual_dict_list.index(qual_kernel_columns[i])]]
+                else:
+                    cat = [self.num_levels_per_var[qual_dict_list.index(k)] for k in qual_kernel_columns[i]]
+                num = sum(cat)
+                zeta, perm, perm_dict = self.zeta_matrix(num_levels=cat, embedding_dim=self.embedding_dim)
+                self.zeta.append(zeta)
+                self.perm.append(perm)
+                self.perm_dict.append(perm_dict)
+                model_temp = FFNN(self, input_size=num, num_classes=embedding_dim, layers=NN_layers_embedding,
+                                  name='latent' + str(qual_kernel_columns[i]))
+                self.A_matrix.append(model_temp)
+
+        if fixed_length_scale:
+            self.covar_module.base_kernel.raw_lengthscale.data = self.fixed_length_scale_val
+            self.covar_module.base_kernel.raw_lengthscale.requires_grad = False
+        # mean functions: gp_plus.py:366-382
+        self.m_gp = m_gp
+        self.m_gp_ref = m_gp_ref
+        self.num_sources = int(torch.max(train_x[:, -1]))
+        size = train_x.shape[1]
+        if self.m_gp.startswith('single'):
+            self.single_m_gp_register(size, m_gp_type=self.m_gp, wm='mean_module')
+        else:
+            self.multi_m_gp_register(train_x, ['multiple_constant'], self.m_gp_ref)
+        self.to(**self.tkwargs)
+
+    # ------------------------------------------------------------------------------------------------
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)  # encoder weights are registered on this module, so they move too
+        self._cat_cache = {}
+        if hasattr(self, 'likelihood') and hasattr(self.likelihood, 'fidel_indices') and torch.is_tensor(self.likelihood.fidel_indices):
+            self.likelihood.fidel_indices = fn(self.likelihood.fidel_indices)
+        return out
+
+    def _features(self, x: torch.Tensor):
+        """gp_plus.py:408-437: x_new = cat([A(zeta[index]), x[:, quant_index]]); returns (x_new, #leading manifold dims)."""
+        dev = self.tkwargs['device']
+        if len(self.qual_kernel_columns) == 0:
+            return x.to(dev), 0
+        i = len(self.qual_kernel_columns) - 1  # the reference embeds only the last group
+        key = (x.data_ptr(), tuple(x.shape), x._version, self.training)
+        zeta_rows = self._cat_cache.get(key)
+        if zeta_rows is None:  # the O(N) lookup runs once per distinct input tensor, not once per forward (B-6)
+            xc = x[:, self.qual_kernel_columns[i]].clone().type(torch.int64)
+            zeta_rows = self.transform_categorical(x=xc, perm_dict=self.perm_dict[i], zeta=self.zeta[i]).to(**self.tkwargs)
+            if len(self._cat_cache) > 8:
+                self._cat_cache.clear()
+            self._cat_cache[key] = zeta_rows
+        emb = self.A_matrix[i](zeta_rows)
+        x_new = torch.cat([emb, x[..., self.quant_index.long()].to(**self.tkwargs)], dim=-1)
+        return x_new, emb.shape[-1]
+
+    def forward(self, x: torch.Tensor) -> MultivariateNormal:
+        """gp_plus.py:386-484 (deterministic single pass)."""
+        if x.dim() > 2:
+            raise NotImplementedError("batched inputs are outside the exact-GP hot path")
+        x_forward_raw = x
+        x_new, dz = self._features(x)
+        if self.m_gp.startswith('multi'):
+            mean_x = self.multi_mean(x_new, x_forward_raw).to(**self.tkwargs)
+        else:
+            mean_x = self.single_mean(x_new).to(**self.tkwargs)
+        covar_x = self.covar_module(x_new)
+        covar_x.n_grad_dims = dz if x_new.requires_grad else 0
+        return MultivariateNormal(mean_x, covar_x)
+
+    # ---- mean functions ------------------------------------------------------------------------------
+    def single_m_gp_register(self, size=1, m_gp_type='single_zero', wm='mean_module'):
+        if m_gp_type == 'single_constant':
+            setattr(self, wm, ConstantMean(prior=NormalPrior(0., 1)))
+        elif m_gp_type == 'single_zero':
+            setattr(self, wm, ZeroMean())
+        else:
+            raise NotImplementedError(m_gp_type)
+
+    def multi_m_gp_register(self, train_x, supported_multi_m_gp_functions, m_gp_ref):
+        size = train_x.shape[1]
+        if self.m_gp in supported_multi_m_gp_functions:
+            for i in range(self.num_sources + 1):
+                m_gp_type = 'single_' + m_gp_ref if i == 0 else 'single' + self.m_gp[8:]
+                self.single_m_gp_register(size, m_gp_type=m_gp_type, wm='mean_module_' + str(i))
+
+    def single_mean(self, x):
+        return getattr(self, 'mean_module')(x)
+
+    def multi_mean(self, x, x_forward_raw):
+        """gp_plus.py:529-534, without the per-row module calls: mean_i = constant of source int(x_raw[i, -1])."""
+        src = x_forward_raw[:, -1].to(torch.int64)
+        mean_x = torch.zeros(x.shape[0], dtype=self.tkwargs['dtype'], device=x.device)
+        for s in range(self.num_sources + 1):
+            mod = getattr(self, 'mean_module_' + str(s))
+            if isinstance(mod, ConstantMean):
+                mean_x = torch.where(src.to(x.device) == s, mod.constant.to(mean_x).expand(x.shape[0]), mean_x)
+        return mean_x
+
+    # ---- fit -----------------------------------------------------------------------------------------
+    def fit(self, add_prior: bool = True, num_restarts: int = 64, theta0_list: Optional[List[np.ndarray]] = None,
+            jac: bool = True, options: Dict = {}, n_jobs: int = -1, method='L-BFGS-B', constraint=False, bounds=False,
+            regularization_parameter: List[int] = [0, 0], optim_type='scipy'):
+        """gp_plus.py:547-599.  On a GPU device the reference always ends in ``fit_model_torch`` (64 restarts for
+        'adam_torch', otherwise a warning and 4 restarts) — reproduced here.  The CPU branches
+        (scipy / continuation drivers) do not exist in this build: the exact-GP path only runs on the MI355X."""
+        print("## Learning the model's parameters has started ##")
+        if self.tkwargs['device'].type != 'cuda':
+            raise RuntimeError("this build evaluates the marginal likelihood only on an MI355X (device='cuda'); "
+                               "there is no CPU path")
+        if optim_type == 'adam_torch':
+            out = fit_model_torch(model=self, model_param_groups=None, lr_default=0.01, num_iter=100, num_restarts=64,
+                                  break_steps=50)
+        else:
+            warnings.warn('The model is built to run on CUDA (GPU), but the current optimization type is invalid for '
+                          'this configuration. So, the optimizer is now using adam_torch to train the model.')
+            out = fit_model_torch(model=self.to(**self.tkwargs), model_param_groups=None, lr_default=0.01, num_iter=100,
+                                  num_restarts=4, break_steps=50)
+        print("## Learning the model's parameters is successfully finished ##")
+        return out
+
+    def fill_nan_with_mean(self, train_x, cal_ID):
+        if torch.isnan(train_x).any():
+            print("There are NaN values in the data, which will be filled with column-wise mean values.")
+            col_means = torch.nanmean(train_x, dim=0)
+            nan_indices = torch.isnan(train_x)
+            train_x[nan_indices] = col_means.repeat(train_x.shape[0], 1)[nan_indices]
+        return train_x
+
+    # ---- prediction / evaluation -----------------------------------------------------------------------
+    def predict(self, Xtest, return_std=True, include_noise=True):
+        Xtest = data_type_check(Xtest)
+        with torch.no_grad():
+            return super().predict(Xtest.to(self.tkwargs['device']), return_std=return_std, include_noise=include_noise)
+
+    def predict_with_grad(self, Xtest, return_std=True, include_noise=True):
+        raise NotImplementedError("gradients of predictions (BO glue, gp_plus.py:626-628) are outside this build's scope")
+
+    def noise_value(self):
+        return self.likelihood.noise_covar.noise.detach() * self.y_std ** 2
+
+    def score(self, Xtest, ytest, plot_MSE=False, title=None, seperate_levels=False):
+        """gp_plus.py:634-660 without the matplotlib part."""
+        Xtest, ytest = data_type_check(Xtest), data_type_check(ytest)
+        ytest = ytest.reshape(-1).to(self.tkwargs['device'])
+        ypred = self.predict(Xtest.to(self.tkwargs['device']), return_std=False)
+        mse = ((ytest.reshape(-1) - ypred) ** 2).mean()
+        noise = self.noise_value()
+        print('################MSE######################')
+        print(f'MSE = {mse:.5f}')
+        print('################Noise####################')
+        print(f'The estimated noise parameter (varaince) is {noise}')
+        print(f'The estimated noise std is {np.sqrt(noise.cpu())}')
+        print('#########################################')
+        return mse
+
+    def evaluation(self, Xtest, ytest, verbose=True):
+        """gp_plus.py:889-932: NLL (joint predictive density / M), MSE, MAE, RRMSE, interval score."""
+        Xtest, ytest = data_type_check(Xtest), data_type_check(ytest)
+        self.eval()
+        dev = self.tkwargs['device']
+        ytest = ytest.reshape(-1).to(dev)
+        Xtest = Xtest.to(dev)
+        ytest_sc = (ytest - self.y_min) / self.y_std
+        with torch.no_grad():
+            if hasattr(self.likelihood, 'fidel_indices'):
+                self.likelihood.fidel_indices = Xtest[:, -1]
+            trained_pred_dist = self.likelihood(self(Xtest))
+            final_nlpd = gpmetrics.negative_log_predictive_density(trained_pred_dist, ytest_sc.to(torch.float64))
+            final_mse = gpmetrics.mean_squared_error(trained_pred_dist, ytest_sc, squared=True)
+            final_mae = gpmetrics.mean_absolute_error(trained_pred_dist, ytest_sc)
+            alpha = 0.05
+            mu_low, mu_up = trained_pred_dist.confidence_region()
+            out = mu_up - mu_low
+            out = out + (ytest_sc > mu_up) * 2 / alpha * (ytest_sc - mu_up)
+            out = out + (ytest_sc < mu_low) * 2 / alpha * (mu_low - ytest_sc)
+            IS = out.mean()
+            final_mse = final_mse * (self.y_std) ** 2
+            final_mae = final_mae * torch.abs(self.y_std)
+            IS = IS * torch.abs(self.y_std)
+            RRMSE = torch.sqrt(final_mse / torch.var(ytest))
+        results = {'NLL': final_nlpd, 'MSE': final_mse, 'MAE': final_mae, 'RRMSE': RRMSE, 'IS': IS}
+        if verbose:
+            from tabulate import tabulate
+            table_data = [['Negative Log-Likelihood (NLL)', final_nlpd], ['Mean Squared Error (MSE)', final_mse],
+                          ['Mean Absolute Error  (MAE)', final_mae], ['Relative Root Mean Square Error (RRMSE)', RRMSE],
+                          ['Interval Score (IS)', IS]]
+            print(tabulate(table_data, headers=['Metric', 'Value'], tablefmt='fancy_grid', colalign=("left", "left")))
+        return results
+
+    def get_params(self, name=None):
+        params = {n: value for n, value in self.named_parameters()}
+        print('###################Parameters###########################')
+        if name is None:
+            print(params)
+            return params
+        key = {'Mean': 'mean_module.constant', 'Sigma': 'covar_module.raw_outputscale',
+               'Noise': 'likelihood.noise_covar.raw_noise'}.get(name)
+        if name == 'Omega':
+            for n in params.keys():
+                if 'raw_lengthscale' in n and params[n].numel() > 1:
+                    key = n
+        print(params[key])
+        return params[key]
+
+    def get_latent_space(self):
+        if len(self.qual_dict_list) > 0:
+            return [self.A_matrix[i](self.zeta[i].to(**self.tkwargs)).detach() for i in range(len(self.qual_kernel_columns))]
+        print('No categorical Variable, No latent positions')
+        return None
+
+    def visualize_latent(self, *args, **kwargs):
+        raise NotImplementedError("plotting (visual/) is out of scope of this build; use get_latent_space()")
+
+    def Sobol(self, *args, **kwargs):
+        raise NotImplementedError("Sobol indices (gp_plus.py:1148-1224) are a post-fit analysis outside this build's scope")
+
+    # ---- categorical encoding ---------------------------------------------------------------------------
+    def zeta_matrix(self, num_levels, embedding_dim: int, batch_shape=torch.Size()):
+        """gp_plus.py:1027-1073."""
+        if any([i == 1 for i in num_levels]):
+            raise ValueError('Categorical variable has only one level!')
+        if embedding_dim == 1:
+            raise RuntimeWarning('1D latent variables are difficult to optimize!')
+        for level in num_levels:
+            if embedding_dim > level - 0:
+                raise RuntimeWarning('The LV dimension can atmost be num_levels-1. '
+                                     'Setting it to %s in place of %s' % (level - 1, embedding_dim))
+        perm = torch.tensor(list(product(*[torch.arange(l).tolist() for l in num_levels])), dtype=torch.int64)
+        perm_dic = {}
+        for i, row in enumerate(perm):
+            perm_dic.setdefault(str(row.tolist()), i)
+        perm_one_hot = torch.concat([torch.nn.functional.one_hot(perm[:, i]) for i in range(perm.size()[1])], axis=1)
+        return perm_one_hot, perm, perm_dic
+
+    def transform_categorical(self, x: torch.Tensor, perm_dict=[], zeta=[]):
+        """gp_plus.py:1077-1095: level combination -> row of zeta, through a vectorised mixed-radix index (the
+        reference's str(row)->dict lookup enumerates itertools.product in exactly that order)."""
+        if x.dim() == 1:
+            x = x.reshape(-1, 1)
+        if self.training is False:
+            # reference: x = setlevels(x) on the joint [train; test] categorical block (gp_plus.py:1081-1082 under
+            # ExactGP's eval-mode forward on cat([train_x, x])).  Equivalent here: levels from train + x together.
+            i = len(self.qual_kernel_columns) - 1
+            tr = self.train_inputs[0][:, self.qual_kernel_columns[i]].to(torch.int64).reshape(-1, x.shape[1]).cpu()
+            joint = setlevels(torch.cat([tr, x.cpu()], dim=0))
+            x = torch.as_tensor(joint)[tr.shape[0]:].to(torch.int64)
+        levels = [int(l) for l in self.perm[0].max(dim=0).values + 1] if len(self.perm) else []
+        xc = x.cpu()
+        if bool((xc < 0).any()) or any(bool((xc[:, c] >= levels[c]).any()) for c in range(xc.shape[1])):
+            raise ValueError("The categorical input (or source indices) are not defined properly. "
+                             "They should be integer values starting from zero. To solve the issue, "
+                             "you can use the 'setlevels' function, which is a preprocessing function.")
+        index = torch.zeros(xc.shape[0], dtype=torch.int64)
+        for c in range(xc.shape[1]):  # itertools.product order = mixed radix, last column fastest
+            index = index * levels[c] + xc[:, c]
+        return zeta[index, :]
+
+
+# ---------------------------------------------------------------------------------------------------------
+class Linear_MAP(nn.Linear):
+    """gp_plus.py:1456-1461."""
+
+    def forward(self, input, transform=lambda x: x):
+        return nn.functional.linear(input, transform(self.weight), self.bias)
+
+
+class FFNN(nn.Module):
+    """Deterministic manifold encoder (gp_plus.py:1227-1265): bias-free linear map (no hidden layers) or tanh MLP.
+    As in the reference the weights are parameters OF THE GP MODEL (registered under the reference's names with N(0,1)
+    priors); this module only remembers those names and reads the live tensors from its owner at call time, so the
+    encoder follows ``model.to(...)`` / ``load_state_dict`` (a CPU->GPU move re-creates Parameter objects)."""
+
+    def __init__(self, GP_Plus, input_size, num_classes, layers, name):
+        super(FFNN, self).__init__()
+        import weakref
+
+        object.__setattr__(self, '_owner', weakref.ref(GP_Plus))
+        self.hidden_num = len(layers)
+        self.weight_names = []
+
+        def _register(pname, prior_name, fan_in, fan_out):
+            init = nn.Linear(fan_in, fan_out, bias=False)  # same default initialisation as the reference's nn.Linear
+            GP_Plus.register_parameter(pname, nn.Parameter(init.weight.detach().clone()))
+            GP_Plus.register_prior(name=prior_name, prior=NormalPrior(0., 1), param_or_closure=pname)
+            self.weight_names.append(pname)
+
+        if self.hidden_num > 0:
+            _register(str(name) + 'fci', 'latent_prior_fci', input_size, layers[0])
+            for i in range(1, self.hidden_num):
+                _register(str(name) + 'h' + str(i), 'latent_prior' + str(i), layers[i - 1], layers[i])
+            _register(str(name) + 'fce', 'latent_prior_fce', layers[-1], num_classes)
+        else:
+            _register(name, 'latent_prior_' + name, input_size, num_classes)
+
+    def _weights(self):
+        owner = self._owner()
+        return [getattr(owner, n) for n in self.weight_names]
+
+    def forward(self, x, transform=lambda x: x):
+        ws = self._weights()
+        if self.hidden_num > 0:
+            for w in ws[:-1]:
+                x = torch.tanh(nn.functional.linear(x, w))
+            return nn.functional.linear(x, ws[-1])
+        return nn.functional.linear(x, transform(ws[0]))

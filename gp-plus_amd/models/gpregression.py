@@ -1,0 +1,105 @@
+"""``GPR``: standard GP regression model of GP+ (reference: models/gpregression.py:38-221), on the own gpcore protocol
+and the HIP back end.  Same constructor, attributes, buffers and state_dict keys; ``posterior``/``fantasize`` (botorch
+glue for Bayesian optimisation) are outside the exact-GP hot path and raise.
+"""
+import math
+from typing import List, Tuple, Union
+
+import torch
+
+from .. import kernels
+from ..gpcore import (ExactGP, GaussianLikelihood, GreaterThan, Kernel, LogNormalPrior, MultivariateNormal, Positive,
+                      settings as gptsettings)
+from ..likelihoods_noise.multifidelity import Multifidelity_likelihood
+from ..priors import LogHalfHorseshoePrior, MollifiedUniformPrior
+from ..utils.transforms import inv_softplus, softplus
+
+
+class GPR(ExactGP):
+    def __init__(self, train_x: torch.Tensor, train_y: torch.Tensor, correlation_kernel, noise_indices: List[int],
+                 fix_noise: bool = False, fix_noise_val: float = 1e-5, lb_noise: float = 1e-12) -> None:
+        # input checks: models/gpregression.py:50-56
+        if not torch.is_tensor(train_x):
+            raise RuntimeError("'train_x' must be a tensor")
+        if not torch.is_tensor(train_y):
+            raise RuntimeError("'train_y' must be a tensor")
+        if train_x.shape[0] != train_y.shape[0]:
+            raise RuntimeError("Inputs and output have different number of observations")
+
+        noise_constraint = GreaterThan(lb_noise, transform=torch.exp, inv_transform=torch.log)
+        if len(noise_indices) == 0:
+            likelihood = GaussianLikelihood(noise_constraint=noise_constraint)
+        else:
+            likelihood = Multifidelity_likelihood(noise_constraint=noise_constraint, noise_indices=noise_indices,
+                                                  fidel_indices=train_x[:, -1])
+        y_min = train_y.min()
+        y_std = train_y.max() - train_y.min()
+        train_y_sc = (train_y - y_min) / y_std
+
+        ExactGP.__init__(self, train_x, train_y_sc, likelihood)
+        self.register_buffer('y_min', y_min)
+        self.register_buffer('y_std', y_std)
+        self.register_buffer('y_scaled', train_y_sc)
+        self._num_outputs = 1
+
+        self.likelihood.register_prior('noise_prior', LogHalfHorseshoePrior(0.01, lb_noise), 'raw_noise')
+        if fix_noise:
+            self.likelihood.raw_noise.requires_grad_(False)
+            self.likelihood.noise_covar.noise = torch.tensor(fix_noise_val)
+
+        if isinstance(correlation_kernel, str):
+            try:
+                correlation_kernel_class = getattr(kernels, correlation_kernel)
+                correlation_kernel = correlation_kernel_class(
+                    ard_num_dims=self.train_inputs[0].size(1),
+                    lengthscale_constraint=Positive(transform=torch.exp, inv_transform=torch.log),
+                )
+                correlation_kernel.register_prior(
+                    'lengthscale_prior', MollifiedUniformPrior(math.log(0.1), math.log(10)), 'raw_lengthscale')
+            except Exception:
+                raise RuntimeError("%s not an allowed kernel" % correlation_kernel)
+        elif not isinstance(correlation_kernel, Kernel):
+            raise RuntimeError("specified correlation kernel is not a `gpytorch.kernels.Kernel` instance")
+
+        self.covar_module = kernels.ScaleKernel(
+            base_kernel=correlation_kernel,
+            outputscale_constraint=Positive(transform=softplus, inv_transform=inv_softplus),
+        )
+        self.covar_module.register_prior('outputscale_prior', LogNormalPrior(1e-6, 1.), 'outputscale')
+
+    # a plain GPR has no mean module in the reference either (forward uses self.mean_module set by subclasses)
+    def forward(self, x: torch.Tensor) -> MultivariateNormal:
+        mean_x = self.mean_module(x)
+        covar_x = self.covar_module(x)
+        return MultivariateNormal(mean_x, covar_x)
+
+    def predict(self, x: torch.Tensor, return_std: bool = False, include_noise: bool = False
+                ) -> Union[torch.Tensor, Tuple[torch.Tensor]]:
+        """models/gpregression.py:122-149."""
+        self.eval()
+        with gptsettings.fast_computations(log_prob=False):
+            if self.train_targets.ndim != 1:
+                raise NotImplementedError("batched GPs are outside the exact-GP hot path")
+            output = self(x)
+            self.fidel_indices = x[:, -1]
+            if return_std and include_noise:
+                self.likelihood.fidel_indices = x[:, -1]  # noise of the test points' own sources
+                output = self.likelihood(output)
+            out_mean = self.y_min + self.y_std * output.mean
+            if return_std:
+                out_std = output.variance.sqrt() * self.y_std
+                return out_mean, out_std
+            return out_mean
+
+    def posterior(self, X, output_indices=None, observation_noise=True, posterior_transform=None, **kwargs):
+        raise NotImplementedError("botorch posterior glue (models/gpregression.py:151-166) is out of scope of this build")
+
+    def fantasize(self, X, sampler, observation_noise=True, **kwargs):
+        raise NotImplementedError("botorch fantasize glue (models/gpregression.py:177-221) is out of scope of this build")
+
+    def reset_parameters(self) -> None:
+        """Reset parameters by sampling from their priors (models/gpregression.py:168-174)."""
+        for _, module, prior, closure, setting_closure in self.named_priors():
+            if not closure(module).requires_grad:
+                continue
+            setting_closure(module, prior.expand(closure(module).shape).sample().to(**self.tkwargs))

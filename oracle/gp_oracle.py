@@ -113,12 +113,11 @@ def rbf_gpytorch(x1: torch.Tensor, x2: torch.Tensor, lengthscale: torch.Tensor) 
 
 
 def rough_rbf_standalone(x1: torch.Tensor, x2: torch.Tensor, lengthscale: torch.Tensor) -> torch.Tensor:
-    """kernels/Rough_RBF.py:27-32 (grad/ARD branch): x * sqrt(l), then exp(-0.5 * sqdist)?  No: the class passes
-    dist_postprocess_func=postprocess_rbf, i.e. exp(-sqdist/2) of the sqrt(l)-scaled inputs
-    => exp(-0.5 * sum_d l_d (x1_d-x2_d)^2)."""
+    """kernels/Rough_RBF.py:6-7,27-32 (grad/ARD branch): inputs scaled by sqrt(l), squared distance, and the file's
+    OWN postprocess_rbf = div_(-1).exp_()  =>  exp(-sum_d l_d (x1_d-x2_d)^2)."""
     s = lengthscale.sqrt()
     eq = x1.shape == x2.shape and torch.equal(x1, x2)
-    return sq_dist_gpytorch(x1 * s, x2 * s, eq).div(-2).exp()
+    return sq_dist_gpytorch(x1 * s, x2 * s, eq).div(-1).exp()
 
 
 # ---------------------------------------------------------------------------------------------------

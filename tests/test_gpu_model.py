@@ -1,0 +1,250 @@
+"""End-to-end GPU parity: the GP+ API (GP_Plus / ExactMarginalLogLikelihood / fit_model_torch / predict) running on the
+HIP back end, against the committed golden fixtures (inputs from the reference's data pipeline, expected values from
+the CPU oracle) and against the oracle itself on fresh seeded inputs.
+
+Tolerances are the north star's: MLL and grad-MLL within 1e-5 relative (fp64); predictive mean / std within 1e-4.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+RTOL_MLL = 1e-5
+RTOL_PRED = 1e-4
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+def build(fx, tag, **kw):
+    from gpplus_amd.models import GP_Plus
+
+    xkey = "Xtrain" if "Xtrain" in fx else "Utrain"
+    m = GP_Plus(torch.tensor(fx[xkey]), torch.tensor(fx["ytrain"]), dtype=torch.float64, device="cuda", **kw)
+    sd = m.state_dict()
+    for k in list(sd):
+        fk = f"{tag}::param::{k}"
+        if fk in fx:
+            sd[k] = torch.as_tensor(fx[fk]).reshape(sd[k].shape).to(sd[k])
+    m.load_state_dict(sd)
+    return m
+
+
+def loss_and_grads(m):
+    from gpplus_amd.gpcore import ExactMarginalLogLikelihood
+
+    m.train()
+    mll = ExactMarginalLogLikelihood(m.likelihood, m)
+    for p in m.parameters():
+        p.grad = None
+    out = m(*m.train_inputs)
+    loss = -mll(out, m.train_targets)
+    loss.backward()
+    return loss.item(), {n: p.grad.detach().cpu().numpy() for n, p in m.named_parameters() if p.grad is not None}
+
+
+CASES = [
+    ("c1_borehole_n500.npz", "theta0", {}),
+    ("c1_borehole_n500.npz", "theta1", {}),
+    ("c3_borehole_mixed_n100.npz", "theta1", {"qual_dict": {0: 5, 5: 5}}),
+    ("c4_wing_mf_n300.npz", "theta1", {"qual_dict": {10: 3}, "multiple_noise": True, "m_gp": "multiple_constant"}),
+]
+
+
+@pytest.mark.parametrize("fixture,tag,kw", CASES)
+def test_loss_and_gradients_match_golden(gpu_ctx, fixture, tag, kw):
+    fx = load(fixture)
+    m = build(fx, tag, **kw)
+    loss, grads = loss_and_grads(m)
+    ref = float(fx[f"{tag}::loss"])
+    assert abs(loss - ref) <= RTOL_MLL * abs(ref), (loss, ref)
+    checked = 0
+    for name, g in grads.items():
+        key = f"{tag}::grad::{name}"
+        assert key in fx, f"fixture has no gradient for {name}"
+        gref = fx[key].reshape(g.shape)
+        scale = max(np.abs(gref).max(), 1e-12)
+        np.testing.assert_allclose(g, gref, rtol=RTOL_MLL, atol=RTOL_MLL * scale, err_msg=name)
+        checked += 1
+    assert checked == sum(1 for k in fx if k.startswith(f"{tag}::grad::"))
+
+
+@pytest.mark.parametrize("fixture,tag,kw", CASES[1:])
+def test_predict_matches_golden(gpu_ctx, fixture, tag, kw):
+    fx = load(fixture)
+    m = build(fx, tag, **kw)
+    xt = torch.tensor(fx["Xtest"] if "Xtest" in fx else fx["Utest"])
+    mean, std = m.predict(xt, return_std=True, include_noise=True)
+    np.testing.assert_allclose(mean.cpu().numpy(), fx[f"{tag}::pred_mean"], rtol=RTOL_PRED, atol=1e-8)
+    np.testing.assert_allclose(std.cpu().numpy(), fx[f"{tag}::pred_std"], rtol=RTOL_PRED, atol=1e-8)
+    mean2, std2 = m.predict(xt, return_std=True, include_noise=False)
+    np.testing.assert_allclose(std2.cpu().numpy(), fx[f"{tag}::pred_std_nonoise"], rtol=RTOL_PRED, atol=1e-7)
+    only_mean = m.predict(xt, return_std=False)
+    np.testing.assert_allclose(only_mean.cpu().numpy(), mean.cpu().numpy(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("n,d,seed", [(64, 3, 0), (777, 8, 1), (2048, 8, 2), (4097, 5, 3)])
+def test_against_oracle_on_fresh_inputs(gpu_ctx, n, d, seed):
+    """Same seeded inputs through the oracle (CPU) and the product (GPU), incl. a non-multiple-of-tile size."""
+    from oracle.gp_oracle import OracleGP
+    from gpplus_amd.models import GP_Plus
+
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, d))
+    y = np.sin(X[:, 0]) + 0.3 * X[:, 1] ** 2 + 0.05 * rng.standard_normal(n)
+    o = OracleGP(X, y)
+    vals = {o.ls_key: np.float32(rng.uniform(-1.5, -0.5, (1, d))), "covar_module.raw_outputscale": np.float32(0.3),
+            "likelihood.noise_covar.raw_noise": np.float32([-6.0]), "mean_module.constant": np.float32([0.4])}
+    for k, v in vals.items():
+        o.params[k] = torch.as_tensor(np.asarray(v, dtype=np.float64)).reshape(o.params[k].shape)
+    lo, go = o.loss_and_grad()
+    m = GP_Plus(torch.tensor(X), torch.tensor(y), dtype=torch.float64, device="cuda")
+    sd = m.state_dict()
+    for k, v in o.params.items():
+        sd[k] = v.reshape(sd[k].shape).to(sd[k])
+    m.load_state_dict(sd)
+    loss, grads = loss_and_grads(m)
+    assert abs(loss - lo.item()) <= RTOL_MLL * abs(lo.item())
+    for k, g in go.items():
+        gref = g.numpy().reshape(grads[k].shape)
+        np.testing.assert_allclose(grads[k], gref, rtol=RTOL_MLL, atol=RTOL_MLL * max(np.abs(gref).max(), 1e-12), err_msg=k)
+
+
+def test_rbfkernel_mode_and_fixed_noise(gpu_ctx):
+    from oracle.gp_oracle import OracleGP
+    from gpplus_amd.models import GP_Plus
+
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((300, 4))
+    y = np.cos(X[:, 0]) + X[:, 2]
+    o = OracleGP(X, y, quant_correlation_class="RBFKernel", fix_noise=True, fix_noise_val=1e-3, m_gp="single_zero")
+    o.params[o.ls_key] = torch.tensor(np.float32([[0.2, -0.1, 0.4, 0.0]]), dtype=torch.float64)
+    lo, go = o.loss_and_grad()
+    m = GP_Plus(torch.tensor(X), torch.tensor(y), dtype=torch.float64, device="cuda", quant_correlation_class="RBFKernel",
+                fix_noise=True, fix_noise_val=1e-3, m_gp="single_zero")
+    sd = m.state_dict()
+    sd[o.ls_key] = o.params[o.ls_key].to(sd[o.ls_key])
+    m.load_state_dict(sd)
+    assert not m.likelihood.raw_noise.requires_grad
+    # set through an fp32 tensor in the reference too (models/gpregression.py:87): fp32-accurate only
+    np.testing.assert_allclose(m.likelihood.noise.item(), 1e-3, rtol=1e-6)
+    loss, grads = loss_and_grads(m)
+    assert abs(loss - lo.item()) <= RTOL_MLL * abs(lo.item())
+    assert "likelihood.noise_covar.raw_noise" not in grads
+    np.testing.assert_allclose(grads[o.ls_key], go[o.ls_key].numpy(), rtol=RTOL_MLL, atol=1e-10)
+
+
+def test_duplicate_rows_and_jitter_policy(gpu_ctx):
+    """Exact duplicate rows (the reference's with-replacement shuffle): Ky is PD only through the noise.
+    With the noise at its 1e-8 floor the factorisation must either succeed or go through the warn-and-retry path, and a
+    matrix that stays indefinite must raise NotPSDError."""
+    from gpplus_amd.gpcore import NotPSDError
+    from gpplus_amd.linalg import KernelSpec, exact_mll
+
+    rng = np.random.default_rng(3)
+    U = rng.standard_normal((200, 3))
+    U[100:] = U[:100]
+    Ud = torch.tensor(U, device="cuda")
+    spec = KernelSpec(torch.full((3,), 0.3, dtype=torch.float64, device="cuda"), torch.tensor(1.0, dtype=torch.float64, device="cuda"))
+    y = torch.tensor(rng.standard_normal(200), device="cuda")
+    mean = torch.zeros(200, dtype=torch.float64, device="cuda")
+    ok = exact_mll(Ud, spec, torch.tensor([1e-3], dtype=torch.float64, device="cuda"), mean, y)
+    assert torch.isfinite(ok)
+    with pytest.warns(RuntimeWarning):
+        v = exact_mll(Ud, spec, torch.tensor([0.0], dtype=torch.float64, device="cuda"), mean, y)
+    assert torch.isfinite(v)
+    with pytest.raises(NotPSDError):
+        exact_mll(Ud, spec, torch.tensor([-0.5], dtype=torch.float64, device="cuda"), mean, y)
+
+
+def test_fit_model_torch_improves_and_restores_best_state(gpu_ctx):
+    from gpplus_amd.optim import fit_model_torch
+    from gpplus_amd.utils import set_seed
+
+    fx = load("c1_borehole_n500.npz")
+    set_seed(0)
+    m = build(fx, "theta0")
+    l0, _ = loss_and_grads(m)
+    f_inc, hist = fit_model_torch(m, lr_default=0.05, num_iter=30, num_restarts=1, verbose=False)
+    assert len(hist) == 2 and len(hist[0]) == 30
+    assert f_inc < l0
+    assert abs(f_inc - min(h[-1] for h in hist)) < 1e-12
+    keys = set(m.state_dict().keys())
+    for k in ("likelihood.noise_covar.raw_noise", "covar_module.raw_outputscale", "covar_module.base_kernel.raw_lengthscale",
+              "mean_module.constant", "y_min", "y_std", "y_scaled", "quant_index", "qual_dict_list"):
+        assert k in keys, k
+    mean, std = m.predict(torch.tensor(fx["Xtest"]), return_std=True)
+    rmse = float(((mean.cpu() - torch.tensor(fx["ytest"])) ** 2).mean().sqrt())
+    assert rmse < 0.6 * float(np.std(fx["ytest"]))  # 2 x 30 Adam steps from the init point: already far better than the mean
+
+
+def test_evaluation_and_dense_evaluate(gpu_ctx):
+    fx = load("c1_borehole_n500.npz")
+    m = build(fx, "theta1")
+    res = m.evaluation(torch.tensor(fx["Xtest"]), torch.tensor(fx["ytest"]), verbose=False)
+    assert all(torch.isfinite(v).all() for v in res.values())
+    m.train()
+    dense = m(*m.train_inputs).lazy_covariance_matrix.evaluate()
+    assert dense.shape == (500, 500)
+    assert torch.allclose(dense, dense.T)
+    np.testing.assert_allclose(dense.diagonal().cpu().numpy(), float(m.covar_module.outputscale), rtol=1e-14)
+
+
+def test_cpu_device_fails_loudly():
+    from gpplus_amd._lib import GppError
+    from gpplus_amd.gpcore import ExactMarginalLogLikelihood
+    from gpplus_amd.models import GP_Plus
+
+    fx = load("c3_borehole_mixed_n100.npz")
+    m = GP_Plus(torch.tensor(fx["Utrain"]), torch.tensor(fx["ytrain"]), qual_dict={0: 5, 5: 5}, dtype=torch.float64)
+    with pytest.raises(GppError):
+        ExactMarginalLogLikelihood(m.likelihood, m)(m(*m.train_inputs), m.train_targets)
+
+
+def test_full_size_properties_n20000(gpu_ctx):
+    """BASELINE.json's N=20000, d=8 through size-independent properties: K alpha = r, L (Linv v) = v, MLL invariance
+    under a permutation of the data, and sum-rule of the noise gradient."""
+    from gpplus_amd.backend import square_buffer
+    from gpplus_amd.linalg import KernelSpec, exact_mll, dense_kernel, get_workspace
+
+    N, D = 20000, 8
+    g = torch.Generator(device="cuda").manual_seed(0)
+    U = torch.rand(N, D, dtype=torch.float64, device="cuda", generator=g) * 3.4 - 1.7
+    y = torch.sin(U[:, 0]) + 0.1 * torch.randn(N, dtype=torch.float64, device="cuda", generator=g)
+    w = torch.full((D,), 0.1, dtype=torch.float64, device="cuda", requires_grad=True)
+    sf2 = torch.tensor(0.85, dtype=torch.float64, device="cuda", requires_grad=True)
+    tau = torch.tensor([2.5e-3], dtype=torch.float64, device="cuda", requires_grad=True)
+    mean = torch.zeros(N, dtype=torch.float64, device="cuda")
+    mll = exact_mll(U, KernelSpec(w, sf2), tau, mean, y)
+    mll.backward()
+    ws = get_workspace(gpu_ctx, N, 0)
+    alpha = ws.alpha.clone()
+    K = dense_kernel(U, KernelSpec(w.detach(), sf2.detach()), tau.detach(), None)
+    resid = torch.mv(K, alpha) - y
+    assert float(resid.norm() / y.norm()) < 1e-8
+    # L (Linv v) = v on the lower factors
+    v = torch.randn(N, dtype=torch.float64, device="cuda", generator=g)
+    L = torch.tril(ws.A)
+    t = torch.mv(torch.tril(ws.Li), v)
+    assert float((torch.mv(L, t) - v).norm() / v.norm()) < 1e-8
+    del K, L
+    g_w, g_tau = w.grad.clone(), tau.grad.clone()
+    # permutation invariance
+    perm = torch.randperm(N, device="cuda", generator=g)
+    w2 = w.detach().clone().requires_grad_(True)
+    mll2 = exact_mll(U[perm].contiguous(), KernelSpec(w2, sf2.detach()), tau.detach(), mean, y[perm].contiguous())
+    mll2.backward()
+    assert abs(mll2.item() - mll.item()) <= 1e-9 * abs(mll.item())
+    np.testing.assert_allclose(w2.grad.cpu().numpy(), g_w.cpu().numpy(), rtol=1e-6)
+    # d/dtau = 0.5 (alpha'alpha - tr Ky^-1): check against the trace computed from Linv (||Linv||_F^2)
+    fro = 0.0
+    for r0 in range(0, N, 2000):
+        blk = torch.tril(ws.Li[r0:r0 + 2000], diagonal=r0)
+        fro += float((blk * blk).sum())
+    expect = 0.5 * (float(alpha @ alpha) - fro)
+    assert abs(g_tau.item() - expect) <= 1e-6 * abs(expect)
