@@ -12,6 +12,10 @@ import subprocess
 from ctypes import POINTER, c_char_p, c_double, c_int, c_int32, c_int64, c_size_t, c_void_p
 from pathlib import Path
 
+# PyTorch must be imported before libgpp_hip.so is loaded: torch bundles its own libamdhip64 and both copies cannot
+# initialise in one process (loading /opt/rocm's first makes every later HIP call report "no device").
+import torch  # noqa: F401  (import order matters, see above)
+
 _PKG_DIR = Path(__file__).resolve().parent
 _LIB_PATH = _PKG_DIR / "libgpp_hip.so"
 _CSRC = _PKG_DIR / "csrc"

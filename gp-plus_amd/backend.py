@@ -16,7 +16,7 @@ from . import _lib
 from ._lib import GppError, check
 
 KIND_RBF, KIND_MATERN32, KIND_MATERN52 = 0, 1, 2
-UPLO_FULL, UPLO_LOWER = 0, 1
+UPLO_FULL, UPLO_LOWER, UPLO_UPPER = 0, 1, 2
 OP_MLL_EVAL, OP_PREDICT = 0, 1
 
 _contexts: Dict[int, "GppContext"] = {}
@@ -109,9 +109,9 @@ class GppContext:
         check(self.lib.gpp_potrf(self.h, A.data_ptr(), A.shape[0], _ld(A), Linv.data_ptr(), _ld(Linv), info.data_ptr()),
               "gpp_potrf")
 
-    def trtri(self, L, Linv, T):
+    def trtri(self, U, Linv, T):
         self._stream()
-        check(self.lib.gpp_trtri(self.h, L.data_ptr(), L.shape[0], _ld(L), Linv.data_ptr(), _ld(Linv), T.data_ptr(), _ld(T)),
+        check(self.lib.gpp_trtri(self.h, U.data_ptr(), U.shape[0], _ld(U), Linv.data_ptr(), _ld(Linv), T.data_ptr(), _ld(T)),
               "gpp_trtri")
 
     def lauum(self, Linv, Kinv):
@@ -127,7 +127,6 @@ class GppContext:
 
     def alpha(self, Linv, z, alpha):
         N = Linv.shape[0]
-        self.ensure_workspace(OP_MLL_EVAL, N, 0, 1, 1)
         self._stream()
         check(self.lib.gpp_alpha(self.h, Linv.data_ptr(), _ld(Linv), N, z.data_ptr(), alpha.data_ptr()), "gpp_alpha")
 
@@ -146,10 +145,10 @@ class GppContext:
                                    mean_out.data_ptr(), _ptr(var_out)), "gpp_predict")
 
     def gemm(self, transA, transB, M, N, K, alpha, A, B, beta, C, *, a_mask=0, b_mask=0, klo_mode=0, khi_mode=0,
-             c_lower=0):
+             c_tri=0):
         self._stream()
         check(self.lib.gpp_gemm(self.h, transA, transB, M, N, K, float(alpha), A.data_ptr(), _ld(A), B.data_ptr(), _ld(B),
-                                float(beta), C.data_ptr(), _ld(C), a_mask, b_mask, klo_mode, khi_mode, c_lower), "gpp_gemm")
+                                float(beta), C.data_ptr(), _ld(C), a_mask, b_mask, klo_mode, khi_mode, c_tri), "gpp_gemm")
 
 
 def get_context(device) -> GppContext:

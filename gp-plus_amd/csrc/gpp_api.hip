@@ -2,13 +2,18 @@
 // dense algorithms.  No reference code corresponds to this file: the reference delegates the whole path to
 // gpytorch/ATen (optim/mll_torch.py:112-117); the algorithms here are the MI355X-native replacement.
 //
-// Cholesky (gpp_potrf): recursive lower factorisation
-//     potrf(A)  = potrf(A11); A21 <- A21 L11^-T (trsm); A22 -= A21 A21^T (syrk); potrf(A22)
-//     trsm(B,L) = trsm(B1,L11); B2 -= X1 L21^T (gemm); trsm(B2,L22)        -- splits at multiples of 128
-// so that every flop above the 128x128 leaves is a call of the MFMA GEMM kernel with a large K, and the leaves
-// (factor + inverse of a 128 block in LDS) also leave inv(L_bb) on the diagonal of Linv.
+// Storage (see gpp.h): the factored matrix keeps its UPPER triangle (A = U^T U, U = L^T), the inverse factor buffer
+// keeps L^-1 lower and its mirror L^-T upper.  With that mix EVERY product below is a "TN" GEMM (both operands
+// row-contiguous along the non-contracted index), the fastest variant of the kernel.
+// Cholesky (gpp_potrf): recursive upper factorisation
+//     potrf(A)  = potrf(A11); U12 <- U11^-T A12 (trsm); A22 -= U12^T U12 (syrk); potrf(A22)
+//     trsm(B,U) = trsm(B1,U11); B2 -= U12^T X1 (gemm); trsm(B2,U22)        -- splits at multiples of 128
+// so that every flop above the 128x128 leaves is a call of the MFMA GEMM kernel with a large K; the leaves (factor +
+// inverse of a 128 block in LDS) also leave inv(L_bb) (mirrored) on the diagonal of Linv, and the leaf trsm is the
+// in-place TN product  U12 <- (inv(L_bb)^T)^T A12.
 // Inverse (gpp_trtri): bottom-up pair merging, for s = 128, 256, ...:
-//     Linv21 = -Linv22 (L21 Linv11)   for all aligned pairs of s-blocks at once (batched launches).
+//     Linv21 = -Linv22 (U12^T Linv11) = -(W22)^T (U12^T Linv11),  W = Linv^T (the mirror), batched over all pairs;
+//     each Linv21 is also written transposed into the mirror.
 // gpp_lauum: Kinv = Linv^T Linv in one lower-triangular TN launch (k >= max(i,j) tile ranges).
 #include "../../include/gpp.h"
 #include "gpp_internal.h"
@@ -49,30 +54,31 @@ inline int64_t split(int64_t n) {
 
 struct Ctx {
   hipStream_t s;
-  double* A; int64_t ld;       // matrix being factored (L on exit)
-  double* Li; int64_t ldi;     // Linv (diagonal leaves written here)
+  double* A; int64_t ld;       // matrix being factored (upper; U on exit)
+  double* Li; int64_t ldi;     // Linv buffer (mirrored diagonal leaves written here)
   int32_t* info;
 };
 
-// X L^T = B for the n x n lower block L at (o,o); B is m x n at rows r0.., columns o..; in place.
-hipError_t trsm_rec(const Ctx& c, int64_t r0, int64_t m, int64_t o, int64_t n) {
+// Solve U_oo^T X = B for the n x n upper block U at (o,o); B is n x m at rows o.., columns c0..; in place.
+hipError_t trsm_rec(const Ctx& c, int64_t c0, int64_t m, int64_t o, int64_t n) {
   if (m <= 0 || n <= 0) return hipSuccess;
   if (n <= NBLK) {
-    // X = B * inv(L_leaf)^T : NT product with the leaf inverse (lower), in place (single column tile)
-    double* Bp = c.A + r0 * c.ld + o;
-    GemmArgs g = mk(Bp, c.ld, c.Li + o * c.ldi + o, c.ldi, Bp, c.ld, m, n, n, 1.0, 0.0);
-    g.b_mask = 1;
-    return gpp_launch_gemm(c.s, 0, g, 1, NBLK);  // in place: the whole panel width must sit in ONE column tile
+    // X[k][j] = sum_i W[i][k] B[i][j] with W = inv(L_leaf)^T = upper part of the mirrored leaf block (keep i <= k).
+    // In place: one row tile (n <= 128), every work-group reads and writes only its own column block.
+    double* Bp = c.A + o * c.ld + c0;
+    GemmArgs g = mk(c.Li + o * c.ldi + o, c.ldi, Bp, c.ld, Bp, c.ld, n, m, n, 1.0, 0.0);
+    g.a_mask = 1;
+    return gpp_launch_gemm(c.s, 2, g, 1, NBLK);
   }
   const int64_t n1 = split(n), n2 = n - n1;
-  hipError_t e = trsm_rec(c, r0, m, o, n1);
+  hipError_t e = trsm_rec(c, c0, m, o, n1);
   if (e != hipSuccess) return e;
-  // B2 -= X1 * L21^T
-  GemmArgs g = mk(c.A + r0 * c.ld + o, c.ld, c.A + (o + n1) * c.ld + o, c.ld, c.A + r0 * c.ld + o + n1, c.ld, m, n2, n1,
+  // B2 -= U12^T X1 : U12 = A[o.., o+n1..] (n1 x n2), X1 = A[o.., c0..] (n1 x m), B2 = A[o+n1.., c0..] (n2 x m)
+  GemmArgs g = mk(c.A + o * c.ld + (o + n1), c.ld, c.A + o * c.ld + c0, c.ld, c.A + (o + n1) * c.ld + c0, c.ld, n2, m, n1,
                   -1.0, 1.0);
-  e = gpp_launch_gemm(c.s, 0, g, 1);
+  e = gpp_launch_gemm(c.s, 2, g, 1);
   if (e != hipSuccess) return e;
-  return trsm_rec(c, r0, m, o + n1, n2);
+  return trsm_rec(c, c0, m, o + n1, n2);
 }
 
 hipError_t potrf_rec(const Ctx& c, int64_t o, int64_t n) {
@@ -84,11 +90,11 @@ hipError_t potrf_rec(const Ctx& c, int64_t o, int64_t n) {
   if (e != hipSuccess) return e;
   e = trsm_rec(c, o + n1, n2, o, n1);
   if (e != hipSuccess) return e;
-  // A22 -= A21 A21^T (lower)
-  const double* A21 = c.A + (o + n1) * c.ld + o;
-  GemmArgs g = mk(A21, c.ld, A21, c.ld, c.A + (o + n1) * c.ld + (o + n1), c.ld, n2, n2, n1, -1.0, 1.0);
-  g.c_lower = 1;
-  e = gpp_launch_gemm(c.s, 0, g, 1);
+  // A22 -= U12^T U12 (upper triangle only)
+  const double* U12 = c.A + o * c.ld + (o + n1);
+  GemmArgs g = mk(U12, c.ld, U12, c.ld, c.A + (o + n1) * c.ld + (o + n1), c.ld, n2, n2, n1, -1.0, 1.0);
+  g.c_lower = 2;
+  e = gpp_launch_gemm(c.s, 2, g, 1);
   if (e != hipSuccess) return e;
   return potrf_rec(c, o + n1, n2);
 }
@@ -139,9 +145,7 @@ size_t gpp_workspace_bytes(gpp_handle_t h, int op, int64_t N, int64_t M, int D, 
   (void)h;
   (void)M;
   if (op == GPP_OP_MLL_EVAL) {
-    const size_t trmv_part = (size_t)((N + 1023) / 1024) * (size_t)N * sizeof(double);
-    const size_t grad = gpp_grad_ws_bytes(N, D, S, D);
-    return std::max(trmv_part, grad) + 256;
+    return gpp_grad_ws_bytes(N, D, S, D) + 256;
   }
   if (op == GPP_OP_PREDICT) return 256;
   return 0;
@@ -167,10 +171,11 @@ int gpp_kernel_build(gpp_handle_t h, const double* U, int64_t N, int D, const do
   if (tau && S < 1) return -9;
   if (kind < 0 || kind > 2) return -11;
   if (d_split < 0 || d_split > D) return -12;
-  if (uplo != GPP_UPLO_FULL && uplo != GPP_UPLO_LOWER) return -13;
+  if (uplo != GPP_UPLO_FULL && uplo != GPP_UPLO_LOWER && uplo != GPP_UPLO_UPPER) return -13;
   if (!Ky) return -14;
   if (ld < N) return -15;
   if (row0 < 0 || nrows < 0 || row0 + nrows > N || (row0 % 64) != 0) return -16;
+  if (uplo == GPP_UPLO_UPPER && (row0 != 0 || nrows != N)) return -16;  // row shards: full or lower mode only
   GPP_TRY(gpp_launch_kernel_build(h->stream, U, N, D, w, sf2, tau, grp, S, jitter, kind, d_split, uplo, Ky, ld, row0, nrows));
   return 0;
 }
@@ -205,10 +210,10 @@ int gpp_potrf(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, in
   return 0;
 }
 
-int gpp_trtri(gpp_handle_t h, const double* L, int64_t N, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt) {
+int gpp_trtri(gpp_handle_t h, const double* U, int64_t N, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt) {
   if (!h) return -1;
   if (N < 0) return -3;
-  if (int r = check_mat(L, ld, N, 2)) return r;
+  if (int r = check_mat(U, ld, N, 2)) return r;
   if (int r = check_mat(Linv, ldi, N, 5)) return r;
   if (int r = check_mat(T, ldt, N, 7)) return r;
   for (int64_t s = NBLK; s < N; s *= 2) {
@@ -225,18 +230,19 @@ int gpp_trtri(gpp_handle_t h, const double* L, int64_t N, int64_t ld, double* Li
         if (rem <= s) continue;  // no second block in the ragged pair
         o = npairs_full * 2 * s; m2 = rem - s; batch = 1;
       }
-      const int64_t pstride_L = 2 * s * (ld + 1), pstride_I = 2 * s * (ldi + 1), pstride_T = 2 * s * (ldt + 1);
-      // T21 = L21 * Linv11      (NN; Linv11 lower: k >= n)
-      GemmArgs g1 = mk(L + (o + s) * ld + o, ld, Linv + o * ldi + o, ldi, T + (o + s) * ldt + o, ldt, m2, s, s, 1.0, 0.0);
+      const int64_t pstride_U = 2 * s * (ld + 1), pstride_I = 2 * s * (ldi + 1), pstride_T = 2 * s * (ldt + 1);
+      // T21 = U12^T * Linv11   (TN; U12 = U[o.., o+s..] is s x m2, Linv11 lower: keep k >= n)
+      GemmArgs g1 = mk(U + o * ld + (o + s), ld, Linv + o * ldi + o, ldi, T + (o + s) * ldt + o, ldt, m2, s, s, 1.0, 0.0);
       g1.b_mask = 2; g1.klo_mode = 2;
-      g1.sA = pstride_L; g1.sB = pstride_I; g1.sC = pstride_T;
-      GPP_TRY(gpp_launch_gemm(h->stream, 1, g1, batch));
-      // Linv21 = -Linv22 * T21  (NN; Linv22 lower: k <= m)
+      g1.sA = pstride_U; g1.sB = pstride_I; g1.sC = pstride_T;
+      GPP_TRY(gpp_launch_gemm(h->stream, 2, g1, batch));
+      // Linv21 = -W22^T * T21  (TN; W22 = mirrored upper part of the (o+s) block: keep k <= m), plus its mirror
       GemmArgs g2 = mk(Linv + (o + s) * ldi + (o + s), ldi, T + (o + s) * ldt + o, ldt, Linv + (o + s) * ldi + o, ldi, m2,
                        s, m2, -1.0, 0.0);
       g2.a_mask = 1; g2.khi_mode = 1;
       g2.sA = pstride_I; g2.sB = pstride_T; g2.sC = pstride_I;
-      GPP_TRY(gpp_launch_gemm(h->stream, 1, g2, batch));
+      g2.C2 = Linv + o * ldi + (o + s); g2.ldc2 = ldi; g2.sC2 = pstride_I;
+      GPP_TRY(gpp_launch_gemm(h->stream, 2, g2, batch));
     }
   }
   return 0;
@@ -253,17 +259,17 @@ int gpp_lauum(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double
   return 0;
 }
 
-int gpp_mll_reduce(gpp_handle_t h, const double* L, int64_t ld, const double* Linv, int64_t ldi, int64_t N,
+int gpp_mll_reduce(gpp_handle_t h, const double* U, int64_t ld, const double* Linv, int64_t ldi, int64_t N,
                    const double* r, double* z, double* out3) {
   if (!h) return -1;
   if (N < 0) return -6;
-  if (int q = check_mat(L, ld, N, 2)) return q;
+  if (int q = check_mat(U, ld, N, 2)) return q;
   if (int q = check_mat(Linv, ldi, N, 4)) return q;
   if (!r || !aligned16(r)) return -7;
   if (!z) return -8;
   if (!out3) return -9;
   GPP_TRY(gpp_launch_trmv_lower(h->stream, Linv, ldi, N, r, z));
-  GPP_TRY(gpp_launch_mll_scalars(h->stream, L, ld, N, z, out3));
+  GPP_TRY(gpp_launch_mll_scalars(h->stream, U, ld, N, z, out3));
   return 0;
 }
 
@@ -271,11 +277,10 @@ int gpp_alpha(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, const 
   if (!h) return -1;
   if (N < 0) return -4;
   if (int q = check_mat(Linv, ldi, N, 2)) return q;
-  if (!z) return -5;
+  if (!z || !aligned16(z)) return -5;
   if (!alpha) return -6;
-  const size_t need = (size_t)((N + 1023) / 1024) * (size_t)N * sizeof(double);
-  if (!h->ws || h->ws_bytes < need) return -1;
-  GPP_TRY(gpp_launch_trmv_lower_t(h->stream, Linv, ldi, N, z, alpha, reinterpret_cast<double*>(h->ws)));
+  // alpha_j = sum_{i>=j} Linv[i][j] z_i = row j of the mirror (upper triangle of the buffer) times z
+  GPP_TRY(gpp_launch_trmv_upper(h->stream, Linv, ldi, N, z, alpha));
   return 0;
 }
 
@@ -327,7 +332,7 @@ int gpp_predict(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, cons
 
 int gpp_gemm(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
              int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int a_mask, int b_mask,
-             int klo_mode, int khi_mode, int c_lower) {
+             int klo_mode, int khi_mode, int c_tri) {
   if (!h) return -1;
   int variant;
   if (transA == 0 && transB == 1) variant = 0;
@@ -340,9 +345,9 @@ int gpp_gemm(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64
   if (!C || !aligned16(C) || (ldc & 1)) return -13;
   if (a_mask < 0 || a_mask > 2 || b_mask < 0 || b_mask > 2) return -15;
   if (klo_mode < 0 || klo_mode > 3 || khi_mode < 0 || khi_mode > 2) return -17;
-  if (c_lower && M != N) return -19;
+  if (c_tri < 0 || c_tri > 2 || (c_tri && M != N)) return -19;
   GemmArgs g = mk(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta);
-  g.a_mask = a_mask; g.b_mask = b_mask; g.klo_mode = klo_mode; g.khi_mode = khi_mode; g.c_lower = c_lower ? 1 : 0;
+  g.a_mask = a_mask; g.b_mask = b_mask; g.klo_mode = klo_mode; g.khi_mode = khi_mode; g.c_lower = c_tri;
   GPP_TRY(gpp_launch_gemm(h->stream, variant, g, 1));
   return 0;
 }

@@ -31,7 +31,7 @@ __device__ __forceinline__ double kfun(double r2_rbf, double r2_mat, int kind) {
   return v;
 }
 
-// grid.x = tile id.  lower != 0: tiles enumerated over the lower triangle of a square problem.
+// grid.x = tile id.  lower = 1 / 2: only the tiles of the lower / upper triangle of a square problem are written.
 __global__ __launch_bounds__(256) void gpp_cov_tile(const double* __restrict__ Ua, int64_t Ma, const double* __restrict__ Ub,
                                                     int64_t Nb, int D, const double* __restrict__ w,
                                                     const double* __restrict__ sf2p, const double* __restrict__ tau,
@@ -51,6 +51,11 @@ __global__ __launch_bounds__(256) void gpp_cov_tile(const double* __restrict__ U
       while (r * (r + 1) / 2 - (int64_t)base > t) --r;
       ti = r;
       tj = t - (r * (r + 1) / 2 - (int64_t)base);
+      if (lower == 2) {  // upper triangle: mirrored tile of the same enumeration
+        const int64_t q = ti;
+        ti = tj;
+        tj = q;
+      }
     } else {
       ti = tile_row0 + t / tiles_n;
       tj = t % tiles_n;

@@ -24,12 +24,14 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int BK = 16;
-// LDS row strides (doubles) for a tile edge T.  [k][row]-stored chunks of row-contiguous operands use T+16: 16-byte
-// aligned rows for ds_write_b128.  Chunks transposed on the fly from k-contiguous operands use T+17: the 16 lanes of
-// a ds_write_b64 group hold (row r, k = 0,2,..,14) and (row r+1, same k), so an odd stride spreads them over all 16
-// 8-byte bank slots.
+// LDS layouts.  Row-contiguous operands ("MC", stored [k][row] in memory) are staged as [k][T+16]: 16-byte aligned
+// rows for ds_write_b128, and the two k-rows a 32-lane ds_read_b64 group touches fall in different bank halves.
+// k-contiguous operands ("KC", stored [row][k]) are staged UNtransposed as [row][18]: every thread writes its 16-byte
+// vector with one ds_write_b128 (8 lanes = one 128-byte row), and with the 144-byte row stride both fragment reads
+// are conflict free: A lanes (i=0..3, k, k+1) hit slots {18i + k}, B lanes (c=0..15, k, k+1) hit 18c + k mod 32,
+// which enumerates all 32 8-byte slots.
 constexpr int ldt_mc(int T) { return T + 16; }
-constexpr int ldt_kc(int T) { return T + 17; }
+constexpr int LDK = BK + 2;  // [row][k] chunks of k-contiguous operands: 144-byte rows, see below
 
 // Staging is split in two so that the global loads of chunk c+1 stay in flight across the MFMAs of chunk c:
 //   load_*  : computes the keep-predicates (range + triangular mask; no loaded data involved) and issues one
@@ -60,15 +62,17 @@ __device__ __forceinline__ unsigned load_kc(const double* __restrict__ P, int64_
   }
   return keep;
 }
-template <int T>
+template <int T, bool SEL>
 __device__ __forceinline__ void store_kc(double* __restrict__ s, int tid, const v2d (&reg)[T / 32], unsigned keep) {
 #pragma unroll
   for (int i = 0; i < T / 32; ++i) {
     const int v = tid + 256 * i;
-    const int r = v >> 3;
-    const int kv = (v & 7) << 1;
-    s[kv * ldt_kc(T) + r] = ((keep >> (2 * i)) & 1u) ? reg[i].x : 0.0;
-    s[(kv + 1) * ldt_kc(T) + r] = ((keep >> (2 * i + 1)) & 1u) ? reg[i].y : 0.0;
+    v2d t = reg[i];
+    if (SEL) {
+      t.x = ((keep >> (2 * i)) & 1u) ? t.x : 0.0;
+      t.y = ((keep >> (2 * i + 1)) & 1u) ? t.y : 0.0;
+    }
+    *reinterpret_cast<v2d*>(s + (v >> 3) * LDK + ((v & 7) << 1)) = t;
   }
 }
 
@@ -92,28 +96,57 @@ __device__ __forceinline__ unsigned load_mc(const double* __restrict__ P, int64_
   }
   return keep;
 }
-template <int T>
+template <int T, bool SEL>
 __device__ __forceinline__ void store_mc(double* __restrict__ s, int tid, const v2d (&reg)[T / 32], unsigned keep) {
 #pragma unroll
   for (int i = 0; i < T / 32; ++i) {
     const int v = tid + 256 * i;
-    const int k = v / (T / 2);
-    const int rv = (v % (T / 2)) << 1;
-    v2d t;
-    t.x = ((keep >> (2 * i)) & 1u) ? reg[i].x : 0.0;
-    t.y = ((keep >> (2 * i + 1)) & 1u) ? reg[i].y : 0.0;
-    *reinterpret_cast<v2d*>(s + k * ldt_mc(T) + rv) = t;
+    v2d t = reg[i];
+    if (SEL) {
+      t.x = ((keep >> (2 * i)) & 1u) ? t.x : 0.0;
+      t.y = ((keep >> (2 * i + 1)) & 1u) ? t.y : 0.0;
+    }
+    *reinterpret_cast<v2d*>(s + (v / (T / 2)) * ldt_mc(T) + ((v % (T / 2)) << 1)) = t;
   }
 }
 
+// ---- interior fast path --------------------------------------------------------------------------------
+// For a chunk whose 16 k's and T rows are all in range and untouched by the triangular mask (a work-group-uniform
+// test), staging needs no predicates at all: one load per vector from  uniform_base + per-thread 32-bit byte offset
+// (SGPR-base addressing), and plain LDS stores.  This removes ~3/4 of the VALU instructions that otherwise compete
+// with the MFMAs for the SIMD's issue port.
+template <int T>
+__device__ __forceinline__ bool chunk_is_interior(int r0, int R, int kb, int kend, int mask) {
+  if (r0 + T > R || kb + BK > kend) return false;
+  if (mask == 1) return kb + BK - 1 <= r0;      // keep k <= row holds for every row >= r0
+  if (mask == 2) return kb >= r0 + T - 1;       // keep k >= row holds for every row <  r0 + T
+  return true;
+}
+template <int T, bool KC>
+__device__ __forceinline__ void thread_offsets(int64_t ld, int tid, unsigned (&off)[T / 32]) {
+#pragma unroll
+  for (int i = 0; i < T / 32; ++i) {
+    const int v = tid + 256 * i;
+    if (KC) off[i] = (unsigned)(((int64_t)(v >> 3) * ld + ((v & 7) << 1)) * 8);
+    else off[i] = (unsigned)(((int64_t)(v / (T / 2)) * ld + ((v % (T / 2)) << 1)) * 8);
+  }
+}
+template <int T>
+__device__ __forceinline__ void load_fast(const double* __restrict__ ubase, const unsigned (&off)[T / 32], v2d (&reg)[T / 32]) {
+#pragma unroll
+  for (int i = 0; i < T / 32; ++i)
+    reg[i] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(ubase) + off[i]);
+}
+
+// The row-contiguous TN variant (every hot product of the evaluation) keeps 2 work-groups per CU (<= 256 VGPRs);
+// variants with a k-contiguous operand are off the hot path (prediction, tests) and take the registers they need.
 template <int VAR, int WT>
-__global__ __launch_bounds__(256, 2) void gpp_gemm_f64(GemmArgs p) {
+__global__ __launch_bounds__(256, (VAR == 2 || WT < 64) ? 2 : 1) void gpp_gemm_f64(GemmArgs p) {
   constexpr bool A_KC = (VAR != 2);
   constexpr bool B_KC = (VAR == 0);
   constexpr int T = 2 * WT;  // work-group tile edge
-  constexpr int LDA = A_KC ? ldt_kc(T) : ldt_mc(T);
-  constexpr int LDB = B_KC ? ldt_kc(T) : ldt_mc(T);
-  constexpr int OPSZ = BK * ldt_kc(T);  // doubles per staged operand chunk (max of both strides)
+  constexpr int LDA = ldt_mc(T), LDB = ldt_mc(T);  // strides of [k][row] chunks (MC operands)
+  constexpr int OPSZ = (BK * ldt_mc(T) > T * LDK) ? BK * ldt_mc(T) : T * LDK;  // doubles per staged operand chunk
   constexpr int RB = WT / 4, CB = WT / 16;
   __shared__ __attribute__((aligned(16))) double smem[2 * 2 * OPSZ];
 
@@ -125,6 +158,11 @@ __global__ __launch_bounds__(256, 2) void gpp_gemm_f64(GemmArgs p) {
       while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
       while (tm * (tm + 1) / 2 > t) --tm;
       tn = t - tm * (tm + 1) / 2;
+      if (p.c_lower == 2) {  // upper triangle: same enumeration, mirrored tile
+        const int q = tm;
+        tm = tn;
+        tn = q;
+      }
     } else {
       tm = t / p.tiles_n;
       tn = t - tm * p.tiles_n;
@@ -157,47 +195,73 @@ __global__ __launch_bounds__(256, 2) void gpp_gemm_f64(GemmArgs p) {
 
   v2d ra[T / 32], rb[T / 32];
   unsigned ka = 0, kb_ = 0;
+  unsigned offa[T / 32], offb[T / 32];
+  thread_offsets<T, A_KC>(p.lda, tid, offa);
+  thread_offsets<T, B_KC>(p.ldb, tid, offb);
+  // uniform bases of the tile's first chunk row/column block; advanced by a scalar per chunk
+  const double* __restrict__ ubaseA = A_KC ? A + (int64_t)row0 * p.lda : A + row0;
+  const double* __restrict__ ubaseB = B_KC ? B + (int64_t)col0 * p.ldb : B + col0;
+  const int64_t stepA = A_KC ? 1 : p.lda, stepB = B_KC ? 1 : p.ldb;  // elements per unit of k
+
+  bool fast = false;
+  auto stage_load = [&](int kb) {
+    // (the lean path is enabled for the row-contiguous TN variant only: with a k-contiguous operand the extra live
+    //  registers push hipcc over the 256-VGPR budget of 2 waves/SIMD and the spills cost more than the VALU saved)
+    fast = (VAR == 2) && chunk_is_interior<T>(row0, p.M, kb, khi, p.a_mask) &&
+           chunk_is_interior<T>(col0, p.N, kb, khi, p.b_mask);
+    if (fast) {
+      load_fast<T>(ubaseA + (int64_t)kb * stepA, offa, ra);
+      load_fast<T>(ubaseB + (int64_t)kb * stepB, offb, rb);
+    } else {
+      ka = A_KC ? load_kc<T>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra)
+                : load_mc<T>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra);
+      kb_ = B_KC ? load_kc<T>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb)
+                 : load_mc<T>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb);
+    }
+  };
+  auto stage_store = [&](double* da, double* db) {
+    if (fast) {
+      if (A_KC) store_kc<T, false>(da, tid, ra, 0); else store_mc<T, false>(da, tid, ra, 0);
+      if (B_KC) store_kc<T, false>(db, tid, rb, 0); else store_mc<T, false>(db, tid, rb, 0);
+    } else {
+      if (A_KC) store_kc<T, true>(da, tid, ra, ka); else store_mc<T, true>(da, tid, ra, ka);
+      if (B_KC) store_kc<T, true>(db, tid, rb, kb_); else store_mc<T, true>(db, tid, rb, kb_);
+    }
+  };
+
   if (nch > 0) {
-    ka = A_KC ? load_kc<T>(A, p.lda, p.M, row0, klo, khi, p.a_mask, tid, ra)
-              : load_mc<T>(A, p.lda, p.M, row0, klo, khi, p.a_mask, tid, ra);
-    kb_ = B_KC ? load_kc<T>(B, p.ldb, p.N, col0, klo, khi, p.b_mask, tid, rb)
-               : load_mc<T>(B, p.ldb, p.N, col0, klo, khi, p.b_mask, tid, rb);
-    if (A_KC) store_kc<T>(smem, tid, ra, ka); else store_mc<T>(smem, tid, ra, ka);
-    if (B_KC) store_kc<T>(smem + OPSZ, tid, rb, kb_); else store_mc<T>(smem + OPSZ, tid, rb, kb_);
+    stage_load(klo);
+    stage_store(smem, smem + OPSZ);
   }
   __syncthreads();
 
   for (int c = 0; c < nch; ++c) {
     const int cur = c & 1;
     const bool more = (c + 1 < nch);
-    if (more) {
-      const int kb = klo + (c + 1) * BK;
-      ka = A_KC ? load_kc<T>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra)
-                : load_mc<T>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra);
-      kb_ = B_KC ? load_kc<T>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb)
-                 : load_mc<T>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb);
-    }
+    if (more) stage_load(klo + (c + 1) * BK);
     // A fragment: lane (i = l&3, k = l>>4), same address in the 4 column groups (l>>2)&3 -> LDS broadcast
-    const double* sa = smem + (cur * 2 + 0) * OPSZ + wm + (lane & 3);
-    const double* sb = smem + (cur * 2 + 1) * OPSZ + wn + li;
+    const double* sa = smem + (cur * 2 + 0) * OPSZ + (A_KC ? (wm + (lane & 3)) * LDK + lk : wm + (lane & 3) + lk * LDA);
+    const double* sb = smem + (cur * 2 + 1) * OPSZ + (B_KC ? (wn + li) * LDK + lk : wn + li + lk * LDB);
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      double af[RB], bf[CB];
+      double bf[CB];
 #pragma unroll
-      for (int a = 0; a < RB; ++a) af[a] = sa[(kk * 4 + lk) * LDA + 4 * a];
+      for (int b = 0; b < CB; ++b) bf[b] = B_KC ? sb[16 * b * LDK + kk * 4] : sb[kk * 4 * LDB + 16 * b];
+      // A fragments in groups of <= 8 row blocks: bounds the live registers (acc + staging already take ~170)
+      constexpr int AG = RB < 8 ? RB : 8;
 #pragma unroll
-      for (int b = 0; b < CB; ++b) bf[b] = sb[(kk * 4 + lk) * LDB + 16 * b];
+      for (int a0 = 0; a0 < RB; a0 += AG) {
+        double af[AG];
 #pragma unroll
-      for (int a = 0; a < RB; ++a)
+        for (int a = 0; a < AG; ++a) af[a] = A_KC ? sa[4 * (a0 + a) * LDK + kk * 4] : sa[kk * 4 * LDA + 4 * (a0 + a)];
 #pragma unroll
-        for (int b = 0; b < CB; ++b) acc[a][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[b], acc[a][b], 0, 0, 0);
+        for (int a = 0; a < AG; ++a)
+#pragma unroll
+          for (int b = 0; b < CB; ++b)
+            acc[a0 + a][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[b], acc[a0 + a][b], 0, 0, 0);
+      }
     }
-    if (more) {
-      double* da = smem + ((cur ^ 1) * 2 + 0) * OPSZ;
-      double* db = smem + ((cur ^ 1) * 2 + 1) * OPSZ;
-      if (A_KC) store_kc<T>(da, tid, ra, ka); else store_mc<T>(da, tid, ra, ka);
-      if (B_KC) store_kc<T>(db, tid, rb, kb_); else store_mc<T>(db, tid, rb, kb_);
-    }
+    if (more) stage_store(smem + ((cur ^ 1) * 2 + 0) * OPSZ, smem + ((cur ^ 1) * 2 + 1) * OPSZ);
     __syncthreads();
   }
 
@@ -215,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void gpp_gemm_f64(GemmArgs p) {
 #pragma unroll
         for (int b = 0; b < CB; ++b) {
           const int n = col0 + wn + 16 * b + li;
-          const bool ok = (m < p.M) && (n < p.N) && (!p.c_lower || n <= m);
+          const bool ok = (m < p.M) && (n < p.N) && (p.c_lower == 0 || (p.c_lower == 1 ? n <= m : n >= m));
           const double* src = ok ? C + (int64_t)m * p.ldc + n : C;
           cold[a][b] = *src;
         }
@@ -227,10 +291,13 @@ __global__ __launch_bounds__(256, 2) void gpp_gemm_f64(GemmArgs p) {
 #pragma unroll
       for (int b = 0; b < CB; ++b) {
         const int n = col0 + wn + 16 * b + li;
-        const bool ok = (m < p.M) && (n < p.N) && (!p.c_lower || n <= m);
+        const bool ok = (m < p.M) && (n < p.N) && (p.c_lower == 0 || (p.c_lower == 1 ? n <= m : n >= m));
         double v = alpha * acc[a0 + a][b];
         if (beta != 0.0) v = fma(beta, cold[a][b], v);
-        if (ok) C[(int64_t)m * p.ldc + n] = v;
+        if (ok) {
+          C[(int64_t)m * p.ldc + n] = v;
+          if (p.C2) p.C2[(int64_t)blockIdx.y * p.sC2 + (int64_t)n * p.ldc2 + m] = v;  // mirrored (transposed) copy
+        }
       }
     }
   }
@@ -255,7 +322,7 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int
   if (a.M <= 0 || a.N <= 0 || batch <= 0) return hipSuccess;
   auto ntiles = [&](int T) -> int64_t {
     const int64_t tm = (a.M + T - 1) / T, tn = (a.N + T - 1) / T;
-    return (a.c_lower ? tm * (tm + 1) / 2 : tm * tn) * batch;
+    return (a.c_lower ? tm * (tm + 1) / 2 : tm * tn) * batch;  // triangular output needs M == N
   };
   if (tile == 0) {
     // enough 128^2 tiles to give every CU a work-group -> big tile; otherwise shrink until the chip is covered

@@ -23,15 +23,19 @@ struct GemmArgs {
   double alpha, beta;
   int a_mask, b_mask;      // 0 none, 1 keep k<=row, 2 keep k>=row
   int klo_mode, khi_mode;  // see gpp.h
-  int c_lower;
+  int c_lower;             // 0 full, 1 lower triangle only (n <= m), 2 upper triangle only (n >= m)
   int64_t sA, sB, sC;      // batch strides in elements (grid.y = batch)
   int tiles_m, tiles_n;
+  double* C2;              // optional mirrored output: C2[n][m] = C[m][n]
+  int64_t ldc2, sC2;
 };
 // variant: 0 = NT (A[m][k], B[n][k]), 1 = NN (A[m][k], B[k][n]), 2 = TN (A[k][m], B[k][n])
 // tile: 0 = choose from the grid size, or force the work-group tile edge 128 / 64 / 32
 hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a, int batch, int tile = 0);
 
 // ---- 128x128 diagonal leaf: Cholesky + triangular inverse in LDS (gpp_leaf.hip) ---------------
+// A holds the UPPER factor (A = U^T U, i.e. L = U^T read/written with swapped indices); the n x n diagonal block of
+// Linv receives inv(L) in its lower triangle and the mirror image inv(L)^T in its strict upper triangle.
 hipError_t gpp_launch_leaf(hipStream_t s, double* A, int64_t lda, double* Linv, int64_t ldi, int n, int32_t* info,
                            int row_offset);
 
@@ -44,8 +48,7 @@ hipError_t gpp_launch_cross_kernel(hipStream_t s, const double* Ua, int64_t Ma, 
 
 // ---- reductions (gpp_reduce.hip) --------------------------------------------------------------
 hipError_t gpp_launch_trmv_lower(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y);
-hipError_t gpp_launch_trmv_lower_t(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
-                                   double* part /* ceil(N/1024) x N */);
+hipError_t gpp_launch_trmv_upper(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y);
 hipError_t gpp_launch_mll_scalars(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* z, double* out3);
 size_t gpp_grad_ws_bytes(int64_t N, int D, int S, int dU);
 hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int D, const double* w, const double* sf2,

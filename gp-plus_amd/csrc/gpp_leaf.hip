@@ -3,8 +3,10 @@
 // LAPACK potf2/trti2 steps inside torch.linalg.cholesky_ex (reference call site: gpytorch psd_safe_cholesky reached
 // from optim/mll_torch.py:116).  It sits on the critical path N/128 times per factorisation, so it is latency-tuned.
 //
-//   in : A[n x n] (lower triangle read; the strict upper triangle is never touched)
-//   out: A    <- L (lower triangle),  Linv <- inv(L) (lower triangle; strict upper of the block zeroed)
+//   in : A[n x n], UPPER triangle read (A = U^T U with U stored row-major = L stored column-major; the strict lower
+//        triangle is never touched).  Internally the kernel works on L = U^T: every access to A swaps its indices.
+//   out: A    <- U (upper triangle),  Linv block <- inv(L) in the lower triangle AND inv(L)^T mirrored in the strict
+//        upper triangle (the mirror lets the inverse enter later products as a row-contiguous "TN" operand)
 //        *info <- row_offset + k + 1 for the first non-positive / NaN pivot (kept if already non-zero)
 //
 // Layout: the 128 x 128 block is an 8 x 8 grid of 16 x 16 tiles; the 36 lower tiles are dealt to the 4 waves
@@ -74,7 +76,7 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
     for (int r = 0; r < 4; ++r) {
       const int row = 16 * ti[q] + lr + 4 * r, col = 16 * tj[q] + lc;
       double v = (row == col) ? 1.0 : 0.0;
-      if (row < n && col <= row) v = A[(int64_t)row * lda + col];
+      if (row < n && col <= row) v = A[(int64_t)col * lda + row];  // L[row][col] = U[col][row]
       acc[q][r] = v;
     }
   }
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
           const double lv = (c <= i) ? a[c] : 0.0;
           D[i * TLD + c] = lv;
           Xd[c * TLD + i] = x[c];  // X[c][i]
-          if (grow < n && c <= i) A[(int64_t)grow * lda + 16 * s + c] = lv;
+          if (grow < n && c <= i) A[(int64_t)(16 * s + c) * lda + grow] = lv;  // U[col][row] = L[row][col]
         }
       }
     }
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * ti[q] + lr + 4 * r;
-            if (row < n) A[(int64_t)row * lda + 16 * s + lc] = o[r];
+            if (row < n) A[(int64_t)(16 * s + lc) * lda + row] = o[r];  // U[col][row] = L[row][col]
           }
         }
       }
@@ -229,12 +231,11 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
     __syncthreads();
   }
 
-  // write inv(L): lower tiles from LDS, strict-upper tiles of the block as zeros
+  // write inv(L) into the lower triangle of the block and its transpose into the strict upper triangle
   for (int e = tid; e < n * n; e += 256) {
     const int row = e / n, col = e - row * n;
-    double v = 0.0;
-    if (col <= row) v = Ximg[toff(row >> 4, col >> 4) + (row & 15) * TLD + (col & 15)];
-    Linv[(int64_t)row * ldi + col] = v;
+    const int hi = row > col ? row : col, lo = row > col ? col : row;
+    Linv[(int64_t)row * ldi + col] = Ximg[toff(hi >> 4, lo >> 4) + (hi & 15) * TLD + (lo & 15)];
   }
 }
 

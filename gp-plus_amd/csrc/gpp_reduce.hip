@@ -39,29 +39,29 @@ __global__ __launch_bounds__(256) void gpp_trmv_lower(const double* __restrict__
   if (lane == 0) y[i] = acc;
 }
 
-// stage 1 of y_j = sum_{i>=j} T[i][j] x_i : block (cb, rb) sums rows [rb*1024, rb*1024+1024) for columns cb*256+tx.
-constexpr int TR_ROWS = 1024;
-__global__ __launch_bounds__(256) void gpp_trmv_lower_t_part(const double* __restrict__ T, int64_t ldt, int64_t N,
-                                                             const double* __restrict__ x, double* __restrict__ part) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t rb = blockIdx.y;
-  const int64_t r0 = rb * TR_ROWS;
-  int64_t r1 = r0 + TR_ROWS;
-  if (r1 > N) r1 = N;
-  double acc = 0.0;
-  if (j < N && r1 > (int64_t)blockIdx.x * 256) {
-    int64_t i = r0 > j ? r0 : j;
-    for (; i < r1; ++i) acc = fma(T[i * ldt + j], x[i], acc);
-  }
-  if (j < N) part[rb * N + j] = acc;
-}
-__global__ __launch_bounds__(256) void gpp_colsum_parts(const double* __restrict__ part, int64_t N, int nparts,
-                                                        double* __restrict__ y) {
-  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// y_j = sum_{i>=j} T[j][i] x_i for the UPPER triangle of T: one wave per row (the mirror of gpp_trmv_lower).
+__global__ __launch_bounds__(256) void gpp_trmv_upper(const double* __restrict__ T, int64_t ldt, int64_t N,
+                                                      const double* __restrict__ x, double* __restrict__ y) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t j = (int64_t)blockIdx.x * 4 + wave;
   if (j >= N) return;
+  const double* row = T + j * ldt;
   double acc = 0.0;
-  for (int p = 0; p < nparts; ++p) acc += part[(int64_t)p * N + j];
-  y[j] = acc;
+  int64_t k0 = j;
+  if (k0 & 1) {  // align the vector loop to an even column
+    if (lane == 0) acc = fma(row[k0], x[k0], acc);
+    ++k0;
+  }
+  const int64_t nvec = (N - k0) >> 1;
+  for (int64_t v = lane; v < nvec; v += 64) {
+    const v2d t = *reinterpret_cast<const v2d*>(row + k0 + 2 * v);
+    const v2d xx = *reinterpret_cast<const v2d*>(x + k0 + 2 * v);
+    acc = fma(t.x, xx.x, acc);
+    acc = fma(t.y, xx.y, acc);
+  }
+  if (lane == 0 && ((N - k0) & 1)) acc = fma(row[N - 1], x[N - 1], acc);
+  acc = wave_sum(acc);
+  if (lane == 0) y[j] = acc;
 }
 
 // out3 = { quad = z'z, logdet = 2 sum log L_ii, mll = -0.5 (quad + logdet + N log 2pi) } : one work-group.
@@ -322,13 +322,9 @@ hipError_t gpp_launch_trmv_lower(hipStream_t s, const double* T, int64_t ldt, in
   return hipGetLastError();
 }
 
-hipError_t gpp_launch_trmv_lower_t(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
-                                   double* part) {
+hipError_t gpp_launch_trmv_upper(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y) {
   if (N <= 0) return hipSuccess;
-  const int nparts = (int)((N + TR_ROWS - 1) / TR_ROWS);
-  hipLaunchKernelGGL(gpp_trmv_lower_t_part, dim3((unsigned)((N + 255) / 256), (unsigned)nparts), dim3(256), 0, s, T, ldt, N,
-                     x, part);
-  hipLaunchKernelGGL(gpp_colsum_parts, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, part, N, nparts, y);
+  hipLaunchKernelGGL(gpp_trmv_upper, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, T, ldt, N, x, y);
   return hipGetLastError();
 }
 

@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-from . import settings
+from .. import settings
 from .kernels import DiagNoise, LazyKernelMatrix
 
 

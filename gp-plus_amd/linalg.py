@@ -17,9 +17,9 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from .backend import (KIND_RBF, OP_MLL_EVAL, UPLO_FULL, UPLO_LOWER, GppContext, get_context, square_buffer)
-from .gpcore.errors import NanError, NotPSDError
-from .gpcore import settings
+from .backend import (KIND_RBF, OP_MLL_EVAL, UPLO_FULL, UPLO_UPPER, GppContext, get_context, square_buffer)
+from .errors import NanError, NotPSDError
+from . import settings
 
 __all__ = ["KernelSpec", "exact_mll", "ExactMLLFunction", "EvalWorkspace", "dense_kernel", "cross_kernel",
            "FactorCache", "factorize", "dense_log_prob"]
@@ -35,8 +35,8 @@ class KernelSpec:
 
 
 class EvalWorkspace:
-    """Device buffers of one N-point evaluation, reused across evaluations (3 N x N fp64 matrices: Ky->L, Linv,
-    scratch/Kinv).  ``epoch`` increments on every forward so a stale backward can tell its factors were overwritten."""
+    """Device buffers of one N-point evaluation, reused across evaluations (3 N x N fp64 matrices: Ky -> U (upper),
+    Linv (lower) + its mirror (upper), scratch / Kinv (lower)).  ``epoch`` increments on every forward so a stale backward can tell its factors were overwritten."""
 
     def __init__(self, ctx: GppContext, N: int):
         dev = ctx.device
@@ -53,6 +53,28 @@ class EvalWorkspace:
 
 
 _workspaces: Dict[Tuple[int, int, int], EvalWorkspace] = {}
+
+#: optional stage timing (bench.py): when this is a list, every stage appends (name, start_event, end_event) recorded
+#: on the stream the kernels are launched on (PyTorch's current stream).
+STAGE_EVENTS = None
+
+
+class _stage:
+    def __init__(self, name: str):
+        self.name = name
+
+    def __enter__(self):
+        if STAGE_EVENTS is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if STAGE_EVENTS is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            STAGE_EVENTS.append((self.name, self.e0, e1))
+        return False
 
 
 def get_workspace(ctx: GppContext, N: int, slot: int = 0) -> EvalWorkspace:
@@ -75,8 +97,10 @@ def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_spl
     """Build Ky (lower) and factor it, with gpytorch's jitter-retry policy.  Returns the jitter that was needed."""
     jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
     for jit in jitters:
-        ctx.kernel_build(U, w, sf2, tau, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_LOWER)
-        ctx.potrf(ws.A, ws.Li, ws.info)
+        with _stage("kernel_build"):
+            ctx.kernel_build(U, w, sf2, tau, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_UPPER)
+        with _stage("potrf"):
+            ctx.potrf(ws.A, ws.Li, ws.info)
         info = int(ws.info.item())  # the one host sync of an evaluation (the reference syncs on loss.item() too)
         if info == 0:
             if jit > 0:
@@ -106,9 +130,11 @@ class ExactMLLFunction(torch.autograd.Function):
         ws = get_workspace(gctx, N, slot)
         ws.epoch += 1
         jit = _factor(gctx, ws, Ud, wd, sd, td, grp, kind, d_split)
-        gctx.trtri(ws.A, ws.Li, ws.Ki)
+        with _stage("trtri"):
+            gctx.trtri(ws.A, ws.Li, ws.Ki)
         torch.sub(_as_f64(y.detach(), dev), _as_f64(mean.detach(), dev), out=ws.r)
-        gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
+        with _stage("mll_reduce"):
+            gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
         ctx.saved = (gctx, ws, ws.epoch, Ud, wd, sd, td, grp, S, kind, d_split, dU, jit, ws.r.clone())
         ctx.in_dtypes = (U.dtype, w.dtype, sf2.dtype, tau.dtype, mean.dtype, y.dtype)
         ctx.shapes = (sf2.shape, tau.shape)
@@ -122,21 +148,24 @@ class ExactMLLFunction(torch.autograd.Function):
         if ws.epoch != epoch:
             # another forward reused the buffers: rebuild this evaluation's factors (correct, costs one extra potrf)
             ws.epoch += 1
-            gctx.kernel_build(Ud, wd, sd, td, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_LOWER)
+            gctx.kernel_build(Ud, wd, sd, td, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_UPPER)
             gctx.potrf(ws.A, ws.Li, ws.info)
             gctx.trtri(ws.A, ws.Li, ws.Ki)
             ws.r.copy_(r_saved)
             gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
-        gctx.alpha(ws.Li, ws.z, ws.alpha)
-        gctx.lauum(ws.Li, ws.Ki)
+        with _stage("alpha"):
+            gctx.alpha(ws.Li, ws.z, ws.alpha)
+        with _stage("lauum"):
+            gctx.lauum(ws.Li, ws.Ki)
         g_w = torch.empty(D, dtype=torch.float64, device=dev)
         g_s = torch.empty(1, dtype=torch.float64, device=dev)
         g_t = torch.empty(S, dtype=torch.float64, device=dev)
         need_U = ctx.needs_input_grad[0] and dU > 0
         g_U = torch.zeros(N, D, dtype=torch.float64, device=dev) if ctx.needs_input_grad[0] else None
         g_Ud = torch.empty(N, dU, dtype=torch.float64, device=dev) if need_U else None
-        gctx.grad_reduce(Ud, wd, sd, grp, S, ws.alpha, ws.Ki, dU if need_U else 0, g_w, g_s, g_t, g_Ud, kind=kind,
-                         d_split=d_split)
+        with _stage("grad_reduce"):
+            gctx.grad_reduce(Ud, wd, sd, grp, S, ws.alpha, ws.Ki, dU if need_U else 0, g_w, g_s, g_t, g_Ud, kind=kind,
+                             d_split=d_split)
         if need_U:
             g_U[:, :dU] = g_Ud
         go = grad_out.to(torch.float64)

@@ -10,8 +10,11 @@
  *
  * Conventions
  *  - every pointer is a DEVICE pointer owned by the caller (PyTorch tensors), except where noted "host";
- *  - matrices are row-major fp64 with an explicit leading dimension `ld` (elements); N x N factors keep
- *    the LOWER triangle authoritative, the strict upper triangle is never read;
+ *  - matrices are row-major fp64 with an explicit leading dimension `ld` (elements).  The covariance and its Cholesky
+ *    factor keep the UPPER triangle authoritative (Ky = U^T U, U row-major == L = U^T column-major, LAPACK 'L' on a
+ *    column-major array); the strict lower triangle of that buffer is never read or written.  The inverse factor
+ *    buffer `Linv` holds L^-1 in its lower triangle and the mirror image L^-T in its strict upper triangle; Kinv keeps
+ *    its LOWER triangle authoritative.  (This mix makes every O(N^3) product a row-contiguous "TN" GEMM.)
  *  - N x N matrix pointers must be 16-byte aligned and `ld` even (the kernels use 16-byte accesses);
  *  - all work is enqueued on the handle's stream (gpp_set_stream) and is asynchronous to the host;
  *  - return value: 0 ok, <0 bad argument (-(index of the argument)), >0 HIP runtime error code + 1000;
@@ -40,6 +43,7 @@ typedef struct gpp_handle_s* gpp_handle_t;
 
 #define GPP_UPLO_FULL  0
 #define GPP_UPLO_LOWER 1    /* only tiles that intersect the lower triangle are written */
+#define GPP_UPLO_UPPER 2    /* only tiles that intersect the upper triangle are written (what gpp_potrf reads) */
 
 /* operation ids for gpp_workspace_bytes */
 #define GPP_OP_MLL_EVAL 0   /* potrf + trtri + lauum + mll_reduce + grad_reduce for an N-point model */
@@ -71,23 +75,25 @@ int gpp_cross_kernel(gpp_handle_t h, const double* Ua, int64_t Ma, const double*
 
 /*
  * K5 (gpytorch psd_safe_cholesky -> torch.linalg.cholesky_ex reached from optim/mll_torch.py:116):
- * in-place lower Cholesky of A (N x N).  Recursive blocked factorisation; every product runs on the
- * fp64 MFMA GEMM kernel, 128 x 128 diagonal leaves are factored AND inverted in LDS.  On return the lower
- * triangle of A holds L and the 128-aligned diagonal blocks of Linv hold inv(L_bb) (needed by gpp_trtri).
+ * in-place Cholesky of A (N x N, UPPER triangle): A = U^T U.  Recursive blocked factorisation; every product runs
+ * on the fp64 MFMA GEMM kernel, 128 x 128 diagonal leaves are factored AND inverted in LDS.  On return the upper
+ * triangle of A holds U = L^T and the 128-aligned diagonal blocks of Linv hold inv(L_bb) (lower) mirrored with
+ * inv(L_bb)^T (upper), as gpp_trtri needs them.
  */
 int gpp_potrf(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, int64_t ldi, int32_t* info_dev);
 
-/* Completes Linv = inv(L) (lower) from the diagonal-block inverses left by gpp_potrf.  T (N x N) is scratch. */
-int gpp_trtri(gpp_handle_t h, const double* L, int64_t N, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt);
+/* Completes Linv = inv(L) (lower triangle, mirrored into the upper) from the diagonal-block inverses left by
+ * gpp_potrf.  `U` is the factored matrix (upper).  T (N x N) is scratch. */
+int gpp_trtri(gpp_handle_t h, const double* U, int64_t N, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt);
 
 /* Kinv(lower) = Linv^T Linv.  With gpp_trtri this is K7's "K_y^-1" (ATen cholesky_backward, optim/mll_torch.py:117). */
 int gpp_lauum(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double* Kinv, int64_t ldk);
 
 /*
  * K6 (gpytorch MultivariateNormal.log_prob -> inv_quad_logdet, optim/mll_torch.py:116):
- *   z = Linv r;  out3 = { quad = z'z, logdet = 2 sum log L_ii, mll = -0.5*(quad + logdet + N log 2pi) }
+ *   z = Linv r;  out3 = { quad = z'z, logdet = 2 sum log U_ii, mll = -0.5*(quad + logdet + N log 2pi) }
  */
-int gpp_mll_reduce(gpp_handle_t h, const double* L, int64_t ld, const double* Linv, int64_t ldi, int64_t N,
+int gpp_mll_reduce(gpp_handle_t h, const double* U, int64_t ld, const double* Linv, int64_t ldi, int64_t N,
                    const double* r, double* z, double* out3);
 
 /* alpha = Linv^T z = Ky^-1 r (gpytorch prediction_strategy mean_cache; dMLL/dmean) */
@@ -117,11 +123,11 @@ int gpp_predict(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, cons
  * Supported (transA,transB): (0,1) "NT", (0,0) "NN", (1,0) "TN".
  * a_mask/b_mask: 0 none, 1 keep entries with k <= row, 2 keep entries with k >= row (row = m for A, n for B);
  * klo_mode: 0 -> 0, 1 -> tile_m*128, 2 -> tile_n*128, 3 -> max of both;  khi_mode: 0 -> K, 1 -> (tile_m+1)*128,
- * 2 -> (tile_n+1)*128;  c_lower: compute/write only entries with n <= m (M == N).
+ * 2 -> (tile_n+1)*128;  c_tri: 0 full output, 1 only entries with n <= m, 2 only entries with n >= m (M == N).
  */
 int gpp_gemm(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
              int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int a_mask, int b_mask,
-             int klo_mode, int khi_mode, int c_lower);
+             int klo_mode, int khi_mode, int c_tri);
 
 #ifdef __cplusplus
 }

@@ -72,11 +72,17 @@ def test_gemm_masks_and_lower(gpu_ctx):
     np.testing.assert_allclose(out.cpu().numpy(), Lo @ X, rtol=1e-12, atol=1e-10)
     # TN lauum: Lo^T Lo, lower part only; upper part of `out` must stay untouched
     out.fill_(7.0)
-    gpu_ctx.gemm(1, 0, n, n, n, 1.0, dL, dL, 0.0, out, a_mask=2, b_mask=2, klo_mode=3, c_lower=1)
+    gpu_ctx.gemm(1, 0, n, n, n, 1.0, dL, dL, 0.0, out, a_mask=2, b_mask=2, klo_mode=3, c_tri=1)
     got = out.cpu().numpy()
     ref = Lo.T @ Lo
     np.testing.assert_allclose(np.tril(got), np.tril(ref), rtol=1e-12, atol=1e-10)
     assert np.all(np.triu(got, 1) == np.triu(np.full((n, n), 7.0), 1))
+    # TN syrk-style update of the UPPER triangle only: C -= X^T X
+    out.fill_(7.0)
+    gpu_ctx.gemm(1, 0, n, n, n, -1.0, dX, dX, 1.0, out, c_tri=2)
+    got = out.cpu().numpy()
+    np.testing.assert_allclose(np.triu(got), np.triu(7.0 - X.T @ X), rtol=1e-12, atol=1e-10)
+    assert np.all(np.tril(got, -1) == np.tril(np.full((n, n), 7.0), -1))
 
 
 @pytest.mark.parametrize("n,d", [(1, 3), (64, 8), (130, 2), (500, 8), (1000, 12)])
@@ -97,6 +103,9 @@ def test_kernel_build_and_cross(gpu_ctx, n, d):
     out2 = _sq(n, fill=-5.0)
     gpu_ctx.kernel_build(dU, dw, dsf2, _dev(tau), _dev(grp), out2, jitter=1e-6, uplo=1)
     np.testing.assert_allclose(np.tril(out2.cpu().numpy()), np.tril(ref), rtol=1e-13, atol=1e-15)
+    out3 = _sq(n, fill=-5.0)
+    gpu_ctx.kernel_build(dU, dw, dsf2, _dev(tau), _dev(grp), out3, jitter=1e-6, uplo=2)
+    np.testing.assert_allclose(np.triu(out3.cpu().numpy()), np.triu(ref), rtol=1e-13, atol=1e-15)
     # cross block against a different point set
     m = 77
     Ua = rng.standard_normal((m, d))
@@ -110,16 +119,19 @@ def test_kernel_build_and_cross(gpu_ctx, n, d):
 def test_potrf_trtri_lauum(gpu_ctx, n):
     U, w, K = _spd(n, seed=n)
     A, Li, T, Ki = _sq(n), _sq(n), _sq(n), _sq(n)
-    A.copy_(_dev(np.tril(K) + np.triu(np.full((n, n), np.nan), 1)))  # upper triangle must never be read
+    A.copy_(_dev(np.triu(K) + np.tril(np.full((n, n), np.nan), -1)))  # the strict lower triangle must never be read
     info = torch.full((1,), -1, dtype=torch.int32, device="cuda")
     gpu_ctx.potrf(A, Li, info)
     assert int(info.item()) == 0
     Lref = np.linalg.cholesky(K)
-    L = np.tril(A.cpu().numpy())
-    np.testing.assert_allclose(L, Lref, rtol=0, atol=1e-10 * np.abs(Lref).max())
+    Ufac = np.triu(A.cpu().numpy())
+    np.testing.assert_allclose(Ufac, Lref.T, rtol=0, atol=1e-10 * np.abs(Lref).max())
+    assert np.isnan(np.tril(A.cpu().numpy(), -1)[np.tril_indices(n, -1)]).all()  # ... and never written
     gpu_ctx.trtri(A, Li, T)
-    Linv = np.tril(Li.cpu().numpy())
+    full = Li.cpu().numpy()
+    Linv = np.tril(full)
     np.testing.assert_allclose(Linv @ Lref, np.eye(n), rtol=0, atol=1e-8)
+    np.testing.assert_array_equal(np.triu(full, 1), np.tril(full, -1).T)  # mirror image L^-T in the upper triangle
     gpu_ctx.lauum(Li, Ki)
     Kinv = np.tril(Ki.cpu().numpy())
     Kinv = Kinv + np.tril(Kinv, -1).T
@@ -166,7 +178,7 @@ def test_mll_and_grad_reduce(gpu_ctx, n, d, S, dU):
     dsf2 = torch.tensor([sf2], dtype=torch.float64, device="cuda")
     dgrp = _dev(grp)
     A, Li, T, Ki = _sq(n), _sq(n), _sq(n), _sq(n)
-    gpu_ctx.kernel_build(dUm, dw, dsf2, _dev(tau), dgrp, A, uplo=1)
+    gpu_ctx.kernel_build(dUm, dw, dsf2, _dev(tau), dgrp, A, uplo=2)
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
     gpu_ctx.potrf(A, Li, info)
     assert int(info.item()) == 0

@@ -229,7 +229,7 @@ def test_full_size_properties_n20000(gpu_ctx):
     assert float(resid.norm() / y.norm()) < 1e-8
     # L (Linv v) = v on the lower factors
     v = torch.randn(N, dtype=torch.float64, device="cuda", generator=g)
-    L = torch.tril(ws.A)
+    L = torch.triu(ws.A).T  # the factor is stored as U = L^T (upper triangle)
     t = torch.mv(torch.tril(ws.Li), v)
     assert float((torch.mv(L, t) - v).norm() / v.norm()) < 1e-8
     del K, L

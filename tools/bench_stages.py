@@ -23,7 +23,7 @@ def main():
     gw = torch.empty(D, dtype=torch.float64, device="cuda"); gs = torch.empty(1, dtype=torch.float64, device="cuda")
     gt = torch.empty(1, dtype=torch.float64, device="cuda")
     stages = {
-        "build": lambda: ctx.kernel_build(U, w, sf2, tau, None, A, uplo=1),
+        "build": lambda: ctx.kernel_build(U, w, sf2, tau, None, A, uplo=2),
         "potrf": lambda: ctx.potrf(A, Li, info),
         "trtri": lambda: ctx.trtri(A, Li, T),
         "mll_reduce": lambda: ctx.mll_reduce(A, Li, r, z, out3),
