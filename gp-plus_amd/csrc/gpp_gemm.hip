@@ -140,14 +140,15 @@ __device__ __forceinline__ void load_fast(const double* __restrict__ ubase, cons
 
 // The row-contiguous TN variant (every hot product of the evaluation) keeps 2 work-groups per CU (<= 256 VGPRs);
 // variants with a k-contiguous operand are off the hot path (prediction, tests) and take the registers they need.
-template <int VAR, int WT>
-__global__ __launch_bounds__(256, (VAR == 2 || WT < 64) ? 2 : 1) void gpp_gemm_f64(GemmArgs p) {
+template <int VAR, int WTM, int WTN>
+__global__ __launch_bounds__(256, (VAR == 2 || WTM < 64) ? 2 : 1) void gpp_gemm_f64(GemmArgs p) {
   constexpr bool A_KC = (VAR != 2);
   constexpr bool B_KC = (VAR == 0);
-  constexpr int T = 2 * WT;  // work-group tile edge
-  constexpr int LDA = ldt_mc(T), LDB = ldt_mc(T);  // strides of [k][row] chunks (MC operands)
-  constexpr int OPSZ = (BK * ldt_mc(T) > T * LDK) ? BK * ldt_mc(T) : T * LDK;  // doubles per staged operand chunk
-  constexpr int RB = WT / 4, CB = WT / 16;
+  constexpr int TM = 2 * WTM, TN = 2 * WTN;  // work-group tile: TM rows x TN columns (2 x 2 waves)
+  constexpr int LDA = ldt_mc(TM), LDB = ldt_mc(TN);  // strides of [k][row] chunks (MC operands)
+  constexpr int TX = TM > TN ? TM : TN;
+  constexpr int OPSZ = (BK * ldt_mc(TX) > TX * LDK) ? BK * ldt_mc(TX) : TX * LDK;  // doubles per staged operand chunk
+  constexpr int RB = WTM / 4, CB = WTN / 16;
   __shared__ __attribute__((aligned(16))) double smem[2 * 2 * OPSZ];
 
   int tm, tn;
@@ -174,17 +175,17 @@ __global__ __launch_bounds__(256, (VAR == 2 || WT < 64) ? 2 : 1) void gpp_gemm_f
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
-  const int wm = (wave >> 1) * WT, wn = (wave & 1) * WT;
+  const int wm = (wave >> 1) * WTM, wn = (wave & 1) * WTN;
   const int li = lane & 15, lk = lane >> 4;
-  const int row0 = tm * T, col0 = tn * T;
+  const int row0 = tm * TM, col0 = tn * TN;
 
   int klo = 0;
   if (p.klo_mode == 1) klo = row0;
   else if (p.klo_mode == 2) klo = col0;
   else if (p.klo_mode == 3) klo = row0 > col0 ? row0 : col0;
   int khi = p.K;
-  if (p.khi_mode == 1) khi = min(p.K, row0 + T);
-  else if (p.khi_mode == 2) khi = min(p.K, col0 + T);
+  if (p.khi_mode == 1) khi = min(p.K, row0 + TM);
+  else if (p.khi_mode == 2) khi = min(p.K, col0 + TN);
   const int nch = khi > klo ? (khi - klo + BK - 1) / BK : 0;
 
   double acc[RB][CB];
@@ -193,11 +194,11 @@ __global__ __launch_bounds__(256, (VAR == 2 || WT < 64) ? 2 : 1) void gpp_gemm_f
 #pragma unroll
     for (int b = 0; b < CB; ++b) acc[a][b] = 0.0;
 
-  v2d ra[T / 32], rb[T / 32];
+  v2d ra[TM / 32], rb[TN / 32];
   unsigned ka = 0, kb_ = 0;
-  unsigned offa[T / 32], offb[T / 32];
-  thread_offsets<T, A_KC>(p.lda, tid, offa);
-  thread_offsets<T, B_KC>(p.ldb, tid, offb);
+  unsigned offa[TM / 32], offb[TN / 32];
+  thread_offsets<TM, A_KC>(p.lda, tid, offa);
+  thread_offsets<TN, B_KC>(p.ldb, tid, offb);
   // uniform bases of the tile's first chunk row/column block; advanced by a scalar per chunk
   const double* __restrict__ ubaseA = A_KC ? A + (int64_t)row0 * p.lda : A + row0;
   const double* __restrict__ ubaseB = B_KC ? B + (int64_t)col0 * p.ldb : B + col0;
@@ -207,30 +208,34 @@ __global__ __launch_bounds__(256, (VAR == 2 || WT < 64) ? 2 : 1) void gpp_gemm_f
   auto stage_load = [&](int kb) {
     // (the lean path is enabled for the row-contiguous TN variant only: with a k-contiguous operand the extra live
     //  registers push hipcc over the 256-VGPR budget of 2 waves/SIMD and the spills cost more than the VALU saved)
-    fast = (VAR == 2) && chunk_is_interior<T>(row0, p.M, kb, khi, p.a_mask) &&
-           chunk_is_interior<T>(col0, p.N, kb, khi, p.b_mask);
+    fast = (VAR == 2) && chunk_is_interior<TM>(row0, p.M, kb, khi, p.a_mask) &&
+           chunk_is_interior<TN>(col0, p.N, kb, khi, p.b_mask);
     if (fast) {
-      load_fast<T>(ubaseA + (int64_t)kb * stepA, offa, ra);
-      load_fast<T>(ubaseB + (int64_t)kb * stepB, offb, rb);
+      load_fast<TM>(ubaseA + (int64_t)kb * stepA, offa, ra);
+      load_fast<TN>(ubaseB + (int64_t)kb * stepB, offb, rb);
     } else {
-      ka = A_KC ? load_kc<T>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra)
-                : load_mc<T>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra);
-      kb_ = B_KC ? load_kc<T>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb)
-                 : load_mc<T>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb);
+      ka = A_KC ? load_kc<TM>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra)
+                : load_mc<TM>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra);
+      kb_ = B_KC ? load_kc<TN>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb)
+                 : load_mc<TN>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb);
     }
   };
   auto stage_store = [&](double* da, double* db) {
     if (fast) {
-      if (A_KC) store_kc<T, false>(da, tid, ra, 0); else store_mc<T, false>(da, tid, ra, 0);
-      if (B_KC) store_kc<T, false>(db, tid, rb, 0); else store_mc<T, false>(db, tid, rb, 0);
+      if (A_KC) store_kc<TM, false>(da, tid, ra, 0); else store_mc<TM, false>(da, tid, ra, 0);
+      if (B_KC) store_kc<TN, false>(db, tid, rb, 0); else store_mc<TN, false>(db, tid, rb, 0);
     } else {
-      if (A_KC) store_kc<T, true>(da, tid, ra, ka); else store_mc<T, true>(da, tid, ra, ka);
-      if (B_KC) store_kc<T, true>(db, tid, rb, kb_); else store_mc<T, true>(db, tid, rb, kb_);
+      if (A_KC) store_kc<TM, true>(da, tid, ra, ka); else store_mc<TM, true>(da, tid, ra, ka);
+      if (B_KC) store_kc<TN, true>(db, tid, rb, kb_); else store_mc<TN, true>(db, tid, rb, kb_);
     }
   };
 
+  // chunk c covers k in [kpos(c), kpos(c)+16).  With k_reverse the chunks run from the top of the range down, so that
+  // tiles whose ranges END together (klo differs per column tile, e.g. X^T * lower-triangular) sweep the shared
+  // operand in lockstep and hit in L2 instead of each streaming its own k rows.
+  auto kpos = [&](int c) { return p.k_reverse ? klo + (nch - 1 - c) * BK : klo + c * BK; };
   if (nch > 0) {
-    stage_load(klo);
+    stage_load(kpos(0));
     stage_store(smem, smem + OPSZ);
   }
   __syncthreads();
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(256, (VAR == 2 || WT < 64) ? 2 : 1) void gpp_gemm_f
   for (int c = 0; c < nch; ++c) {
     const int cur = c & 1;
     const bool more = (c + 1 < nch);
-    if (more) stage_load(klo + (c + 1) * BK);
+    if (more) stage_load(kpos(c + 1));
     // A fragment: lane (i = l&3, k = l>>4), same address in the 4 column groups (l>>2)&3 -> LDS broadcast
     const double* sa = smem + (cur * 2 + 0) * OPSZ + (A_KC ? (wm + (lane & 3)) * LDK + lk : wm + (lane & 3) + lk * LDA);
     const double* sb = smem + (cur * 2 + 1) * OPSZ + (B_KC ? (wn + li) * LDK + lk : wn + li + lk * LDB);
@@ -304,40 +309,41 @@ __global__ __launch_bounds__(256, (VAR == 2 || WT < 64) ? 2 : 1) void gpp_gemm_f
 }
 
 template <int VAR>
-hipError_t launch_var(hipStream_t s, int wt, dim3 grid, const GemmArgs& a) {
-  switch (wt) {
-    case 64: hipLaunchKernelGGL((gpp_gemm_f64<VAR, 64>), grid, dim3(256), 0, s, a); break;
-    case 32: hipLaunchKernelGGL((gpp_gemm_f64<VAR, 32>), grid, dim3(256), 0, s, a); break;
-    case 16: hipLaunchKernelGGL((gpp_gemm_f64<VAR, 16>), grid, dim3(256), 0, s, a); break;
-    default: return hipErrorInvalidValue;
-  }
+hipError_t launch_var(hipStream_t s, int tm, int tn, dim3 grid, const GemmArgs& a) {
+  if (tm == 128 && tn == 128) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 64, 64>), grid, dim3(256), 0, s, a);
+  else if (tm == 64 && tn == 64) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 32, 32>), grid, dim3(256), 0, s, a);
+  else if (tm == 32 && tn == 32) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 16, 16>), grid, dim3(256), 0, s, a);
+  else if (tm == 128 && tn == 32) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 64, 16>), grid, dim3(256), 0, s, a);
+  else return hipErrorInvalidValue;
   return hipGetLastError();
 }
 
 }  // namespace
 
-// tile: 0 = pick by grid size, else the work-group tile edge (128 / 64 / 32).
-hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int batch, int tile) {
+// tile_m/tile_n: 0 = pick a square tile by grid size; else the work-group tile (128x128, 64x64, 32x32 or 128x32).
+hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int batch, int tile_m, int tile_n) {
   GemmArgs a = a_in;
   if (a.M <= 0 || a.N <= 0 || batch <= 0) return hipSuccess;
   auto ntiles = [&](int T) -> int64_t {
     const int64_t tm = (a.M + T - 1) / T, tn = (a.N + T - 1) / T;
     return (a.c_lower ? tm * (tm + 1) / 2 : tm * tn) * batch;  // triangular output needs M == N
   };
-  if (tile == 0) {
+  if (tile_m == 0) {
     // enough 128^2 tiles to give every CU a work-group -> big tile; otherwise shrink until the chip is covered
-    if (ntiles(128) >= 256) tile = 128;
-    else if (ntiles(64) >= 192) tile = 64;
-    else tile = 32;
+    if (ntiles(128) >= 256) tile_m = 128;
+    else if (ntiles(64) >= 192) tile_m = 64;
+    else tile_m = 32;
+    tile_n = tile_m;
   }
-  a.tiles_m = (a.M + tile - 1) / tile;
-  a.tiles_n = (a.N + tile - 1) / tile;
+  if (a.c_lower && tile_m != tile_n) return hipErrorInvalidValue;
+  a.tiles_m = (a.M + tile_m - 1) / tile_m;
+  a.tiles_n = (a.N + tile_n - 1) / tile_n;
   const int64_t nt = a.c_lower ? (int64_t)a.tiles_m * (a.tiles_m + 1) / 2 : (int64_t)a.tiles_m * a.tiles_n;
   dim3 grid((unsigned)nt, (unsigned)batch, 1);
   switch (variant) {
-    case 0: return launch_var<0>(s, tile / 2, grid, a);
-    case 1: return launch_var<1>(s, tile / 2, grid, a);
-    case 2: return launch_var<2>(s, tile / 2, grid, a);
+    case 0: return launch_var<0>(s, tile_m, tile_n, grid, a);
+    case 1: return launch_var<1>(s, tile_m, tile_n, grid, a);
+    case 2: return launch_var<2>(s, tile_m, tile_n, grid, a);
     default: return hipErrorInvalidValue;
   }
 }

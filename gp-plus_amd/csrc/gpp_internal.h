@@ -28,10 +28,11 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   double* C2;              // optional mirrored output: C2[n][m] = C[m][n]
   int64_t ldc2, sC2;
+  int k_reverse;           // walk the k range from its top down (see gpp_gemm.hip)
 };
 // variant: 0 = NT (A[m][k], B[n][k]), 1 = NN (A[m][k], B[k][n]), 2 = TN (A[k][m], B[k][n])
-// tile: 0 = choose from the grid size, or force the work-group tile edge 128 / 64 / 32
-hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a, int batch, int tile = 0);
+// tile_m = 0: choose a square tile from the grid size; else force the work-group tile (128x128, 64x64, 32x32, 128x32)
+hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a, int batch, int tile_m = 0, int tile_n = 0);
 
 // ---- 128x128 diagonal leaf: Cholesky + triangular inverse in LDS (gpp_leaf.hip) ---------------
 // A holds the UPPER factor (A = U^T U, i.e. L = U^T read/written with swapped indices); the n x n diagonal block of
