@@ -255,8 +255,8 @@ int gpp_lauum(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double
   if (int r = check_mat(Linv, ldi, N, 2)) return r;
   if (int r = check_mat(Kinv, ldk, N, 5)) return r;
   GemmArgs g = mk(Linv, ldi, Linv, ldi, Kinv, ldk, N, N, N, 1.0, 0.0);
-  g.a_mask = 2; g.b_mask = 2; g.klo_mode = 3; g.c_lower = 1;
-  GPP_TRY(gpp_launch_gemm(h->stream, 2, g, 1));
+  g.a_mask = 2; g.b_mask = 2; g.klo_mode = 3; g.c_lower = 1; g.tag = 1;
+  GPP_TRY(gpp_launch_gemm(h->stream, 2, g, 1, NBLK, NBLK));
   return 0;
 }
 

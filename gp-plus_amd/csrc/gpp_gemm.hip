@@ -140,7 +140,9 @@ __device__ __forceinline__ void load_fast(const double* __restrict__ ubase, cons
 
 // The row-contiguous TN variant (every hot product of the evaluation) keeps 2 work-groups per CU (<= 256 VGPRs);
 // variants with a k-contiguous operand are off the hot path (prediction, tests) and take the registers they need.
-template <int VAR, int WTM, int WTN>
+// TAG only changes the kernel's NAME: the single N^3/3-flop LAUUM launch runs as <2,64,64,1> so that profilers report
+// it on its own line (the roofline entry of bench.py), apart from the ~1300 launches of the recursions.
+template <int VAR, int WTM, int WTN, int TAG = 0>
 __global__ __launch_bounds__(256, (VAR == 2 || WTM < 64) ? 2 : 1) void gpp_gemm_f64(GemmArgs p) {
   constexpr bool A_KC = (VAR != 2);
   constexpr bool B_KC = (VAR == 0);
@@ -310,7 +312,9 @@ __global__ __launch_bounds__(256, (VAR == 2 || WTM < 64) ? 2 : 1) void gpp_gemm_
 
 template <int VAR>
 hipError_t launch_var(hipStream_t s, int tm, int tn, dim3 grid, const GemmArgs& a) {
-  if (tm == 128 && tn == 128) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 64, 64>), grid, dim3(256), 0, s, a);
+  if (tm == 128 && tn == 128 && a.tag == 1 && VAR == 2)
+    hipLaunchKernelGGL((gpp_gemm_f64<2, 64, 64, 1>), grid, dim3(256), 0, s, a);
+  else if (tm == 128 && tn == 128) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 64, 64>), grid, dim3(256), 0, s, a);
   else if (tm == 64 && tn == 64) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 32, 32>), grid, dim3(256), 0, s, a);
   else if (tm == 32 && tn == 32) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 16, 16>), grid, dim3(256), 0, s, a);
   else if (tm == 128 && tn == 32) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 64, 16>), grid, dim3(256), 0, s, a);

@@ -51,6 +51,24 @@ class GP_Plus(GPR):
                  m_gp='single_constant', m_gp_ref='zero', NN_layers_m_gp=[], calibration_type='deterministic',
                  calibration_id=[], mean_prior_cal=None, std_prior_cal=None, interval_score=False, num_pass_train=1,
                  num_pass_pred=1, seed_number=1) -> None:
+        # parameters and buffers are created directly in ``dtype`` (the reference creates fp32 parameters and casts
+        # in fit(), gp_plus.py:562 / SURVEY.md B-4); with dtype=float64 initial values such as lengthscale=1 are exact
+        _prev_default = torch.get_default_dtype()
+        torch.set_default_dtype(dtype)
+        try:
+            self._construct(train_x, train_y, dtype, device, qual_dict, multiple_noise, lb_noise, fix_noise, fix_noise_val,
+                            quant_correlation_class, fixed_length_scale, fixed_length_scale_val, encoding_type,
+                            embedding_dim, separate_embedding, embedding_type, NN_layers_embedding, m_gp, m_gp_ref,
+                            NN_layers_m_gp, calibration_type, calibration_id, mean_prior_cal, std_prior_cal, interval_score,
+                            num_pass_train, num_pass_pred, seed_number)
+        finally:
+            torch.set_default_dtype(_prev_default)
+
+    def _construct(self, train_x, train_y, dtype, device, qual_dict, multiple_noise, lb_noise, fix_noise, fix_noise_val,
+                   quant_correlation_class, fixed_length_scale, fixed_length_scale_val, encoding_type, embedding_dim,
+                   separate_embedding, embedding_type, NN_layers_embedding, m_gp, m_gp_ref, NN_layers_m_gp,
+                   calibration_type, calibration_id, mean_prior_cal, std_prior_cal, interval_score, num_pass_train,
+                   num_pass_pred, seed_number) -> None:
         self.mean_prior_cal = [0 for _ in calibration_id] if mean_prior_cal is None else mean_prior_cal
         self.std_prior_cal = [1 for _ in calibration_id] if std_prior_cal is None else std_prior_cal
         self.interval_score = interval_score

@@ -1,1 +1,2 @@
 from .mll_torch import fit_model_torch  # noqa: F401
+from .mll_parallel import fit_restarts_parallel, split_restarts  # noqa: F401

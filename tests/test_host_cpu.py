@@ -1,0 +1,188 @@
+"""CPU tests of the host side: C-ABI export list, the gpytorch-protocol mirror (names, transforms, priors, state_dict
+keys), the data-prep helpers against the reference-generated fixtures, and the fail-loudly rule.  No compute call is
+made into the HIP library here."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gpplus_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "gpp.h")).read()
+    declared = set(re.findall(r"\b(gpp_[a-z_0-9]+)\s*\(", header))
+    declared -= {"gpp_handle_s"}
+    lib = _lib.load()
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert b"gfx950" in lib.gpp_version()
+
+
+def test_data_pipeline_reproduces_reference_fixtures():
+    """Our borehole / split / standard must give exactly what the reference's own functions gave (fixture inputs)."""
+    from gpplus_amd.preprocessing import train_test_split_normalizeX
+    from gpplus_amd.test_functions.analytical import borehole, borehole_mixed_variables
+    from gpplus_amd.utils import set_seed
+
+    fx = load("c1_borehole_n500.npz")
+    set_seed(1245)
+    X, y = borehole(n=10000, random_state=12345)
+    Xtr, Xte, ytr, yte = train_test_split_normalizeX(X, y, test_size=0.95)
+    np.testing.assert_array_equal(Xtr.numpy(), fx["Xtrain"])
+    np.testing.assert_array_equal(ytr.numpy(), fx["ytrain"])
+    np.testing.assert_array_equal(Xte.numpy()[:200], fx["Xtest"])
+    assert len(np.unique(fx["Xtrain"], axis=0)) == 490  # duplicate rows of the with-replacement shuffle (B-1)
+
+    fx = load("c3_borehole_mixed_n100.npz")
+    set_seed(4)
+    qd = {0: 5, 5: 5}
+    U, y = borehole_mixed_variables(n=10000, qual_dict=qd, random_state=4)
+    Utr, Ute, ytr, yte = train_test_split_normalizeX(U, y, test_size=0.99, qual_dict=qd)
+    np.testing.assert_array_equal(Utr.numpy(), fx["Utrain"])
+    np.testing.assert_array_equal(ytr.numpy(), fx["ytrain"])
+
+
+def test_setlevels_and_standard():
+    from gpplus_amd.preprocessing import setlevels, standard
+
+    X = torch.tensor([[3.5, 10.0], [1.5, 20.0], [3.5, 30.0], [2.0, 10.0]])
+    out, labels = setlevels(X, qual_index=[0], return_label=True)
+    np.testing.assert_array_equal(out[:, 0].numpy(), [2, 0, 2, 1])
+    assert labels == [[1.5, 2.0, 3.5]]
+    Xs, mean, std = standard(X.clone().double(), {0: 3})
+    np.testing.assert_allclose(Xs[:, 1].numpy(), (X[:, 1].numpy() - 17.5) / np.std([10, 20, 30, 10]), rtol=1e-12)
+
+
+def _mixed_model(**kw):
+    from gpplus_amd.models import GP_Plus
+
+    fx = load("c3_borehole_mixed_n100.npz")
+    return fx, GP_Plus(torch.tensor(fx["Utrain"]), torch.tensor(fx["ytrain"]), qual_dict={0: 5, 5: 5}, dtype=torch.float64, **kw)
+
+
+def test_gp_plus_structure_matches_reference_names():
+    fx, m = _mixed_model()
+    sd = m.state_dict()
+    for k in ("likelihood.noise_covar.raw_noise", "covar_module.raw_outputscale",
+              "covar_module.base_kernel.kernels.0.raw_lengthscale", "covar_module.base_kernel.kernels.1.raw_lengthscale",
+              "mean_module.constant", "latent[0, 5]", "y_min", "y_std", "y_scaled", "quant_index", "qual_dict_list"):
+        assert k in sd, k
+    assert sd["covar_module.base_kernel.kernels.1.raw_lengthscale"].shape == (1, 6)
+    assert sd["latent[0, 5]"].shape == (2, 10)
+    assert not m.covar_module.base_kernel.kernels[0].raw_lengthscale.requires_grad
+    names = [n for n, *_ in m.named_priors()]
+    assert names == ["latent_prior_latent[0, 5]", "likelihood.noise_prior", "covar_module.outputscale_prior",
+                     "covar_module.base_kernel.kernels.1.lengthscale_prior", "mean_module.mean_prior"]
+    # y scaling (gpregression.py:67-69)
+    y = torch.tensor(fx["ytrain"])
+    np.testing.assert_allclose(m.train_targets.numpy(), ((y - y.min()) / (y.max() - y.min())).numpy(), rtol=1e-14)
+
+
+def test_weights_transforms_and_lazy_forward():
+    fx, m = _mixed_model()
+    with torch.no_grad():
+        m.covar_module.base_kernel.kernels[1].raw_lengthscale.copy_(torch.tensor([[-1.0, 0.0, 0.5, 1.0, -2.0, 0.25]]))
+        m.covar_module.raw_outputscale.fill_(0.3)
+        m.likelihood.noise_covar.raw_noise.fill_(-6.0)
+    out = m(*m.train_inputs)
+    cov = out.lazy_covariance_matrix
+    omega = np.array([-1.0, 0.0, 0.5, 1.0, -2.0, 0.25])
+    np.testing.assert_allclose(cov.spec.w.detach().numpy(), np.concatenate([[0.5, 0.5], 10.0 ** omega]), rtol=1e-13)
+    np.testing.assert_allclose(cov.spec.sf2.item(), np.log1p(np.exp(0.3)), rtol=1e-14)
+    assert cov.shape == (100, 100) and cov.n_grad_dims == 2
+    noisy = m.likelihood(out).lazy_covariance_matrix
+    np.testing.assert_allclose(noisy.tau.detach().numpy(), [np.exp(-6.0) + 1e-8], rtol=1e-14)
+    np.testing.assert_allclose(noisy.diag().detach().numpy(), np.log1p(np.exp(0.3)) + np.exp(-6.0) + 1e-8, rtol=1e-13)
+    # manifold features: z = zeta[index] @ A^T with the reference's str(list) dictionary order
+    A = m.state_dict()["latent[0, 5]"]
+    Utr = torch.tensor(fx["Utrain"])
+    idx = [m.perm_dict[0][str(r.tolist())] for r in Utr[:, [0, 5]].to(torch.int64)]
+    z = m.zeta[0][idx].double() @ A.T
+    np.testing.assert_allclose(cov.U1[:, :2].detach().numpy(), z.numpy(), rtol=1e-13)
+    np.testing.assert_array_equal(cov.U1[:, 2:].detach().numpy(), fx["Utrain"][:, [1, 2, 3, 4, 6, 7]])
+
+
+def test_multifidelity_noise_and_means():
+    from gpplus_amd.models import GP_Plus
+
+    fx = load("c4_wing_mf_n300.npz")
+    m = GP_Plus(torch.tensor(fx["Xtrain"]), torch.tensor(fx["ytrain"]), qual_dict={10: 3}, multiple_noise=True,
+                m_gp="multiple_constant", dtype=torch.float64)
+    with torch.no_grad():
+        m.likelihood.noise_covar.raw_noise.copy_(torch.log(torch.tensor([1e-4, 4e-4, 9e-4], dtype=torch.float64)))
+        m.mean_module_1.constant.fill_(0.1)
+        m.mean_module_2.constant.fill_(-0.2)
+    out = m(*m.train_inputs)
+    src = fx["Xtrain"][:, -1].astype(int)
+    np.testing.assert_allclose(out.mean.detach().numpy(), np.array([0.0, 0.1, -0.2])[src], rtol=1e-14)
+    noisy = m.likelihood(out).lazy_covariance_matrix
+    np.testing.assert_allclose(noisy.noise_vector().detach().numpy(), (np.array([1e-4, 4e-4, 9e-4]) + 1e-8)[src], rtol=1e-10)
+    assert isinstance(m.mean_module_0, type(m.mean_module_0)) and not list(m.mean_module_0.parameters())  # ZeroMean
+    assert m.likelihood.raw_noise.shape == (3,)
+
+
+def test_reset_parameters_and_fixed_noise():
+    from gpplus_amd.models import GP_Plus
+
+    fx = load("c1_borehole_n500.npz")
+    m = GP_Plus(torch.tensor(fx["Xtrain"]), torch.tensor(fx["ytrain"]), dtype=torch.float64, fix_noise=True)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    torch.manual_seed(0)
+    m.reset_parameters()
+    after = m.state_dict()
+    assert torch.equal(before["likelihood.noise_covar.raw_noise"], after["likelihood.noise_covar.raw_noise"])  # fixed
+    for k in ("covar_module.raw_outputscale", "covar_module.base_kernel.raw_lengthscale", "mean_module.constant"):
+        assert not torch.equal(before[k], after[k]), k
+    assert torch.isfinite(after["covar_module.raw_outputscale"]).all()
+
+
+def test_argument_validation_and_scope():
+    from gpplus_amd.models import GP_Plus, GPR
+
+    X, y = torch.randn(20, 3, dtype=torch.float64), torch.randn(20, dtype=torch.float64)
+    with pytest.raises(ValueError):
+        GP_Plus(X, y, qual_dict=[0])
+    with pytest.raises(ValueError):
+        GP_Plus(X, y, quant_correlation_class="Cubic")
+    with pytest.raises(NotImplementedError):
+        GP_Plus(X, y, embedding_type="probabilistic", qual_dict={})
+    with pytest.raises(RuntimeError):
+        GPR(X.numpy(), y, "Rough_RBF", [])
+    with pytest.raises(RuntimeError):
+        GPR(X, y[:5], "Rough_RBF", [])
+    g = GPR(X, y, "Rough_RBF", [])
+    assert g.covar_module.base_kernel.raw_lengthscale.shape == (1, 3)
+    np.testing.assert_allclose(g.covar_module.base_kernel.feature_weights(3).detach().numpy(), np.ones(3), rtol=1e-14)  # w = exp(raw)
+
+
+def test_no_cpu_fallback():
+    from gpplus_amd._lib import GppError
+    from gpplus_amd.gpcore import ExactMarginalLogLikelihood
+
+    fx, m = _mixed_model()
+    with pytest.raises(GppError, match="no CPU fallback"):
+        ExactMarginalLogLikelihood(m.likelihood, m)(m(*m.train_inputs), m.train_targets)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        m.fit()
+    with pytest.raises(GppError):
+        m(*m.train_inputs).lazy_covariance_matrix.evaluate()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "gp-plus_amd")
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b|gp_oracle|importlib.*oracle", src, re.M), os.path.join(d, f)
