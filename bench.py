@@ -57,13 +57,17 @@ def set_theta1(model):
 def cpu_baseline(budget_s=30.0):
     """Oracle loss+grad (= optim/mll_torch.py:114-117 on the CPU oracle) on this box's host cores.  Bounded sample: one
     untimed warm-up, then N = 2048, 4096, 8192 while the N^3 projection of the next size fits the budget; the largest
-    timed size is scaled to N = 20000 by N^3 (the evaluation is dominated by the O(N^3) Cholesky backward)."""
+    timed size is scaled to N = 20000 by N^3 (the evaluation is dominated by the O(N^3) Cholesky backward).  Thread
+    count: PyTorch CPU ops oversubscribe badly at these sizes with every hardware thread (256 threads are 10x slower
+    than 32 on a 2 x 64-core host), so the ladder runs with min(32, cores) threads and the last size is re-timed with
+    4x as many when the budget allows; the faster of the two is reported together with its thread count."""
     from oracle.gp_oracle import OracleGP
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    ncpu = os.cpu_count() or 1
     X, y = make_c2_data(8192)
 
-    def one(n):
+    def one(n, threads):
+        torch.set_num_threads(threads)
         o = OracleGP(X[:n], y[:n])
         o.params[o.ls_key].fill_(THETA1["omega"])
         o.params["covar_module.raw_outputscale"].fill_(THETA1["raw_os"])
@@ -73,19 +77,27 @@ def cpu_baseline(budget_s=30.0):
         o.loss_and_grad()
         return time.perf_counter() - t0
 
-    one(512)  # warm-up: thread pool, allocator
+    th = min(32, ncpu)
+    one(512, th)  # warm-up: thread pool, allocator
     used, sizes = 0.0, []
     for n in (2048, 4096, 8192):
         if sizes and used + sizes[-1][1] * 8.0 > budget_s:
             break
-        t = one(n)
+        t = one(n, th)
         used += t
         sizes.append((n, t))
     n_s, t_s = sizes[-1]
+    best_th = th
+    th2 = min(4 * th, ncpu)
+    if th2 > th and used + 2.0 * t_s < budget_s:
+        t2 = one(n_s, th2)
+        if t2 < t_s:
+            t_s, best_th = t2, th2
     est = t_s * (N_C2 / n_s) ** 3
-    return {"value": 1.0 / est, "unit": "evals/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle loss+grad timed at N={n_s} ({t_s:.2f} s, same C2 generator, 1 warm-up) and scaled by "
-                      f"(20000/{n_s})^3 = {est:.0f} s/eval; ladder {[(a, round(b, 2)) for a, b in sizes]}"}
+    return {"value": 1.0 / est, "unit": "evals/s", "cores": best_th, "kind": "port",
+            "sample": f"oracle loss+grad timed at N={n_s} ({t_s:.2f} s with {best_th} threads of {ncpu}, same C2 "
+                      f"generator, 1 warm-up) and scaled by (20000/{n_s})^3 = {est:.0f} s/eval; "
+                      f"ladder at {th} threads {[(a, round(b, 2)) for a, b in sizes]}"}
 
 
 def main():
@@ -95,6 +107,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--n", type=int, default=N_C2, help="problem size (default: the C2 config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent replicas evaluated concurrently on this GPU (one host thread + HIP stream + "
+                         "workspace slot each), the per-GPU form of restart parallelism")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -116,13 +131,17 @@ def main():
     from gpplus_amd.models import GP_Plus
 
     X, y = make_c2_data(args.n)
-    model = GP_Plus(X, y, dtype=torch.float64, device=dev)
-    set_theta1(model)
-    model.train()
-    mll = ExactMarginalLogLikelihood(model.likelihood, model)
-    params = [p for p in model.parameters() if p.requires_grad]
+    S = max(1, args.streams)
+    replicas = []
+    for k in range(S):
+        model = GP_Plus(X, y, dtype=torch.float64, device=dev)
+        set_theta1(model)
+        model.train()
+        replicas.append((model, ExactMarginalLogLikelihood(model.likelihood, model),
+                         [p for p in model.parameters() if p.requires_grad]))
 
-    def step():
+    def step(k=0):
+        model, mll, params = replicas[k]
         for p in params:
             p.grad = None
         output = model(*model.train_inputs)
@@ -130,22 +149,47 @@ def main():
         loss.backward()
         return loss
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(nsteps):
+        """``nsteps`` evaluations in total; with S > 1 they are dealt to S threads, each on its own stream and slot."""
+        if S == 1:
+            out = None
+            for _ in range(nsteps):
+                out = step()
+            return out
+        import threading
+
+        results = [None] * S
+        counts = [nsteps // S + (1 if k < nsteps % S else 0) for k in range(S)]
+
+        def worker(k):
+            torch.cuda.set_device(local_rank)
+            with torch.cuda.stream(streams[k]), linalg.eval_slot(k):
+                for _ in range(counts[k]):
+                    results[k] = step(k)
+                streams[k].synchronize()
+
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(S)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        return next(r for r in results if r is not None)
+
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
+    run_steps(max(args.warmup, S if S > 1 else 0))
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    linalg.STAGE_EVENTS = []
+    linalg.STAGE_EVENTS = []  # list.append is atomic: the replica threads share it
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    loss = run_steps(args.steps)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    events, linalg.STAGE_EVENTS = linalg.STAGE_EVENTS, None
+    events, linalg.STAGE_EVENTS = (linalg.STAGE_EVENTS or []), None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -168,7 +212,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C2: synthetic Borehole (Sobol seed 0, unique rows, z-scored) N={N} d={D_C2} fp64, "
                                    "GP_Plus Rough_RBF exact GP at theta1, one replica per GPU (restart-parallel)",
-                       "N": N, "d": D_C2, "loss": float(loss.item())},
+                       "N": N, "d": D_C2, "loss": float(loss.item()), "streams_per_gpu": S},
             "roofline": {"bound": "mfma", "kernel": "gpp_gemm_f64<2, 64, 64, 1> (LAUUM: Kinv = Linv^T Linv, the one lower-triangular TN launch)",
                          "achieved": lauum_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": lauum_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,

@@ -8,7 +8,8 @@ Reference boundary this replaces: the gpytorch/ATen operators reached from ``opt
 from __future__ import annotations
 
 import ctypes
-from typing import Dict, Optional
+import threading
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -19,7 +20,10 @@ KIND_RBF, KIND_MATERN32, KIND_MATERN52 = 0, 1, 2
 UPLO_FULL, UPLO_LOWER, UPLO_UPPER = 0, 1, 2
 OP_MLL_EVAL, OP_PREDICT = 0, 1
 
-_contexts: Dict[int, "GppContext"] = {}
+#: one context (library handle + stream binding + scratch) per (device, host thread): concurrent evaluations driven
+#: from different threads on different HIP streams never share a handle
+_contexts: Dict[Tuple[int, int], "GppContext"] = {}
+_contexts_lock = threading.Lock()
 
 
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
@@ -157,8 +161,10 @@ def get_context(device) -> GppContext:
         raise GppError(
             f"the exact-GP hot path runs only on an MI355X through libgpp_hip (device={device}); no CPU fallback exists")
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    ctx = _contexts.get(idx)
+    key = (idx, threading.get_ident())
+    ctx = _contexts.get(key)
     if ctx is None:
-        ctx = GppContext(torch.device("cuda", idx))
-        _contexts[idx] = ctx
+        with _contexts_lock:
+            ctx = GppContext(torch.device("cuda", idx))
+            _contexts[key] = ctx
     return ctx

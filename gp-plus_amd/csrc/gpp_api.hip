@@ -234,7 +234,7 @@ int gpp_trtri(gpp_handle_t h, const double* U, int64_t N, int64_t ld, double* Li
       const int64_t pstride_U = 2 * s * (ld + 1), pstride_I = 2 * s * (ldi + 1), pstride_T = 2 * s * (ldt + 1);
       // T21 = U12^T * Linv11   (TN; U12 = U[o.., o+s..] is s x m2, Linv11 lower: keep k >= n)
       GemmArgs g1 = mk(U + o * ld + (o + s), ld, Linv + o * ldi + o, ldi, T + (o + s) * ldt + o, ldt, m2, s, s, 1.0, 0.0);
-      g1.b_mask = 2; g1.klo_mode = 2; g1.k_reverse = 1;
+      g1.b_mask = 2; g1.klo_mode = 2; g1.col_major = 1;  // K range depends on the column tile: keep columns together
       g1.sA = pstride_U; g1.sB = pstride_I; g1.sC = pstride_T;
       GPP_TRY(gpp_launch_gemm(h->stream, 2, g1, batch));
       // Linv21 = -W22^T * T21  (TN; W22 = mirrored upper part of the (o+s) block: keep k <= m), plus its mirror

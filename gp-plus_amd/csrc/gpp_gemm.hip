@@ -154,7 +154,19 @@ __global__ __launch_bounds__(256, (VAR == 2 || WTM < 64) ? 2 : 1) void gpp_gemm_
   __shared__ __attribute__((aligned(16))) double smem[2 * 2 * OPSZ];
 
   int tm, tn;
-  {
+  if (p.swz) {
+    // XCD-aware mapping (blocks are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2): the 64 work-groups
+    // an XCD runs concurrently (32 CUs x 2) form ONE 8 x 8 super-tile of output tiles, so every staged A chunk is
+    // shared by 8 and every B chunk by 8 work-groups of that L2.  Tiles outside the matrix / triangle exit at once.
+    const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
+    const int S = (i >> 6) * 8 + xcd, w = i & 63;
+    const int super_n = (p.tiles_n + 7) >> 3;
+    const int sm = S / super_n, sn = S - sm * super_n;
+    tm = sm * 8 + (w >> 3);
+    tn = sn * 8 + (w & 7);
+    if (tm >= p.tiles_m || tn >= p.tiles_n) return;
+    if ((p.c_lower == 1 && tn > tm) || (p.c_lower == 2 && tn < tm)) return;
+  } else {
     const int t = blockIdx.x;
     if (p.c_lower) {
       tm = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
@@ -166,6 +178,11 @@ __global__ __launch_bounds__(256, (VAR == 2 || WTM < 64) ? 2 : 1) void gpp_gemm_
         tm = tn;
         tn = q;
       }
+    } else if (p.col_major) {
+      // column-major tile order: consecutive work-groups share the column tile (hence the K range when it depends on
+      // the column, and the B chunks) and run in lockstep
+      tn = t / p.tiles_m;
+      tm = t - tn * p.tiles_m;
     } else {
       tm = t / p.tiles_n;
       tn = t - tm * p.tiles_n;
@@ -342,7 +359,16 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int
   if (a.c_lower && tile_m != tile_n) return hipErrorInvalidValue;
   a.tiles_m = (a.M + tile_m - 1) / tile_m;
   a.tiles_n = (a.N + tile_n - 1) / tile_n;
-  const int64_t nt = a.c_lower ? (int64_t)a.tiles_m * (a.tiles_m + 1) / 2 : (int64_t)a.tiles_m * a.tiles_n;
+  int64_t nt = a.c_lower ? (int64_t)a.tiles_m * (a.tiles_m + 1) / 2 : (int64_t)a.tiles_m * a.tiles_n;
+  a.swz = 0;
+  // Measured on MI355X (N = 20000): the super-tile mapping LOSES 10-20 % against plain row-major order (row-major
+  // already shares each A chunk among 16 and each B chunk among 4 work-groups of an XCD, and the triangular launches
+  // waste whole super-tiles), so it stays off; kept for experiments with GPP_SWZ-style builds.
+  if (false && nt >= 1024) {
+    const int64_t n_super = (int64_t)((a.tiles_m + 7) / 8) * ((a.tiles_n + 7) / 8);
+    nt = ((n_super + 7) / 8) * 8 * 64;
+    a.swz = 1;
+  }
   dim3 grid((unsigned)nt, (unsigned)batch, 1);
   switch (variant) {
     case 0: return launch_var<0>(s, tile_m, tile_n, grid, a);

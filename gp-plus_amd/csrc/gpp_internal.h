@@ -30,6 +30,8 @@ struct GemmArgs {
   int64_t ldc2, sC2;
   int k_reverse;           // walk the k range from its top down (see gpp_gemm.hip)
   int tag;                 // 1: launch the separately named instantiation (profiling label, same code)
+  int col_major;           // enumerate tiles column by column (non-triangular outputs)
+  int swz;                 // set by the launcher: XCD-aware 8x8 super-tile mapping of blockIdx -> tile
 };
 // variant: 0 = NT (A[m][k], B[n][k]), 1 = NN (A[m][k], B[k][n]), 2 = TN (A[k][m], B[k][n])
 // tile_m = 0: choose a square tile from the grid size; else force the work-group tile (128x128, 64x64, 32x32, 128x32)

@@ -11,7 +11,9 @@ Jitter policy restates gpytorch.utils.cholesky.psd_safe_cholesky [3P]: 1e-8 * 10
 """
 from __future__ import annotations
 
+import threading
 import warnings
+from contextlib import contextmanager
 from dataclasses import dataclass
 from typing import Dict, Optional, Tuple
 
@@ -53,6 +55,25 @@ class EvalWorkspace:
 
 
 _workspaces: Dict[Tuple[int, int, int], EvalWorkspace] = {}
+_workspaces_lock = threading.Lock()
+_tls = threading.local()
+
+
+@contextmanager
+def eval_slot(slot: int):
+    """Evaluations issued inside this block (by this host thread) use workspace ``slot``.  Independent evaluations
+    that run concurrently — e.g. two restarts of a fit driven from two threads on two HIP streams — take distinct
+    slots so their N x N buffers do not alias (each slot holds 3 x 8 N^2 bytes)."""
+    old = getattr(_tls, "slot", 0)
+    _tls.slot = slot
+    try:
+        yield
+    finally:
+        _tls.slot = old
+
+
+def current_slot() -> int:
+    return getattr(_tls, "slot", 0)
 
 #: optional stage timing (bench.py): when this is a list, every stage appends (name, start_event, end_event) recorded
 #: on the stream the kernels are launched on (PyTorch's current stream).
@@ -81,11 +102,12 @@ def get_workspace(ctx: GppContext, N: int, slot: int = 0) -> EvalWorkspace:
     key = (ctx.index, N, slot)
     ws = _workspaces.get(key)
     if ws is None:
-        # keep at most one size per (device, slot): drop others so 3 x 8 N^2 bytes are not held per historical N
-        for k in [k for k in _workspaces if k[0] == ctx.index and k[2] == slot]:
-            del _workspaces[k]
-        ws = EvalWorkspace(ctx, N)
-        _workspaces[key] = ws
+        with _workspaces_lock:
+            # keep at most one size per (device, slot): drop others so 3 x 8 N^2 bytes are not held per historical N
+            for k in [k for k in _workspaces if k[0] == ctx.index and k[2] == slot]:
+                del _workspaces[k]
+            ws = EvalWorkspace(ctx, N)
+            _workspaces[key] = ws
     return ws
 
 
@@ -182,8 +204,10 @@ class ExactMLLFunction(torch.autograd.Function):
 
 
 def exact_mll(U: torch.Tensor, spec: KernelSpec, tau: torch.Tensor, mean: torch.Tensor, y: torch.Tensor,
-              grp: Optional[torch.Tensor] = None, n_grad_dims: Optional[int] = None, slot: int = 0) -> torch.Tensor:
+              grp: Optional[torch.Tensor] = None, n_grad_dims: Optional[int] = None, slot: Optional[int] = None) -> torch.Tensor:
     """log N(y | mean, Ky) on the GPU; differentiable w.r.t. U[:, :n_grad_dims], spec.w, spec.sf2, tau, mean, y."""
+    if slot is None:
+        slot = current_slot()
     if n_grad_dims is None:
         n_grad_dims = U.shape[1] if U.requires_grad else 0
     return ExactMLLFunction.apply(U, spec.w, spec.sf2, tau, mean, y, grp, spec.kind, spec.d_split, int(n_grad_dims), slot)
