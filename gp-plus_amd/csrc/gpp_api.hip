@@ -25,6 +25,7 @@
 namespace {
 
 constexpr int NBLK = GPP_TILE;
+constexpr int64_t LOOKAHEAD_NB = 1024;  // block-row height of the two-stream outer level (N >= 4 NB)
 
 inline int rc(hipError_t e) { return e == hipSuccess ? 0 : 1000 + (int)e; }
 #define GPP_TRY(expr)                   \
@@ -100,6 +101,79 @@ hipError_t potrf_rec(const Ctx& c, int64_t o, int64_t n) {
   return potrf_rec(c, o + n1, n2);
 }
 
+// ---- look-ahead (right-looking) driver on two streams ----------------------------------------------------------
+// The recursive factorisation spends ~40 % of its time in latency-bound launches (128-block leaves, leaf trsm, small
+// updates) during which most of the 256 CUs idle.  For large N the outer level is therefore right-looking over block
+// rows of NB with ONE step of look-ahead: the diagonal block + block-row panel of step k+1 are factored on a second,
+// high-priority stream while the main stream still runs the bulk of step k's trailing update.
+//   panel stream : wait S(k-1); U_kk = potrf(A_kk) (recursive); U_k,k+1: = U_kk^-T A_k,k+1: ; record P(k)
+//   main  stream : wait P(k);  strip (next block row) -= ...; record S(k);  rest of the trailing matrix -= ...
+hipError_t ensure_streams(gpp_handle_s* h) {
+  if (!h->panel_stream) {
+    int lo = 0, hi = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
+    if (e != hipSuccess) return e;
+    e = hipStreamCreateWithPriority(&h->panel_stream, hipStreamNonBlocking, hi);
+    if (e != hipSuccess) return e;
+  }
+  while (h->n_events < 16) {
+    hipError_t e = hipEventCreateWithFlags(&h->events[h->n_events], hipEventDisableTiming);
+    if (e != hipSuccess) return e;
+    ++h->n_events;
+  }
+  return hipSuccess;
+}
+inline hipEvent_t next_event(gpp_handle_s* h) {
+  hipEvent_t ev = h->events[h->ev_next];
+  h->ev_next = (h->ev_next + 1) % 16;
+  return ev;
+}
+#define HIP_TRY(expr)                \
+  do {                               \
+    hipError_t _e = (expr);          \
+    if (_e != hipSuccess) return _e; \
+  } while (0)
+
+hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB) {
+  HIP_TRY(ensure_streams(h));
+  Ctx cp = cm;
+  cp.s = h->panel_stream;
+  hipEvent_t ev = next_event(h);
+  HIP_TRY(hipEventRecord(ev, cm.s));            // inputs (kernel build) are ready
+  HIP_TRY(hipStreamWaitEvent(cp.s, ev, 0));
+  for (int64_t o = 0; o < N; o += NB) {
+    const int64_t nb = std::min(NB, N - o), rem = N - o - nb;
+    HIP_TRY(potrf_rec(cp, o, nb));
+    if (rem > 0) HIP_TRY(trsm_rec(cp, o + nb, rem, o, nb));
+    hipEvent_t P = next_event(h);
+    HIP_TRY(hipEventRecord(P, cp.s));
+    HIP_TRY(hipStreamWaitEvent(cm.s, P, 0));
+    if (rem == 0) break;
+    const int64_t nb2 = std::min(NB, rem), rest = rem - nb2;
+    const double* Urow = cm.A + o * cm.ld;       // block row o: U[o.., :]
+    // strip = next block row of the trailing matrix (its diagonal block, upper, then the part to its right)
+    GemmArgs g = mk(Urow + (o + nb), cm.ld, Urow + (o + nb), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb), cm.ld, nb2, nb2, nb,
+                    -1.0, 1.0);
+    g.c_lower = 2;
+    HIP_TRY(gpp_launch_gemm(cm.s, 2, g, 1));
+    if (rest > 0) {
+      GemmArgs g2 = mk(Urow + (o + nb), cm.ld, Urow + (o + nb + nb2), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb + nb2), cm.ld,
+                       nb2, rest, nb, -1.0, 1.0);
+      HIP_TRY(gpp_launch_gemm(cm.s, 2, g2, 1));
+    }
+    hipEvent_t S = next_event(h);
+    HIP_TRY(hipEventRecord(S, cm.s));
+    HIP_TRY(hipStreamWaitEvent(cp.s, S, 0));     // the next panel may start
+    if (rest > 0) {
+      GemmArgs g3 = mk(Urow + (o + nb + nb2), cm.ld, Urow + (o + nb + nb2), cm.ld,
+                       cm.A + (o + nb + nb2) * cm.ld + (o + nb + nb2), cm.ld, rest, rest, nb, -1.0, 1.0);
+      g3.c_lower = 2;
+      HIP_TRY(gpp_launch_gemm(cm.s, 2, g3, 1));
+    }
+  }
+  return hipSuccess;
+}
+
 int check_mat(const void* p, int64_t ld, int64_t n, int argi) {
   if (!p) return -argi;
   if (!aligned16(p) || (ld & 1) || ld < n) return -(argi + 1);
@@ -126,12 +200,17 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->stream = nullptr;
   h->ws = nullptr;
   h->ws_bytes = 0;
+  h->panel_stream = nullptr;
+  h->n_events = 0;
+  h->ev_next = 0;
   *out = h;
   return 0;
 }
 
 int gpp_destroy(gpp_handle_t h) {
   if (!h) return -1;
+  if (h->panel_stream) (void)hipStreamDestroy(h->panel_stream);
+  for (int i = 0; i < h->n_events; ++i) (void)hipEventDestroy(h->events[i]);
   delete h;
   return 0;
 }
@@ -207,7 +286,8 @@ int gpp_potrf(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, in
   if (!info_dev) return -7;
   GPP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int32_t), h->stream));
   Ctx c{h->stream, A, ld, Linv, ldi, info_dev};
-  GPP_TRY(potrf_rec(c, 0, N));
+  if (N >= 4 * LOOKAHEAD_NB) GPP_TRY(potrf_lookahead(h, c, N, LOOKAHEAD_NB));
+  else GPP_TRY(potrf_rec(c, 0, N));
   return 0;
 }
 

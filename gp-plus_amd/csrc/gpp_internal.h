@@ -8,9 +8,12 @@
 
 struct gpp_handle_s {
   int device;
-  hipStream_t stream;
+  hipStream_t stream;        // caller's stream (gpp_set_stream)
   void* ws;
   size_t ws_bytes;
+  hipStream_t panel_stream;  // internal high-priority, non-blocking stream of the look-ahead Cholesky (lazy)
+  hipEvent_t events[16];     // ring of timing-disabled events for the two-stream hand-offs (lazy)
+  int n_events, ev_next;
 };
 
 // ---- fp64 MFMA GEMM (gpp_gemm.hip) ------------------------------------------------------------

@@ -51,9 +51,12 @@ __device__ __forceinline__ void store_acc(double* tile, const v4d& a, int lane) 
 
 __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
                                                           int64_t ldi, int n, int32_t* info, int row_offset) {
+  // ONE 36-tile image (76.5 KiB, so the leaf can share a CU with a 72.5 KiB GEMM work-group when it runs on the
+  // look-ahead stream).  Slot (i,j) holds, in turn: the parked raw tile, L(i,j) (off-diagonal) or inv(L_jj) (diagonal),
+  // and finally inv(L)(i,j): L(i,j) is consumed exactly at the merge level that overwrites it.
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* Limg = lds;             // 36 tiles
-  double* Ximg = lds + NT * TSZ;  // 36 tiles
+  double* Limg = lds;
+  double* Ximg = lds;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane >> 4, lc = lane & 15;
 
@@ -128,11 +131,10 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
       }
       if (lane < 16) {
         const int grow = 16 * s + i;
-        double* Xd = Ximg + toff(s, s);
+        double* Xd = Ximg + toff(s, s);  // == D: the raw diagonal tile was read into registers above
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
           const double lv = (c <= i) ? a[c] : 0.0;
-          D[i * TLD + c] = lv;
           Xd[c * TLD + i] = x[c];  // X[c][i]
           if (grow < n && c <= i) A[(int64_t)(16 * s + c) * lda + grow] = lv;  // U[col][row] = L[row][col]
         }
@@ -197,6 +199,15 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
           for (int kk = 0; kk < 4; ++kk)
             t[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag_rk(Lt, 4 * kk, lane), frag_kn(Xt, 4 * kk, lane), t[q], 0, 0, 0);
         }
+      }
+    }
+    __syncthreads();  // every L(i,k) of this level has been read: the slots may now take T
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = wave + 4 * q;
+      if (e < ntile) {
+        const int p = e / (h * h), rem = e - p * h * h;
+        const int b = 2 * h * p, i = b + h + rem / h, j = b + rem % h;
         store_acc(Ximg + toff(i, j), t[q], lane);
       }
     }
@@ -246,7 +257,7 @@ hipError_t gpp_launch_leaf(hipStream_t s, double* A, int64_t lda, double* Linv, 
   if (n <= 0) return hipSuccess;
   if (n > NB) return hipErrorInvalidValue;
   static bool attr_set = false;
-  const size_t shmem = (size_t)2 * NT * TSZ * sizeof(double);
+  const size_t shmem = (size_t)NT * TSZ * sizeof(double);
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gpp_leaf_potrf_inv),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
