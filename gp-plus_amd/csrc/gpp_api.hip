@@ -20,6 +20,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <new>
 
 namespace {
@@ -108,13 +110,43 @@ hipError_t potrf_rec(const Ctx& c, int64_t o, int64_t n) {
 // high-priority stream while the main stream still runs the bulk of step k's trailing update.
 //   panel stream : wait S(k-1); U_kk = potrf(A_kk) (recursive); U_k,k+1: = U_kk^-T A_k,k+1: ; record P(k)
 //   main  stream : wait P(k);  strip (next block row) -= ...; record S(k);  rest of the trailing matrix -= ...
+// Stream priorities alone do not help: while a trailing update saturates every CU the hardware does not place the
+// (single work-group, 72 KiB LDS) leaf of the next panel until the update drains (measured: the leaf "ran" for 5.8 ms).
+// So the two internal streams get DISJOINT CU sets through CU masks: PANEL_CUS compute units run the latency-bound
+// diagonal-block factorisations, the remaining ones the wide trsm and trailing updates.
+constexpr int PANEL_CUS = 16;
 hipError_t ensure_streams(gpp_handle_s* h) {
-  if (!h->panel_stream) {
-    int lo = 0, hi = 0;
-    hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
+  if (h->cu_split < 0) {
+    hipDeviceProp_t prop;
+    hipError_t e = hipGetDeviceProperties(&prop, h->device);
     if (e != hipSuccess) return e;
-    e = hipStreamCreateWithPriority(&h->panel_stream, hipStreamNonBlocking, hi);
-    if (e != hipSuccess) return e;
+    const int ncu = prop.multiProcessorCount;
+    h->cu_split = 0;
+    if (ncu >= 4 * PANEL_CUS && ncu <= 1024) {
+      uint32_t mp[32] = {0}, mu[32] = {0};
+      const int words = (ncu + 31) / 32;
+      for (int c = 0; c < ncu; ++c) (c < PANEL_CUS ? mp : mu)[c >> 5] |= 1u << (c & 31);
+      hipStream_t sp = nullptr, su = nullptr;
+      if (hipExtStreamCreateWithCUMask(&sp, words, mp) == hipSuccess &&
+          hipExtStreamCreateWithCUMask(&su, words, mu) == hipSuccess) {
+        h->panel_stream = sp;
+        h->upd_stream = su;
+        h->cu_split = 1;
+      } else {
+        (void)hipGetLastError();
+        if (sp) (void)hipStreamDestroy(sp);
+        if (su) (void)hipStreamDestroy(su);
+      }
+    }
+    if (!h->cu_split) {  // fallback: priority streams sharing all CUs
+      int lo = 0, hi = 0;
+      e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (e != hipSuccess) return e;
+      e = hipStreamCreateWithPriority(&h->panel_stream, hipStreamNonBlocking, hi);
+      if (e != hipSuccess) return e;
+      e = hipStreamCreateWithFlags(&h->upd_stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return e;
+    }
   }
   while (h->n_events < 16) {
     hipError_t e = hipEventCreateWithFlags(&h->events[h->n_events], hipEventDisableTiming);
@@ -134,43 +166,58 @@ inline hipEvent_t next_event(gpp_handle_s* h) {
     if (_e != hipSuccess) return _e; \
   } while (0)
 
+// panel stream : wait S(k-1); U_kk = potrf(A_kk) (recursive, narrow launches); record D(k)
+// update stream: wait D(k); U_k,k+1: = U_kk^-T A_k,k+1: (wide trsm); next block row of the trailing matrix -= ...;
+//                record S(k); rest of the trailing matrix -= ...
 hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB) {
   HIP_TRY(ensure_streams(h));
-  Ctx cp = cm;
+  Ctx cp = cm, cu = cm;
   cp.s = h->panel_stream;
+  cu.s = h->upd_stream;
   hipEvent_t ev = next_event(h);
-  HIP_TRY(hipEventRecord(ev, cm.s));            // inputs (kernel build) are ready
+  HIP_TRY(hipEventRecord(ev, cm.s));  // inputs (kernel build) are ready
   HIP_TRY(hipStreamWaitEvent(cp.s, ev, 0));
-  for (int64_t o = 0; o < N; o += NB) {
-    const int64_t nb = std::min(NB, N - o), rem = N - o - nb;
+  HIP_TRY(hipStreamWaitEvent(cu.s, ev, 0));
+  const char* env_nb = getenv("GPP_LOOKAHEAD_NB");  // experiment knob: "big,small,threshold"
+  long nb_big = NB, nb_small = NB / 2, nb_thresh = 6 * NB;  // measured best at N = 20000 (70.6 ms vs 71.7 for 1024 flat)
+  if (env_nb) sscanf(env_nb, "%ld,%ld,%ld", &nb_big, &nb_small, &nb_thresh);
+  for (int64_t o = 0, nb = 0; o < N; o += nb) {
+    // tall block rows while the trailing update is long enough to hide their diagonal factorisation, shorter after
+    const int64_t want = (N - o >= nb_thresh) ? nb_big : nb_small;
+    nb = std::min(want, N - o);
+    const int64_t rem = N - o - nb;
     HIP_TRY(potrf_rec(cp, o, nb));
-    if (rem > 0) HIP_TRY(trsm_rec(cp, o + nb, rem, o, nb));
-    hipEvent_t P = next_event(h);
-    HIP_TRY(hipEventRecord(P, cp.s));
-    HIP_TRY(hipStreamWaitEvent(cm.s, P, 0));
+    hipEvent_t D = next_event(h);
+    HIP_TRY(hipEventRecord(D, cp.s));
+    HIP_TRY(hipStreamWaitEvent(cu.s, D, 0));
     if (rem == 0) break;
-    const int64_t nb2 = std::min(NB, rem), rest = rem - nb2;
-    const double* Urow = cm.A + o * cm.ld;       // block row o: U[o.., :]
+    HIP_TRY(trsm_rec(cu, o + nb, rem, o, nb));
+    const int64_t want2 = (rem >= nb_thresh) ? nb_big : nb_small;
+    const int64_t nb2 = std::min(want2, rem), rest = rem - nb2;
+    const double* Urow = cm.A + o * cm.ld;  // block row o: U[o.., :]
     // strip = next block row of the trailing matrix (its diagonal block, upper, then the part to its right)
     GemmArgs g = mk(Urow + (o + nb), cm.ld, Urow + (o + nb), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb), cm.ld, nb2, nb2, nb,
                     -1.0, 1.0);
     g.c_lower = 2;
-    HIP_TRY(gpp_launch_gemm(cm.s, 2, g, 1));
+    HIP_TRY(gpp_launch_gemm(cu.s, 2, g, 1));
     if (rest > 0) {
       GemmArgs g2 = mk(Urow + (o + nb), cm.ld, Urow + (o + nb + nb2), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb + nb2), cm.ld,
                        nb2, rest, nb, -1.0, 1.0);
-      HIP_TRY(gpp_launch_gemm(cm.s, 2, g2, 1));
+      HIP_TRY(gpp_launch_gemm(cu.s, 2, g2, 1));
     }
     hipEvent_t S = next_event(h);
-    HIP_TRY(hipEventRecord(S, cm.s));
-    HIP_TRY(hipStreamWaitEvent(cp.s, S, 0));     // the next panel may start
+    HIP_TRY(hipEventRecord(S, cu.s));
+    HIP_TRY(hipStreamWaitEvent(cp.s, S, 0));  // the next diagonal block may be factored
     if (rest > 0) {
       GemmArgs g3 = mk(Urow + (o + nb + nb2), cm.ld, Urow + (o + nb + nb2), cm.ld,
                        cm.A + (o + nb + nb2) * cm.ld + (o + nb + nb2), cm.ld, rest, rest, nb, -1.0, 1.0);
       g3.c_lower = 2;
-      HIP_TRY(gpp_launch_gemm(cm.s, 2, g3, 1));
+      HIP_TRY(gpp_launch_gemm(cu.s, 2, g3, 1));
     }
   }
+  hipEvent_t E = next_event(h);
+  HIP_TRY(hipEventRecord(E, cu.s));
+  HIP_TRY(hipStreamWaitEvent(cm.s, E, 0));  // (the update stream already waited for the last D)
   return hipSuccess;
 }
 
@@ -201,6 +248,8 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->ws = nullptr;
   h->ws_bytes = 0;
   h->panel_stream = nullptr;
+  h->upd_stream = nullptr;
+  h->cu_split = -1;
   h->n_events = 0;
   h->ev_next = 0;
   *out = h;
@@ -210,6 +259,7 @@ int gpp_create(gpp_handle_t* out, int device) {
 int gpp_destroy(gpp_handle_t h) {
   if (!h) return -1;
   if (h->panel_stream) (void)hipStreamDestroy(h->panel_stream);
+  if (h->upd_stream) (void)hipStreamDestroy(h->upd_stream);
   for (int i = 0; i < h->n_events; ++i) (void)hipEventDestroy(h->events[i]);
   delete h;
   return 0;
@@ -320,7 +370,7 @@ int gpp_trtri(gpp_handle_t h, const double* U, int64_t N, int64_t ld, double* Li
       // Linv21 = -W22^T * T21  (TN; W22 = mirrored upper part of the (o+s) block: keep k <= m), plus its mirror
       GemmArgs g2 = mk(Linv + (o + s) * ldi + (o + s), ldi, T + (o + s) * ldt + o, ldt, Linv + (o + s) * ldi + o, ldi, m2,
                        s, m2, -1.0, 0.0);
-      g2.a_mask = 1; g2.khi_mode = 1;
+      g2.a_mask = 1; g2.khi_mode = 1; g2.row_reverse = 1;
       g2.sA = pstride_I; g2.sB = pstride_T; g2.sC = pstride_I;
       g2.C2 = Linv + o * ldi + (o + s); g2.ldc2 = ldi; g2.sC2 = pstride_I;
       GPP_TRY(gpp_launch_gemm(h->stream, 2, g2, batch));

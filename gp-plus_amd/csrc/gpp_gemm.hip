@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256, (VAR == 2 || WTM < 64) ? 2 : 1) void gpp_gemm_
     } else {
       tm = t / p.tiles_n;
       tn = t - tm * p.tiles_n;
+      if (p.row_reverse) tm = p.tiles_m - 1 - tm;  // longest K ranges (khi grows with the row) first: short tail
     }
   }
   const double* __restrict__ A = p.A + (int64_t)blockIdx.y * p.sA;

@@ -11,7 +11,9 @@ struct gpp_handle_s {
   hipStream_t stream;        // caller's stream (gpp_set_stream)
   void* ws;
   size_t ws_bytes;
-  hipStream_t panel_stream;  // internal high-priority, non-blocking stream of the look-ahead Cholesky (lazy)
+  hipStream_t panel_stream;  // internal stream of the look-ahead Cholesky: diagonal-block factorisations (lazy)
+  hipStream_t upd_stream;    // internal stream of the look-ahead Cholesky: wide trsm / trailing updates (lazy)
+  int cu_split;              // 1: the two streams own disjoint CU sets (CU masks), 0: plain priority streams, -1: unknown
   hipEvent_t events[16];     // ring of timing-disabled events for the two-stream hand-offs (lazy)
   int n_events, ev_next;
 };
@@ -34,6 +36,7 @@ struct GemmArgs {
   int k_reverse;           // walk the k range from its top down (see gpp_gemm.hip)
   int tag;                 // 1: launch the separately named instantiation (profiling label, same code)
   int col_major;           // enumerate tiles column by column (non-triangular outputs)
+  int row_reverse;         // row-major order, last row tile first
   int swz;                 // set by the launcher: XCD-aware 8x8 super-tile mapping of blockIdx -> tile
 };
 // variant: 0 = NT (A[m][k], B[n][k]), 1 = NN (A[m][k], B[k][n]), 2 = TN (A[k][m], B[k][n])

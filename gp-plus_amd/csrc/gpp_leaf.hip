@@ -22,8 +22,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int NB = GPP_TILE;
-constexpr int TLD = 17;            // padded tile row (doubles)
-constexpr int TSZ = 16 * TLD;      // doubles per LDS tile
+constexpr int TSZ = 16 * 16;       // doubles per LDS tile (unpadded: the whole image must fit ONE GEMM LDS slot)
 constexpr int NT = 36;             // lower tiles of an 8x8 grid
 constexpr int SLOTS = 9;           // tiles per wave
 
@@ -36,23 +35,27 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
   return __hiloint2double(hi, lo);
 }
 
+// Element (row, col) of a 16 x 16 LDS tile.  Rows are 128 bytes; the XOR swizzle (col ^ row>>1) spreads a column
+// read (16 rows, same col) over 16 distinct 8-byte bank slots without padding the tile.
+__device__ __forceinline__ int tix(int row, int col) { return row * 16 + (col ^ (row >> 1)); }
+
 // A-operand fragment of tile[m][k] (also the B operand of an "X * tile^T" product): lane (m = l&15, k = k0 + l>>4)
 __device__ __forceinline__ double frag_rk(const double* tile, int k0, int lane) {
-  return tile[(lane & 15) * TLD + k0 + (lane >> 4)];
+  return tile[tix(lane & 15, k0 + (lane >> 4))];
 }
 // B-operand fragment of tile[k][n]: lane (n = l&15, k = k0 + l>>4)
 __device__ __forceinline__ double frag_kn(const double* tile, int k0, int lane) {
-  return tile[(k0 + (lane >> 4)) * TLD + (lane & 15)];
+  return tile[tix(k0 + (lane >> 4), lane & 15)];
 }
 __device__ __forceinline__ void store_acc(double* tile, const v4d& a, int lane) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) tile[((lane >> 4) + 4 * r) * TLD + (lane & 15)] = a[r];
+  for (int r = 0; r < 4; ++r) tile[tix((lane >> 4) + 4 * r, lane & 15)] = a[r];
 }
 
 __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
                                                           int64_t ldi, int n, int32_t* info, int row_offset) {
-  // ONE 36-tile image (76.5 KiB, so the leaf can share a CU with a 72.5 KiB GEMM work-group when it runs on the
-  // look-ahead stream).  Slot (i,j) holds, in turn: the parked raw tile, L(i,j) (off-diagonal) or inv(L_jj) (diagonal),
+  // ONE 36-tile image of exactly 72 KiB: LDS is allocated contiguously, so on the look-ahead stream the leaf can only
+  // start beside a running GEMM work-group if it fits the 72.5 KiB slot a finished GEMM work-group leaves behind.  Slot (i,j) holds, in turn: the parked raw tile, L(i,j) (off-diagonal) or inv(L_jj) (diagonal),
   // and finally inv(L)(i,j): L(i,j) is consumed exactly at the merge level that overwrites it.
   extern __shared__ __attribute__((aligned(16))) double lds[];
   double* Limg = lds;
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
       const int i = lc;
       double a[16], x[16], rd[16];
 #pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = D[i * TLD + c];
+      for (int c = 0; c < 16; ++c) a[c] = D[tix(i, c)];
       int bad = 0;
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
           const double lv = (c <= i) ? a[c] : 0.0;
-          Xd[c * TLD + i] = x[c];  // X[c][i]
+          Xd[tix(c, i)] = x[c];  // X[c][i]
           if (grow < n && c <= i) A[(int64_t)(16 * s + c) * lda + grow] = lv;  // U[col][row] = L[row][col]
         }
       }
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
   for (int e = tid; e < n * n; e += 256) {
     const int row = e / n, col = e - row * n;
     const int hi = row > col ? row : col, lo = row > col ? col : row;
-    Linv[(int64_t)row * ldi + col] = Ximg[toff(hi >> 4, lo >> 4) + (hi & 15) * TLD + (lo & 15)];
+    Linv[(int64_t)row * ldi + col] = Ximg[toff(hi >> 4, lo >> 4) + tix(hi & 15, lo & 15)];
   }
 }
 

@@ -1,0 +1,58 @@
+"""BASELINE.json configs C1..C5 on ONE MI355X: evaluations/s of loss+grad through the GP_Plus API (dev / docs tool)."""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpplus_amd.gpcore import ExactMarginalLogLikelihood
+from gpplus_amd.models import GP_Plus
+from gpplus_amd.preprocessing import standard
+from gpplus_amd.test_functions.analytical import borehole, borehole_mixed_variables
+from gpplus_amd.test_functions.multi_fidelity import multi_fidelity_wing
+from scipy.stats.qmc import Sobol
+
+def timed(model, reps):
+    model.train(); mll = ExactMarginalLogLikelihood(model.likelihood, model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    def step():
+        for p in params: p.grad = None
+        loss = -mll(model(*model.train_inputs), model.train_targets); loss.backward(); return loss
+    step(); torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps): loss = step()
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+    return dt, loss.item()
+
+def theta(model, omega=-1.0):
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if 'raw_lengthscale' in n and p.requires_grad: p.fill_(omega)
+            elif n == 'covar_module.raw_outputscale': p.fill_(0.3)
+            elif 'raw_noise' in n: p.fill_(-6.0)
+            elif n.endswith('.constant'): p.fill_(0.4 if n == 'mean_module.constant' else 0.1)
+
+which = sys.argv[1:] or ['C1', 'C2', 'C3', 'C4', 'C5']
+dev = 'cuda'
+for c in which:
+    if c == 'C1':
+        X, y = borehole(n=10000, random_state=12345); X = torch.tensor(X[:500]); y = torch.tensor(y[:500]); X, _, _ = standard(X, {})
+        m = GP_Plus(X, y, dtype=torch.float64, device=dev); reps = 20
+    elif c == 'C2':
+        X, y = borehole(n=20000, random_state=0, shuffle=False); X, _, _ = standard(torch.tensor(X), {})
+        m = GP_Plus(X, torch.tensor(y), dtype=torch.float64, device=dev); reps = 5
+    elif c == 'C3':
+        np.random.seed(4); qd = {0: 5, 5: 5}
+        U, y = borehole_mixed_variables(n=10000, qual_dict=qd, random_state=4, shuffle=False)
+        U, _, _ = standard(torch.as_tensor(U).double(), qd)
+        m = GP_Plus(U, torch.tensor(y), qual_dict=qd, dtype=torch.float64, device=dev); reps = 5
+    elif c == 'C4':
+        X, y = multi_fidelity_wing(n={'0': 5000, '1': 5000, '2': 5000}, noise_std={'0': 0.5, '1': 1.0, '2': 1.5}, random_state=4)
+        X, _, _ = standard(torch.tensor(X), {10: 3})
+        m = GP_Plus(X, torch.tensor(y), qual_dict={10: 3}, multiple_noise=True, m_gp='multiple_constant', dtype=torch.float64, device=dev); reps = 5
+    elif c == 'C5':
+        Xs = Sobol(d=16, seed=0).random(2 ** 16)[:60000]; Xs = (Xs - Xs.mean(0)) / Xs.std(0)
+        rng = np.random.default_rng(0); y = np.sin(Xs).sum(1) + 1e-2 * rng.standard_normal(60000)
+        m = GP_Plus(torch.tensor(Xs), torch.tensor(y), dtype=torch.float64, device=dev); reps = 2
+    theta(m, -1.5 if c == 'C5' else -1.0)
+    dt, loss = timed(m, reps)
+    N = m.train_targets.shape[0]
+    print(f"{c}: N={N} D={m.train_inputs[0].shape[1]}  {dt*1e3:9.2f} ms/eval  {1/dt:8.3f} evals/s  {N**3/dt/1e12:6.2f} TFLOP/s(N^3)  loss={loss:.6f}  mem={torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
+    del m; torch.cuda.empty_cache()
+    import gpplus_amd.linalg as L; L._workspaces.clear(); torch.cuda.empty_cache()
