@@ -1,0 +1,150 @@
+"""L-BFGS-B (and friends) multistart fit driver through scipy (reference: optim/mll_scipy.py:37-307).
+
+Same objective and surface as the reference — ``obj = -(log_prob + sum of prior log-densities)`` (NOT divided by N,
+optim/mll_scipy.py:37-43,120), parameter pack/unpack over ``named_parameters`` with ``requires_grad``, the bounds table
+(:149-183), method defaults (:261-271), NotPSD/NaN starts scored ``inf`` (:232-240,295) — with every evaluation on the
+HIP back end.  Differences, by design:
+  * the starts run one after the other on the GPU instead of in joblib/loky worker processes (:287-293); with an
+    initialised process group use ``fit_restarts_parallel(model, fit_fn=fit_model_scipy, ...)`` to spread them over GPUs;
+  * restart points come from ``model.reset_parameters()`` (prior samples pushed through the parameters' own setting
+    closures) — the reference concatenates prior samples in ``named_priors`` order and on the constrained scale for the
+    outputscale (:130-137), which does not line up with its own packing order;
+  * parameters keep the model's dtype (the reference round-trips theta through fp32, :32-35,97);
+  * the interval-score term and the NN-weight regularisers (:44-59) belong to out-of-scope model variants.
+"""
+from collections import OrderedDict
+from copy import deepcopy
+from functools import reduce
+from typing import Dict, List, Optional, Tuple, Union
+
+import numpy as np
+import torch
+from scipy.optimize import Bounds, OptimizeResult, minimize
+
+from ..errors import NanError, NotPSDError
+
+
+def marginal_log_likelihood(model, add_prior: bool, regularization_parameter=[0, 0]):
+    """optim/mll_scipy.py:37-60 (exact log-marginal + priors, un-normalised)."""
+    output = model(*model.train_inputs)
+    out = model.likelihood(output).log_prob(model.train_targets)
+    if add_prior:
+        for _, module, prior, closure, _ in model.named_priors():
+            out = out + prior.log_prob(closure(module)).sum().to(out)
+    if getattr(model, "interval_score", False):
+        raise NotImplementedError("the interval-score objective term (optim/mll_scipy.py:57-59) is outside this build's scope")
+    return out
+
+
+class MLLObjective:
+    """optim/mll_scipy.py:63-127."""
+
+    def __init__(self, model, add_prior, regularization_parameter):
+        self.model, self.add_prior, self.regularization_parameter = model, add_prior, regularization_parameter
+        self.param_shapes = OrderedDict()
+        for n, p in self.model.named_parameters():
+            if p.requires_grad:
+                self.param_shapes[n] = p.size() if len(p.size()) > 0 else torch.Size([1])
+
+    def _params(self):
+        return OrderedDict([(n, p) for n, p in self.model.named_parameters() if p.requires_grad])
+
+    def pack_parameters(self) -> np.ndarray:
+        return np.concatenate([p.detach().cpu().double().numpy().ravel() for p in self._params().values()])
+
+    def unpack_parameters(self, x: np.ndarray) -> "OrderedDict[str, torch.Tensor]":
+        i, named = 0, OrderedDict()
+        params = self._params()
+        for n, shape in self.param_shapes.items():
+            ln = reduce(lambda a, b: a * b, shape)
+            named[n] = torch.from_numpy(np.asarray(x[i:i + ln], dtype=np.float64).reshape(*shape)).to(params[n]).reshape(params[n].shape)
+            i += ln
+        return named
+
+    def pack_grads(self) -> np.ndarray:
+        return np.concatenate([p.grad.detach().cpu().double().numpy().ravel() for p in self._params().values()]).astype(np.float64)
+
+    def fun(self, x: np.ndarray, return_grad=True) -> Union[float, Tuple[float, np.ndarray]]:
+        old = self.model.state_dict()
+        old.update(self.unpack_parameters(x))
+        self.model.load_state_dict(old)
+        self.model.zero_grad()
+        obj = -marginal_log_likelihood(self.model, self.add_prior, self.regularization_parameter)
+        if return_grad:
+            obj.backward()
+            return obj.item(), self.pack_grads()
+        return obj.item()
+
+
+def get_bounds(likobj: MLLObjective, theta: np.ndarray):
+    """optim/mll_scipy.py:149-183."""
+    lo, hi = [], []
+    for name, values in likobj.unpack_parameters(theta).items():
+        n = values.numel()
+        if name == 'likelihood.noise_covar.raw_noise' or name.startswith('[') or name.startswith('latent['):
+            a, b = -np.inf, np.inf
+        elif 'raw_lengthscale' in name or name.startswith('covar_module'):
+            a, b = -10.0, 3.0
+        elif name.startswith('mean'):
+            a, b = -1.5, 1.5
+        else:
+            a, b = -np.inf, np.inf
+        lo += [a] * n
+        hi += [b] * n
+    return np.array(lo), np.array(hi)
+
+
+def _fit_model_from_state(likobj, theta0, jac, options, method='L-BFGS-B', constraint=False, bounds=False):
+    if constraint:
+        raise NotImplementedError("latent-position constraints (optim/mll_scipy.py:140-147,189) are outside this build's scope")
+    bnds = Bounds(*get_bounds(likobj, theta0)) if bounds else None
+    try:
+        return minimize(fun=likobj.fun, x0=theta0, args=(True) if jac else (False), method=method, jac=jac, bounds=bnds,
+                        options=options)
+    except (NotPSDError, NanError) as e:  # unstable start: scored inf by the caller (optim/mll_scipy.py:232-236,295)
+        return e
+
+
+def fit_model_scipy(model, add_prior: bool = True, num_restarts: int = 1, theta0_list: Optional[List[np.ndarray]] = None,
+                    jac: bool = True, options: Dict = {}, n_jobs: int = -1, method='L-BFGS-B', constraint=False,
+                    bounds=False, regularization_parameter: List[int] = [0, 0]) -> Tuple[List[OptimizeResult], float]:
+    if method == 'L-BFGS-B':
+        defaults = {'ftol': 1e-6, 'gtol': 1e-5, 'maxfun': 5000, 'maxiter': 2000}
+    elif method == 'trust-constr':
+        defaults = {'verbose': 1}
+    elif method == 'BFGS':
+        defaults = {'gtol': 1e-07, 'norm': np.inf, 'eps': 1.4901161193847656e-08, 'maxiter': None, 'disp': False,
+                    'return_all': False, 'finite_diff_rel_step': None}
+    elif method == 'SLSQP':
+        defaults = {'maxiter': 100, 'ftol': 1e-06, 'iprint': 1, 'disp': False, 'eps': 1.4901161193847656e-08,
+                    'finite_diff_rel_step': None}
+    elif method == 'Newton-CG':
+        defaults = {'xtol': 1e-05, 'eps': 1.4901161193847656e-08, 'maxiter': None, 'disp': False, 'return_all': False}
+    else:
+        raise ValueError('Wrong method')
+    for key in options.keys():
+        if key not in defaults.keys():
+            raise RuntimeError('Unknown option %s!' % key)
+        defaults[key] = options[key]
+
+    model.train()
+    likobj = MLLObjective(model, add_prior, regularization_parameter)
+    if theta0_list is None:
+        theta0_list = [likobj.pack_parameters()]
+        if num_restarts > -1:
+            start_state = deepcopy(model.state_dict())
+            samples = []
+            for _ in range(num_restarts + 1):
+                model.reset_parameters()
+                samples.append(likobj.pack_parameters())
+            model.load_state_dict(start_state)
+            theta0_list.extend(samples)
+            theta0_list.pop(0)  # as the reference: the incumbent point itself is not among the starts
+    out = [_fit_model_from_state(likobj, theta0, jac, defaults, method, constraint, bounds) for theta0 in theta0_list]
+    nlls_opt = [np.inf if isinstance(res, Exception) else res.fun for res in out]
+    best_idx = int(np.argmin(nlls_opt))
+    if not isinstance(out[best_idx], Exception):
+        old = deepcopy(model.state_dict())
+        old.update(likobj.unpack_parameters(out[best_idx].x))
+        model.load_state_dict(old)
+    return out, nlls_opt[best_idx]

@@ -248,3 +248,29 @@ def test_full_size_properties_n20000(gpu_ctx):
         fro += float((blk * blk).sum())
     expect = 0.5 * (float(alpha @ alpha) - fro)
     assert abs(g_tau.item() - expect) <= 1e-6 * abs(expect)
+
+
+def test_fit_model_scipy_lbfgs(gpu_ctx):
+    """the scipy multistart driver on the HIP back end; objective = -(log_prob + priors), not / N."""
+    from oracle.gp_oracle import OracleGP
+    from gpplus_amd.optim import MLLObjective, fit_model_scipy
+    from gpplus_amd.utils import set_seed
+
+    fx = load("c1_borehole_n500.npz")
+    m = build(fx, "theta1")
+    m.train()
+    obj = MLLObjective(m, True, [0, 0])
+    theta = obj.pack_parameters()
+    f, g = obj.fun(theta)
+    o = OracleGP(fx["Xtrain"], fx["ytrain"])
+    for k in list(o.params):
+        o.params[k] = torch.as_tensor(fx[f"theta1::param::{k}"], dtype=torch.float64)
+    lo, go = o.loss_and_grad(normalize=False)
+    assert abs(f - lo.item()) <= RTOL_MLL * abs(lo.item())
+    gref = np.concatenate([go[n].numpy().ravel() for n in obj.param_shapes])
+    np.testing.assert_allclose(g, gref, rtol=RTOL_MLL, atol=RTOL_MLL * np.abs(gref).max())
+    set_seed(3)
+    res, best = fit_model_scipy(m, num_restarts=1, options={"maxiter": 25}, bounds=True)
+    assert len(res) == 2 and np.isfinite(best) and best < f
+    f_after, _ = MLLObjective(m, True, [0, 0]).fun(MLLObjective(m, True, [0, 0]).pack_parameters())
+    assert abs(f_after - best) <= 1e-8 * abs(best)   # the model holds the best start's parameters
