@@ -425,7 +425,8 @@ int gpp_grad_reduce(gpp_handle_t h, const double* U, int64_t N, int D, const dou
   if (!w) return -5;
   if (!sf2) return -6;
   if (S < 1 || S > 64) return -8;
-  if (kind != GPP_KIND_RBF) return -9;
+  if (kind < 0 || kind > 2) return -9;
+  if (d_split < 0 || d_split > D) return -10;
   if (!alpha) return -11;
   if (int q = check_mat(Kinv, ldk, N, 12)) return q;
   if (dU < 0 || dU > D) return -14;

@@ -119,7 +119,7 @@ __device__ __forceinline__ void tile_from_index(int64_t t, int64_t& ti, int64_t&
 template <int DT>
 __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__ U, int64_t N, int D,
                                                       const double* __restrict__ w, const double* __restrict__ sf2p,
-                                                      const double* __restrict__ alpha, const double* __restrict__ Kinv,
+                                                      int kind, int d_split, const double* __restrict__ alpha, const double* __restrict__ Kinv,
                                                       int64_t ldk, int dU, int64_t ntiles,
                                                       double* __restrict__ rec /* [gridDim.x][D+1] */,
                                                       double* __restrict__ wdiag /* [N] */,
@@ -157,29 +157,47 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
     }
     __syncthreads();
 
-    double G[4][4];
+    // G  = mult * W_ij * dK_ij/d(-r2_rbf)  (= mult W K for the RBF dims)
+    // GM = mult * W_ij * dK_ij/d(-r2_mat)  for the Matern dims (d >= d_split), with K = sf2 e^{-r2_rbf} m(a):
+    //      nu = 3/2: a = sqrt(6 r2_mat), m = (1+a)e^{-a},          dm/d(-r2_mat) = 3 e^{-a}
+    //      nu = 5/2: a = sqrt(10 r2_mat), m = (1+a+a^2/3)e^{-a},   dm/d(-r2_mat) = (5/3)(1+a) e^{-a}
+    const int dsp = (kind == 0) ? DT : d_split;
+    double G[4][4], GM[4][4];
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
       const int64_t i = i0 + 4 * ty + a;
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         const int64_t j = j0 + 4 * tx + b;
-        double g = 0.0;
+        double g = 0.0, gm = 0.0;
         if (i < N && j <= i) {
-          double r2 = 0.0;
+          double r2 = 0.0, r2m = 0.0;
 #pragma unroll
           for (int d = 0; d < DT; ++d) {
             const double df = sa[d * GT + 4 * ty + a] - sb[d * GT + 4 * tx + b];
-            r2 = fma(sw[d] * df, df, r2);
+            if (d < dsp) r2 = fma(sw[d] * df, df, r2);
+            else r2m = fma(sw[d] * df, df, r2m);
           }
-          const double kv = exp(-r2);
+          const double er = exp(-r2);
+          double kv = er, kd = 0.0;
+          if (kind == 1) {
+            const double aa = sqrt(6.0 * r2m), ea = exp(-aa);
+            kv = er * (1.0 + aa) * ea;
+            kd = er * 3.0 * ea;
+          } else if (kind == 2) {
+            const double aa = sqrt(10.0 * r2m), ea = exp(-aa);
+            kv = er * (1.0 + aa + aa * aa * (1.0 / 3.0)) * ea;
+            kd = er * (5.0 / 3.0) * (1.0 + aa) * ea;
+          }
           const double Wij = 0.5 * (sal_a[4 * ty + a] * sal_b[4 * tx + b] - Kinv[i * ldk + j]);
           const double mult = (i == j) ? 1.0 : 2.0;
           my_sf2 = fma(mult * Wij, kv, my_sf2);
           g = mult * Wij * sf2 * kv;
+          gm = mult * Wij * sf2 * kd;
           if (i == j) wdiag[i] = Wij;
         }
         G[a][b] = g;
+        GM[a][b] = gm;
       }
     }
 #pragma unroll
@@ -190,25 +208,28 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
           const double df = sa[d * GT + 4 * ty + a] - sb[d * GT + 4 * tx + b];
-          s = fma(-G[a][b] * df, df, s);
+          s = fma(-((d < dsp) ? G[a][b] : GM[a][b]) * df, df, s);
         }
       my_w[d] += s;
     }
     for (int d = 0; d < dU; ++d) {
       const double m2w = -2.0 * sw[d];
+      const bool rbf_dim = d < dsp;
       double rs[4], cs[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
         double s = 0.0;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) s = fma(G[a][b], sa[d * GT + 4 * ty + a] - sb[d * GT + 4 * tx + b], s);
+        for (int b = 0; b < 4; ++b)
+          s = fma(rbf_dim ? G[a][b] : GM[a][b], sa[d * GT + 4 * ty + a] - sb[d * GT + 4 * tx + b], s);
         rs[a] = s;
       }
 #pragma unroll
       for (int b = 0; b < 4; ++b) {
         double s = 0.0;
 #pragma unroll
-        for (int a = 0; a < 4; ++a) s = fma(G[a][b], sb[d * GT + 4 * tx + b] - sa[d * GT + 4 * ty + a], s);
+        for (int a = 0; a < 4; ++a)
+          s = fma(rbf_dim ? G[a][b] : GM[a][b], sb[d * GT + 4 * tx + b] - sa[d * GT + 4 * ty + a], s);
         cs[b] = s;
       }
       __syncthreads();
@@ -344,8 +365,7 @@ hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int
                                   const int32_t* grp, int S, int kind, int d_split, const double* alpha,
                                   const double* Kinv, int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau,
                                   double* g_U, void* ws, size_t ws_bytes) {
-  (void)d_split;
-  if (kind != 0) return hipErrorInvalidValue;  // Matern gradients: SURVEY.md §8(f2), not on the round-1 path
+  if (kind < 0 || kind > 2) return hipErrorInvalidValue;
   if (D > GD_MAX || D < 1 || S > GS_MAX || S < 1 || dU > D || dU < 0) return hipErrorInvalidValue;
   if (ws_bytes < gpp_grad_ws_bytes(N, D, S, dU)) return hipErrorInvalidValue;
   const int T = (int)((N + GT - 1) / GT);
@@ -355,8 +375,8 @@ hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int
   double* wdiag = rec + (size_t)G_WGS * (D + 1);
   double* gUpart = wdiag + N;
 #define GPP_GRAD_LAUNCH(DT)                                                                                              \
-  hipLaunchKernelGGL(gpp_grad_tiles<DT>, dim3(nwg), dim3(256), 0, s, U, N, D, w, sf2, alpha, Kinv, ldk, dU, ntiles, rec, \
-                     wdiag, gUpart)
+  hipLaunchKernelGGL(gpp_grad_tiles<DT>, dim3(nwg), dim3(256), 0, s, U, N, D, w, sf2, kind, d_split, alpha, Kinv, ldk, dU, \
+                     ntiles, rec, wdiag, gUpart)
   if (D <= 8) GPP_GRAD_LAUNCH(8);
   else if (D <= 16) GPP_GRAD_LAUNCH(16);
   else if (D <= 32) GPP_GRAD_LAUNCH(32);

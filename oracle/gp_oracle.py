@@ -112,6 +112,25 @@ def rbf_gpytorch(x1: torch.Tensor, x2: torch.Tensor, lengthscale: torch.Tensor) 
     return sq_dist_gpytorch(x1 / lengthscale, x2 / lengthscale, eq).div(-2).exp()
 
 
+def matern_gpytorch(x1: torch.Tensor, x2: torch.Tensor, lengthscale: torch.Tensor, nu: float) -> torch.Tensor:
+    """[3P] gpytorch MaternKernel.forward (kernels/matern.py:4-8 fix nu = 1.5 / 2.5): centre on x1's mean, scale by the
+    lengthscale, Euclidean distance = sqrt(clamp(sq_dist, 1e-30)), (1 + sqrt(3) d) e^{-sqrt(3) d}  or
+    (1 + sqrt(5) d + 5/3 d^2) e^{-sqrt(5) d}."""
+    mean = x1.reshape(-1, x1.size(-1)).mean(0)
+    x1_ = (x1 - mean) / lengthscale
+    x2_ = (x2 - mean) / lengthscale
+    eq = x1.shape == x2.shape and torch.equal(x1, x2)
+    dist = sq_dist_gpytorch(x1_, x2_, eq).clamp_min(1e-30).sqrt()
+    exp_component = torch.exp(-math.sqrt(nu * 2) * dist)
+    if nu == 1.5:
+        constant_component = (math.sqrt(3) * dist).add(1)
+    elif nu == 2.5:
+        constant_component = (math.sqrt(5) * dist).add(1).add(5.0 / 3.0 * dist ** 2)
+    else:
+        raise ValueError(nu)
+    return constant_component * exp_component
+
+
 def rough_rbf_standalone(x1: torch.Tensor, x2: torch.Tensor, lengthscale: torch.Tensor) -> torch.Tensor:
     """kernels/Rough_RBF.py:6-7,27-32 (grad/ARD branch): inputs scaled by sqrt(l), squared distance, and the file's
     OWN postprocess_rbf = div_(-1).exp_()  =>  exp(-sum_d l_d (x1_d-x2_d)^2)."""
@@ -276,7 +295,8 @@ class OracleGP:
     def lengthscale(self, p=None):
         p = self.params if p is None else p
         raw = p[self.ls_key]
-        return rough_lengthscale(raw) if self.kclass == "Rough_RBF" else exp_lengthscale(raw)
+        # gp_plus.py:243-272: only 'RBFKernel' uses exp; Rough_RBF and the Matern classes share the 10^(-x/2) transform
+        return exp_lengthscale(raw) if self.kclass == "RBFKernel" else rough_lengthscale(raw)
 
     def prior_cov(self, U1, U2, p=None):
         """gp_plus.py:219-303 + gpregression.py:108-111: ScaleKernel(RBF(z; l=1) * RBF(x_quant; l(omega)))."""
@@ -285,7 +305,11 @@ class OracleGP:
         if self.qual_cols:
             K = rbf_gpytorch(U1[:, : self.dz], U2[:, : self.dz], torch.ones(1, self.dz, dtype=DT))  # gp_plus.py:223-226
         if self.ls_key is not None:
-            Kq = rbf_gpytorch(U1[:, self.dz:], U2[:, self.dz:], self.lengthscale(p))
+            if self.kclass in ("Matern32Kernel", "Matern52Kernel"):
+                Kq = matern_gpytorch(U1[:, self.dz:], U2[:, self.dz:], self.lengthscale(p),
+                                     1.5 if self.kclass == "Matern32Kernel" else 2.5)
+            else:
+                Kq = rbf_gpytorch(U1[:, self.dz:], U2[:, self.dz:], self.lengthscale(p))
             K = Kq if K is None else K * Kq
         return softplus(p["covar_module.raw_outputscale"]) * K
 
@@ -318,10 +342,10 @@ class OracleGP:
         tot = log_half_horseshoe_log_prob(p["likelihood.noise_covar.raw_noise"], 0.01, self.lb_noise).sum()  # gpregression.py:84
         tot = tot + lognormal_log_prob(softplus(p["covar_module.raw_outputscale"]), 1e-6, 1.0)  # gpregression.py:113-115
         if self.ls_key is not None:
-            if self.kclass == "Rough_RBF":
-                tot = tot + normal_log_prob(p[self.ls_key], -3.0, 3.0).sum()  # gp_plus.py:279-282
-            else:
+            if self.kclass == "RBFKernel":
                 tot = tot + mollified_uniform_log_prob(p[self.ls_key], math.log(0.1), math.log(10)).sum()  # gp_plus.py:274-277
+            else:
+                tot = tot + normal_log_prob(p[self.ls_key], -3.0, 3.0).sum()  # gp_plus.py:279-295 (Rough_RBF, Matern*)
         for k, v in p.items():
             if k.startswith("mean_module") and k.endswith(".constant"):
                 tot = tot + normal_log_prob(v, 0.0, 1.0).sum()  # gp_plus.py:495

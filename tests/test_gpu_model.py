@@ -274,3 +274,39 @@ def test_fit_model_scipy_lbfgs(gpu_ctx):
     assert len(res) == 2 and np.isfinite(best) and best < f
     f_after, _ = MLLObjective(m, True, [0, 0]).fun(MLLObjective(m, True, [0, 0]).pack_parameters())
     assert abs(f_after - best) <= 1e-8 * abs(best)   # the model holds the best start's parameters
+
+
+@pytest.mark.parametrize("kclass", ["Matern32Kernel", "Matern52Kernel"])
+@pytest.mark.parametrize("mixed", [False, True])
+def test_matern_models_against_oracle(gpu_ctx, kclass, mixed):
+    """Matern 3/2 and 5/2 quantitative kernels (alone, and times the RBF manifold kernel)."""
+    from oracle.gp_oracle import OracleGP
+    from gpplus_amd.models import GP_Plus
+
+    rng = np.random.default_rng(11)
+    n = 400
+    X = rng.standard_normal((n, 5))
+    kw = {}
+    if mixed:
+        X[:, 2] = rng.integers(0, 4, n)
+        kw = {"qual_dict": {2: 4}}
+    y = np.sin(X[:, 0]) + 0.2 * X[:, 1] + 0.1 * X[:, 2]
+    o = OracleGP(X, y, quant_correlation_class=kclass, seed=2, **kw)
+    o.params[o.ls_key] = torch.as_tensor(np.float32(rng.uniform(-1.0, 0.0, o.params[o.ls_key].shape)), dtype=torch.float64)
+    o.params["likelihood.noise_covar.raw_noise"] = torch.tensor([-5.0], dtype=torch.float64)
+    lo, go = o.loss_and_grad()
+    m = GP_Plus(torch.tensor(X), torch.tensor(y), dtype=torch.float64, device="cuda", quant_correlation_class=kclass, **kw)
+    sd = m.state_dict()
+    for k, v in o.params.items():
+        sd[k] = v.reshape(sd[k].shape).to(sd[k])
+    m.load_state_dict(sd)
+    loss, grads = loss_and_grads(m)
+    assert abs(loss - lo.item()) <= RTOL_MLL * abs(lo.item())
+    for k, g in go.items():
+        gref = g.numpy().reshape(grads[k].shape)
+        np.testing.assert_allclose(grads[k], gref, rtol=RTOL_MLL, atol=RTOL_MLL * max(np.abs(gref).max(), 1e-12), err_msg=k)
+    mean, std = m.predict(torch.tensor(X[:50] + 0.05), return_std=True, include_noise=True)
+    om, os_ = o.predict(X[:50] + 0.05 if not mixed else np.column_stack([X[:50, :2] + 0.05, X[:50, 2], X[:50, 3:] + 0.05]))
+    if not mixed:
+        np.testing.assert_allclose(mean.cpu().numpy(), om.numpy(), rtol=RTOL_PRED, atol=1e-7)
+        np.testing.assert_allclose(std.cpu().numpy(), os_.numpy(), rtol=RTOL_PRED, atol=1e-7)

@@ -201,3 +201,24 @@ def test_predict_matches_numpy():
     tau = math.exp(o.params["likelihood.noise_covar.raw_noise"].item()) + o.lb_noise
     sd = np.sqrt(np.maximum(sf2 - (V**2).sum(0) + tau, 1e-10)) * o.y_std.item()
     np.testing.assert_allclose(std.numpy(), sd, rtol=1e-6)
+
+
+def test_matern_kernels_against_direct_formula():
+    rng = np.random.default_rng(5)
+    x = torch.tensor(rng.standard_normal((30, 4)))
+    ls = torch.tensor([[0.7, 1.3, 0.9, 2.0]], dtype=torch.float64)
+    d = np.sqrt((((x.numpy()[:, None, :] - x.numpy()[None, :, :]) / ls.numpy()) ** 2).sum(-1))
+    k32 = (1 + math.sqrt(3) * d) * np.exp(-math.sqrt(3) * d)
+    k52 = (1 + math.sqrt(5) * d + 5.0 / 3.0 * d**2) * np.exp(-math.sqrt(5) * d)
+    np.testing.assert_allclose(G.matern_gpytorch(x, x, ls, 1.5).numpy(), k32, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(G.matern_gpytorch(x, x, ls, 2.5).numpy(), k52, rtol=1e-7, atol=1e-9)
+    o = G.OracleGP(x.numpy(), rng.standard_normal(30), quant_correlation_class="Matern52Kernel")
+    _, grads = o.loss_and_grad()
+    h = 1e-5
+    flat = o.params[o.ls_key].reshape(-1)
+    for i in range(4):
+        old = flat[i].item()
+        flat[i] = old + h; fp = o.loss().item()
+        flat[i] = old - h; fm = o.loss().item()
+        flat[i] = old
+        assert abs((fp - fm) / (2 * h) - grads[o.ls_key].reshape(-1)[i].item()) < 1e-7
