@@ -7,6 +7,7 @@ Reference boundary this replaces: the gpytorch/ATen operators reached from ``opt
 """
 from __future__ import annotations
 
+import atexit
 import ctypes
 import threading
 from typing import Dict, Optional, Tuple
@@ -168,3 +169,21 @@ def get_context(device) -> GppContext:
             ctx = GppContext(torch.device("cuda", idx))
             _contexts[key] = ctx
     return ctx
+
+
+@atexit.register
+def _destroy_contexts() -> None:
+    """Release the library handles (and their internal CU-masked streams / events) while the HIP runtime is still
+    alive; leaving them to process teardown crashes under rocprofv3."""
+    if not _contexts:
+        return
+    try:
+        torch.cuda.synchronize()
+    except Exception:
+        pass
+    for key, ctx in list(_contexts.items()):
+        try:
+            ctx.lib.gpp_destroy(ctx.h)
+        except Exception:
+            pass
+        _contexts.pop(key, None)
