@@ -33,6 +33,7 @@ _SIGNATURES = {
     "gpp_cross_kernel": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int,
                                  c_int, c_void_p, c_int64]),
     "gpp_potrf": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "gpp_potrf_ws": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "gpp_trtri": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     "gpp_lauum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64]),
     "gpp_mll_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),

@@ -108,11 +108,15 @@ class GppContext:
               "gpp_cross_kernel")
         return out
 
-    def potrf(self, A, Linv, info):
+    def potrf(self, A, Linv, info, T=None):
         _need(A, torch.float64, "A"); _need(Linv, torch.float64, "Linv"); _need(info, torch.int32, "info")
         self._stream()
-        check(self.lib.gpp_potrf(self.h, A.data_ptr(), A.shape[0], _ld(A), Linv.data_ptr(), _ld(Linv), info.data_ptr()),
-              "gpp_potrf")
+        if T is None:
+            check(self.lib.gpp_potrf(self.h, A.data_ptr(), A.shape[0], _ld(A), Linv.data_ptr(), _ld(Linv), info.data_ptr()),
+                  "gpp_potrf")
+        else:
+            check(self.lib.gpp_potrf_ws(self.h, A.data_ptr(), A.shape[0], _ld(A), Linv.data_ptr(), _ld(Linv), T.data_ptr(),
+                                        _ld(T), info.data_ptr()), "gpp_potrf_ws")
 
     def trtri(self, U, Linv, T):
         self._stream()

@@ -103,6 +103,47 @@ hipError_t potrf_rec(const Ctx& c, int64_t o, int64_t n) {
   return potrf_rec(c, o + n1, n2);
 }
 
+// ---- triangular inverse by pair merging -------------------------------------------------------------------------
+// One level: for the pairs of s-blocks [b, b+s), [b+s, min(b+2s, base+n)) of the range [base, base+n):
+//     T21 = U12^T Linv11 ;  Linv21 = -W22^T T21 (+ mirror).  ``skip(b)`` drops pairs that are already merged.
+template <typename Skip>
+hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt,
+                       int64_t base, int64_t n, int64_t s, Skip skip) {
+  const int64_t npairs_full = n / (2 * s);
+  const int64_t rem = n - npairs_full * 2 * s;  // leftover rows after the full pairs
+  auto launch = [&](int64_t o, int64_t m2, int batch) -> hipError_t {
+    const int64_t pstride_U = 2 * s * (ld + 1), pstride_I = 2 * s * (ldi + 1), pstride_T = 2 * s * (ldt + 1);
+    // T21 = U12^T * Linv11   (TN; U12 = U[o.., o+s..] is s x m2, Linv11 lower: keep k >= n)
+    GemmArgs g1 = mk(U + o * ld + (o + s), ld, Linv + o * ldi + o, ldi, T + (o + s) * ldt + o, ldt, m2, s, s, 1.0, 0.0);
+    g1.b_mask = 2; g1.klo_mode = 2; g1.col_major = 1;  // K range depends on the column tile: keep columns together
+    g1.sA = pstride_U; g1.sB = pstride_I; g1.sC = pstride_T;
+    hipError_t e = gpp_launch_gemm(st, 2, g1, batch);
+    if (e != hipSuccess) return e;
+    // Linv21 = -W22^T * T21  (TN; W22 = mirrored upper part of the (o+s) block: keep k <= m), plus its mirror
+    GemmArgs g2 = mk(Linv + (o + s) * ldi + (o + s), ldi, T + (o + s) * ldt + o, ldt, Linv + (o + s) * ldi + o, ldi, m2, s,
+                     m2, -1.0, 0.0);
+    g2.a_mask = 1; g2.khi_mode = 1; g2.row_reverse = 1;
+    g2.sA = pstride_I; g2.sB = pstride_T; g2.sC = pstride_I;
+    g2.C2 = Linv + o * ldi + (o + s); g2.ldc2 = ldi; g2.sC2 = pstride_I;
+    return gpp_launch_gemm(st, 2, g2, batch);
+  };
+  // full pairs: batched over maximal runs of pairs that still need merging
+  int64_t p = 0;
+  while (p < npairs_full) {
+    if (skip(base + 2 * s * p)) { ++p; continue; }
+    int64_t q = p;
+    while (q < npairs_full && !skip(base + 2 * s * q)) ++q;
+    hipError_t e = launch(base + 2 * s * p, s, (int)(q - p));
+    if (e != hipSuccess) return e;
+    p = q;
+  }
+  if (rem > s && !skip(base + npairs_full * 2 * s)) {  // ragged last pair (second block shorter than s)
+    hipError_t e = launch(base + npairs_full * 2 * s, rem - s, 1);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 // ---- look-ahead (right-looking) driver on two streams ----------------------------------------------------------
 // The recursive factorisation spends ~40 % of its time in latency-bound launches (128-block leaves, leaf trsm, small
 // updates) during which most of the 256 CUs idle.  For large N the outer level is therefore right-looking over block
@@ -169,7 +210,7 @@ inline hipEvent_t next_event(gpp_handle_s* h) {
 // panel stream : wait S(k-1); U_kk = potrf(A_kk) (recursive, narrow launches); record D(k)
 // update stream: wait D(k); U_k,k+1: = U_kk^-T A_k,k+1: (wide trsm); next block row of the trailing matrix -= ...;
 //                record S(k); rest of the trailing matrix -= ...
-hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB) {
+hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB, double* T, int64_t ldt) {
   HIP_TRY(ensure_streams(h));
   Ctx cp = cm, cu = cm;
   cp.s = h->panel_stream;
@@ -187,11 +228,33 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
     nb = std::min(want, N - o);
     const int64_t rem = N - o - nb;
     HIP_TRY(potrf_rec(cp, o, nb));
+    if (T) {
+      // complete inverse of this diagonal block, still on the panel stream (hidden behind the trailing update): it turns
+      // the wide trsm below into ONE GEMM and is exactly the low levels of gpp_trtri, which will skip them
+      for (int64_t s = NBLK; s < nb; s *= 2)
+        HIP_TRY(trtri_level(cp.s, cm.A, cm.ld, cm.Li, cm.ldi, T, ldt, o, nb, s, [](int64_t) { return false; }));
+      if (h->inv_nblocks < 128) {
+        h->inv_o[h->inv_nblocks] = o;
+        h->inv_n[h->inv_nblocks] = nb;
+        ++h->inv_nblocks;
+      }
+    }
     hipEvent_t D = next_event(h);
     HIP_TRY(hipEventRecord(D, cp.s));
     HIP_TRY(hipStreamWaitEvent(cu.s, D, 0));
     if (rem == 0) break;
-    HIP_TRY(trsm_rec(cu, o + nb, rem, o, nb));
+    if (T) {
+      // U12 = (inv(L_oo)^T)^T A12 = W_oo^T A12 : one TN GEMM (W_oo = mirror, keep i <= k) into the scratch, then copied
+      // over A12 (a GEMM with several row tiles cannot run in place)
+      GemmArgs gt = mk(cm.Li + o * cm.ldi + o, cm.ldi, cm.A + o * cm.ld + (o + nb), cm.ld, T + o * ldt + (o + nb), ldt, nb,
+                       rem, nb, 1.0, 0.0);
+      gt.a_mask = 1; gt.khi_mode = 1;
+      HIP_TRY(gpp_launch_gemm(cu.s, 2, gt, 1));
+      HIP_TRY(hipMemcpy2DAsync(cm.A + o * cm.ld + (o + nb), cm.ld * sizeof(double), T + o * ldt + (o + nb),
+                               ldt * sizeof(double), rem * sizeof(double), nb, hipMemcpyDeviceToDevice, cu.s));
+    } else {
+      HIP_TRY(trsm_rec(cu, o + nb, rem, o, nb));
+    }
     const int64_t want2 = (rem >= nb_thresh) ? nb_big : nb_small;
     const int64_t nb2 = std::min(want2, rem), rest = rem - nb2;
     const double* Urow = cm.A + o * cm.ld;  // block row o: U[o.., :]
@@ -252,6 +315,8 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->cu_split = -1;
   h->n_events = 0;
   h->ev_next = 0;
+  h->inv_N = 0;
+  h->inv_nblocks = 0;
   *out = h;
   return 0;
 }
@@ -328,17 +393,28 @@ int gpp_cross_kernel(gpp_handle_t h, const double* Ua, int64_t Ma, const double*
   return 0;
 }
 
-int gpp_potrf(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, int64_t ldi, int32_t* info_dev) {
+int gpp_potrf_ws(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt,
+                 int32_t* info_dev) {
   if (!h) return -1;
   if (N < 0) return -3;
   if (int r = check_mat(A, ld, N, 2)) return r;
   if (int r = check_mat(Linv, ldi, N, 5)) return r;
-  if (!info_dev) return -7;
+  if (T) {
+    if (int r = check_mat(T, ldt, N, 7)) return r;
+  }
+  if (!info_dev) return -9;
   GPP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int32_t), h->stream));
   Ctx c{h->stream, A, ld, Linv, ldi, info_dev};
-  if (N >= 4 * LOOKAHEAD_NB) GPP_TRY(potrf_lookahead(h, c, N, LOOKAHEAD_NB));
+  h->inv_N = N;
+  h->inv_nblocks = 0;
+  if (N >= 4 * LOOKAHEAD_NB) GPP_TRY(potrf_lookahead(h, c, N, LOOKAHEAD_NB, T, ldt));
   else GPP_TRY(potrf_rec(c, 0, N));
   return 0;
+}
+
+int gpp_potrf(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, int64_t ldi, int32_t* info_dev) {
+  const int r = gpp_potrf_ws(h, A, N, ld, Linv, ldi, nullptr, 0, info_dev);
+  return r == -9 ? -7 : r;
 }
 
 int gpp_trtri(gpp_handle_t h, const double* U, int64_t N, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt) {
@@ -347,35 +423,21 @@ int gpp_trtri(gpp_handle_t h, const double* U, int64_t N, int64_t ld, double* Li
   if (int r = check_mat(U, ld, N, 2)) return r;
   if (int r = check_mat(Linv, ldi, N, 5)) return r;
   if (int r = check_mat(T, ldt, N, 7)) return r;
+  // diagonal blocks already inverted by the preceding gpp_potrf_ws (same N): a pair inside one of them is done
+  const bool have = (h->inv_N == N && h->inv_nblocks > 0);
   for (int64_t s = NBLK; s < N; s *= 2) {
-    // pairs p: blocks [2ps, 2ps+s) and [2ps+s, min(2ps+2s, N)); full pairs batched, a ragged last pair on its own.
-    const int64_t npairs_full = N / (2 * s);
-    const int64_t rem = N - npairs_full * 2 * s;  // leftover rows after the full pairs
-    for (int pass = 0; pass < 2; ++pass) {
-      int64_t o, m2;
-      int batch;
-      if (pass == 0) {
-        if (npairs_full == 0) continue;
-        o = 0; m2 = s; batch = (int)npairs_full;
-      } else {
-        if (rem <= s) continue;  // no second block in the ragged pair
-        o = npairs_full * 2 * s; m2 = rem - s; batch = 1;
-      }
-      const int64_t pstride_U = 2 * s * (ld + 1), pstride_I = 2 * s * (ldi + 1), pstride_T = 2 * s * (ldt + 1);
-      // T21 = U12^T * Linv11   (TN; U12 = U[o.., o+s..] is s x m2, Linv11 lower: keep k >= n)
-      GemmArgs g1 = mk(U + o * ld + (o + s), ld, Linv + o * ldi + o, ldi, T + (o + s) * ldt + o, ldt, m2, s, s, 1.0, 0.0);
-      g1.b_mask = 2; g1.klo_mode = 2; g1.col_major = 1;  // K range depends on the column tile: keep columns together
-      g1.sA = pstride_U; g1.sB = pstride_I; g1.sC = pstride_T;
-      GPP_TRY(gpp_launch_gemm(h->stream, 2, g1, batch));
-      // Linv21 = -W22^T * T21  (TN; W22 = mirrored upper part of the (o+s) block: keep k <= m), plus its mirror
-      GemmArgs g2 = mk(Linv + (o + s) * ldi + (o + s), ldi, T + (o + s) * ldt + o, ldt, Linv + (o + s) * ldi + o, ldi, m2,
-                       s, m2, -1.0, 0.0);
-      g2.a_mask = 1; g2.khi_mode = 1; g2.row_reverse = 1;
-      g2.sA = pstride_I; g2.sB = pstride_T; g2.sC = pstride_I;
-      g2.C2 = Linv + o * ldi + (o + s); g2.ldc2 = ldi; g2.sC2 = pstride_I;
-      GPP_TRY(gpp_launch_gemm(h->stream, 2, g2, batch));
-    }
+    auto skip = [&](int64_t b) {
+      if (!have) return false;
+      for (int i = 0; i < h->inv_nblocks; ++i)
+        if (b >= h->inv_o[i] && b + 2 * s <= h->inv_o[i] + h->inv_n[i]) return true;
+      // a ragged pair [b, N) inside the last block
+      for (int i = 0; i < h->inv_nblocks; ++i)
+        if (b >= h->inv_o[i] && h->inv_o[i] + h->inv_n[i] == N && b + s < N) return true;
+      return false;
+    };
+    GPP_TRY(trtri_level(h->stream, U, ld, Linv, ldi, T, ldt, 0, N, s, skip));
   }
+  h->inv_N = 0;  // consumed
   return 0;
 }
 

@@ -16,6 +16,11 @@ struct gpp_handle_s {
   int cu_split;              // 1: the two streams own disjoint CU sets (CU masks), 0: plain priority streams, -1: unknown
   hipEvent_t events[16];     // ring of timing-disabled events for the two-stream hand-offs (lazy)
   int n_events, ev_next;
+  // diagonal blocks whose inverse the last gpp_potrf_ws call completed (look-ahead path with scratch): gpp_trtri
+  // skips the pair merges that lie inside one of them
+  int64_t inv_N;             // N of that factorisation (0: nothing recorded)
+  int inv_nblocks;
+  int64_t inv_o[128], inv_n[128];
 };
 
 // ---- fp64 MFMA GEMM (gpp_gemm.hip) ------------------------------------------------------------

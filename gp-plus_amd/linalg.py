@@ -122,7 +122,7 @@ def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_spl
         with _stage("kernel_build"):
             ctx.kernel_build(U, w, sf2, tau, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_UPPER)
         with _stage("potrf"):
-            ctx.potrf(ws.A, ws.Li, ws.info)
+            ctx.potrf(ws.A, ws.Li, ws.info, ws.Ki)
         info = int(ws.info.item())  # the one host sync of an evaluation (the reference syncs on loss.item() too)
         if info == 0:
             if jit > 0:
@@ -171,7 +171,7 @@ class ExactMLLFunction(torch.autograd.Function):
             # another forward reused the buffers: rebuild this evaluation's factors (correct, costs one extra potrf)
             ws.epoch += 1
             gctx.kernel_build(Ud, wd, sd, td, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_UPPER)
-            gctx.potrf(ws.A, ws.Li, ws.info)
+            gctx.potrf(ws.A, ws.Li, ws.info, ws.Ki)
             gctx.trtri(ws.A, ws.Li, ws.Ki)
             ws.r.copy_(r_saved)
             gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)

@@ -81,6 +81,11 @@ int gpp_cross_kernel(gpp_handle_t h, const double* Ua, int64_t Ma, const double*
  * inv(L_bb)^T (upper), as gpp_trtri needs them.
  */
 int gpp_potrf(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, int64_t ldi, int32_t* info_dev);
+/* Same, with an N x N scratch T (may be the Kinv buffer): for large N the look-ahead driver then also completes the
+ * inverse of every diagonal block row it factors (hidden behind the trailing updates) and uses it to solve each wide
+ * block-row panel with ONE GEMM; the following gpp_trtri on the same handle skips the merges that are already done. */
+int gpp_potrf_ws(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt,
+                 int32_t* info_dev);
 
 /* Completes Linv = inv(L) (lower triangle, mirrored into the upper) from the diagonal-block inverses left by
  * gpp_potrf.  `U` is the factored matrix (upper).  T (N x N) is scratch. */

@@ -115,13 +115,16 @@ def test_kernel_build_and_cross(gpu_ctx, n, d):
     np.testing.assert_allclose(cross.cpu().numpy(), sf2 * np.exp(-d2c), rtol=1e-13, atol=1e-15)
 
 
-@pytest.mark.parametrize("n", [1, 5, 128, 129, 300, 777, 2048, 4097])
-def test_potrf_trtri_lauum(gpu_ctx, n):
+@pytest.mark.parametrize("n,use_ws", [(1, False), (5, True), (128, False), (129, True), (300, False), (777, True),
+                                      (2048, True), (4097, False), (4097, True), (6700, True)])
+def test_potrf_trtri_lauum(gpu_ctx, n, use_ws):
+    """use_ws: pass the scratch to the factorisation (look-ahead path for n >= 4096 then inverts its diagonal block rows
+    itself, solves panels with one GEMM and lets trtri skip the merged levels)."""
     U, w, K = _spd(n, seed=n)
     A, Li, T, Ki = _sq(n), _sq(n), _sq(n), _sq(n)
     A.copy_(_dev(np.triu(K) + np.tril(np.full((n, n), np.nan), -1)))  # the strict lower triangle must never be read
     info = torch.full((1,), -1, dtype=torch.int32, device="cuda")
-    gpu_ctx.potrf(A, Li, info)
+    gpu_ctx.potrf(A, Li, info, T if use_ws else None)
     assert int(info.item()) == 0
     Lref = np.linalg.cholesky(K)
     Ufac = np.triu(A.cpu().numpy())

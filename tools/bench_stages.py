@@ -24,8 +24,8 @@ def main():
     gt = torch.empty(1, dtype=torch.float64, device="cuda")
     stages = {
         "build": lambda: ctx.kernel_build(U, w, sf2, tau, None, A, uplo=2),
-        "potrf": lambda: ctx.potrf(A, Li, info),
-        "trtri": lambda: ctx.trtri(A, Li, T),
+        "potrf": lambda: ctx.potrf(A, Li, info, Ki if len(sys.argv) <= 4 else None),
+        "trtri": lambda: ctx.trtri(A, Li, Ki),
         "mll_reduce": lambda: ctx.mll_reduce(A, Li, r, z, out3),
         "alpha": lambda: ctx.alpha(Li, z, al),
         "lauum": lambda: ctx.lauum(Li, Ki),
