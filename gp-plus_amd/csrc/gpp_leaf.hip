@@ -1,7 +1,8 @@
 // gpp_leaf.hip — diagonal leaf of the recursive Cholesky: factor an n x n (n <= 128) SPD block and invert its
 // factor inside ONE work-group, with the block held in MFMA accumulator registers and LDS.  Replaces the unblocked
 // LAPACK potf2/trti2 steps inside torch.linalg.cholesky_ex (reference call site: gpytorch psd_safe_cholesky reached
-// from optim/mll_torch.py:116).  It sits on the critical path N/128 times per factorisation, so it is latency-tuned.
+// from optim/mll_torch.py:116).  It runs N/128 times per factorisation on a latency-bound chain, so it is latency-tuned
+// (tools/leaf_probe.hip prints its per-phase cycle counts).
 //
 //   in : A[n x n], UPPER triangle read (A = U^T U with U stored row-major = L stored column-major; the strict lower
 //        triangle is never touched).  Internally the kernel works on L = U^T: every access to A swaps its indices.
@@ -10,58 +11,264 @@
 //        *info <- row_offset + k + 1 for the first non-positive / NaN pivot (kept if already non-zero)
 //
 // Layout: the 128 x 128 block is an 8 x 8 grid of 16 x 16 tiles; the 36 lower tiles are dealt to the 4 waves
-// (9 accumulator tiles = 72 VGPRs each, v_mfma_f64_16x16x4_f64 C/D layout).  Right-looking over tile columns s:
-//   (1) owners park column s in LDS;  (2) wave 0 factors the 16 x 16 diagonal tile and inverts it with lane-per-row
-//   registers and v_readlane broadcasts (no LDS round trips inside the 16 sequential pivots);  (3) panel tiles
-//   become L(i,s) = raw(i,s) * inv(L_ss)^T on the MFMA;  (4) trailing tiles acc(i,j) -= L(i,s) L(j,s)^T on the MFMA.
-// The inverse is then assembled by pair merging at tile level (sizes 16, 32, 64): X21 = -X22 (L21 X11), MFMA again.
+// (9 accumulator tiles = 72 VGPRs each, C/D layout row = (l>>4) + 4r, col = l&15).  Right-looking over tile columns s:
+//   (1) owners park column s in LDS;
+//   (2) wave 0 factors the 16 x 16 diagonal tile with lane-per-row registers and v_readlane broadcasts and leaves it in
+//       LDS with its diagonal replaced by the reciprocals 1/L_cc;
+//   (3) panel rows are solved by forward substitution, one lane per row, against broadcast LDS reads of that tile
+//       (no 16 x 16 inverse on the critical path);
+//   (4) trailing tiles acc(i,j) -= L(i,s) L(j,s)^T on the MFMA (four v_mfma_f64_4x4x4_4b per 16x16x4 step: they issue
+//       every 16 cycles on gfx950, v_mfma_f64_16x16x4 only every ~138, tools/mfma_probe.hip).
+// Then the 8 diagonal tiles are inverted in parallel (2 per wave, lane per column) and the inverse is assembled by
+// pair merging at tile level (sizes 16, 32, 64): X21 = -X22 (L21 X11), MFMA again.
 #include "gpp_internal.h"
 
 typedef double v4d __attribute__((ext_vector_type(4)));
+typedef double v2d __attribute__((ext_vector_type(2)));
+
+// Phase stamps for tools/leaf_probe.hip only (the product build defines nothing and the macro vanishes).
+#ifdef GPP_LEAF_STAMP
+__device__ unsigned long long g_leaf_stamps[64];
+#define STAMP(i)                                                                   \
+  do {                                                                             \
+    if (threadIdx.x == 0) g_leaf_stamps[(i)] = __builtin_amdgcn_s_memtime();       \
+  } while (0)
+#else
+#define STAMP(i) \
+  do {           \
+  } while (0)
+#endif
 
 namespace {
 
 constexpr int NB = GPP_TILE;
-constexpr int TSZ = 16 * 16;       // doubles per LDS tile (unpadded: the whole image must fit ONE GEMM LDS slot)
-constexpr int NT = 36;             // lower tiles of an 8x8 grid
-constexpr int SLOTS = 9;           // tiles per wave
+constexpr int TSZ = 16 * 16;  // doubles per LDS tile (unpadded: the whole image must fit ONE GEMM LDS slot)
+constexpr int NT = 36;        // lower tiles of an 8x8 grid
+constexpr int SLOTS = 9;      // tiles per wave
 
 __device__ __forceinline__ int toff(int i, int j) { return (i * (i + 1) / 2 + j) * TSZ; }
-
-__device__ __forceinline__ double readlane_d(double v, int lane) {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_readlane(lo, lane);
-  hi = __builtin_amdgcn_readlane(hi, lane);
-  return __hiloint2double(hi, lo);
-}
 
 // Element (row, col) of a 16 x 16 LDS tile.  Rows are 128 bytes; the XOR swizzle (col ^ row>>1) spreads a column
 // read (16 rows, same col) over 16 distinct 8-byte bank slots without padding the tile.
 __device__ __forceinline__ int tix(int row, int col) { return row * 16 + (col ^ (row >> 1)); }
 
-// A-operand fragment of tile[m][k] (also the B operand of an "X * tile^T" product): lane (m = l&15, k = k0 + l>>4)
-__device__ __forceinline__ double frag_rk(const double* tile, int k0, int lane) {
-  return tile[tix(lane & 15, k0 + (lane >> 4))];
+// Broadcast lane J of every 16-lane row (gfx90a+ DPP row_newbcast, the only DPP mode of the fp64 ALU).
+template <int J>
+__device__ __forceinline__ double bcast16(double v) {
+  return __builtin_amdgcn_update_dpp(0.0, v, 0x150 + J, 0xf, 0xf, false);
 }
-// B-operand fragment of tile[k][n]: lane (n = l&15, k = k0 + l>>4)
-__device__ __forceinline__ double frag_kn(const double* tile, int k0, int lane) {
-  return tile[tix(k0 + (lane >> 4), lane & 15)];
+// acc -= bcast16<J>(l) * m in ONE instruction (v_fmac_f64 with a DPP source).  The s_nop covers the two wait states
+// a DPP read needs after a VALU write of its source, which the compiler does not track through inline asm.
+template <int J>
+__device__ __forceinline__ void fnma_bcast16(double& acc, double l, double m) {
+  asm("s_nop 1\n\tv_fmac_f64_dpp %0, -%1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+      : "+v"(acc)
+      : "v"(l), "v"(m), "n"(J));
 }
-__device__ __forceinline__ void store_acc(double* tile, const v4d& a, int lane) {
+
+// Per-lane element offsets inside a tile for the three MFMA fragment shapes, swizzle folded in so that every LDS read
+// is "tile base + lane offset + immediate".  With lr = lane>>4, lc = lane&15, i = lane&3:
+//  A operand of v_mfma_f64_4x4x4_4b (rows 4rb+i, k = 4kk+lr; same 4x4 block in all four lane groups = LDS broadcast):
+//      tix = a[rb&1] + 64 rb + (4kk ^ 4(rb>>1))
+//  B operand "tile^T" (n = lc, k = 4kk+lr reads tile[n][k]):      tix = rk[kk&1] + 8 (kk>>1)
+//  B operand "tile"   (k = 4kk+lr, n = lc reads tile[k][n]) and the C/D layout (row lr+4r, col lc): tix = kn[kk]
+struct LaneOff {
+  int a[2], rk[2], kn[4];
+};
+__device__ __forceinline__ LaneOff lane_offsets(int lane) {
+  const int lr = lane >> 4, lc = lane & 15, i = lane & 3;
+  LaneOff o;
+  o.a[0] = 16 * i + (lr ^ (i >> 1));
+  o.a[1] = 16 * i + (lr ^ (2 + (i >> 1)));
+  const int m = (lc >> 1) & 4, base = 16 * lc + (lr ^ ((lc >> 1) & 3));
+  o.rk[0] = base + m;
+  o.rk[1] = base + (4 ^ m);
 #pragma unroll
-  for (int r = 0; r < 4; ++r) tile[tix((lane >> 4) + 4 * r, lane & 15)] = a[r];
+  for (int kk = 0; kk < 4; ++kk) o.kn[kk] = 64 * kk + 16 * lr + ((lc ^ (lr >> 1)) ^ (2 * kk));
+  return o;
+}
+
+// Operand fragments of one 16 x 16 x 16 tile product acc += At * B on the MFMA.  All 20 LDS reads of a product are
+// requested together, and the callers request the NEXT product's fragments before issuing this one's 16 MFMAs, so the
+// LDS latency hides behind the matrix pipe instead of preceding every instruction.
+struct Frag {
+  double a[4][4];  // [kk][rb]: rows 4rb + (l&3), k = 4kk + (l>>4) of At
+  double b[4];     // [kk]: B[k = 4kk + (l>>4)][n = l&15]
+};
+// KN: B is stored [k][n] (merge products);  !KN: B is stored [n][k], i.e. the product is At * Bt^T (trailing update)
+template <bool NEG, bool KN>
+__device__ __forceinline__ void load_frag(Frag& f, const double* At, const double* Bt, const LaneOff& o) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const double v = KN ? Bt[o.kn[kk]] : Bt[o.rk[kk & 1] + 8 * (kk >> 1)];
+    f.b[kk] = NEG ? -v : v;
+  }
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) f.a[kk][rb] = At[o.a[rb & 1] + 64 * rb + ((4 * kk) ^ (4 * (rb >> 1)))];
+}
+__device__ __forceinline__ void mma_frag(v4d& acc, const Frag& f) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(f.a[kk][rb], f.b[kk], acc[rb], 0, 0, 0);
+}
+// t += sgn * sum_{k=k0}^{k1} tile(i,k) * tile(k,j)   (k1 >= k0), double-buffered over k
+template <bool NEG>
+__device__ __forceinline__ void tile_chain(v4d& t, const double* img, int i, int j, int k0, int k1, const LaneOff& o) {
+  Frag f0, f1;
+  int k = k0;
+  load_frag<NEG, true>(f0, img + toff(i, k), img + toff(k, j), o);
+  // every "request next, multiply current" pair sits in ONE basic block: the compiler's s_waitcnt bookkeeping is only
+  // exact inside a block, and a conservative wait at a join would serialise the LDS reads and the MFMAs again
+  while (true) {
+    if (k == k1) {
+      mma_frag(t, f0);
+      break;
+    }
+    load_frag<NEG, true>(f1, img + toff(i, k + 1), img + toff(k + 1, j), o);
+    mma_frag(t, f0);
+    ++k;
+    if (k == k1) {
+      mma_frag(t, f1);
+      break;
+    }
+    load_frag<NEG, true>(f0, img + toff(i, k + 1), img + toff(k + 1, j), o);
+    mma_frag(t, f1);
+    ++k;
+  }
+}
+
+__device__ __forceinline__ void store_acc(double* tile, const v4d& a, const LaneOff& o) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) tile[o.kn[r]] = a[r];
+}
+
+// Right-looking Cholesky of the 16 x 16 tile held one row per lane (a[c] = row (lane&15), column c), pivot K.
+template <int K, int J>
+__device__ __forceinline__ void chol_update(double (&a)[16], double l) {
+  if constexpr (J < 16) {
+    fnma_bcast16<J>(a[J], l, l);  // a[J] -= L[J][K] * L[i][K]
+    chol_update<K, J + 1>(a, l);
+  }
+}
+template <int K>
+__device__ __forceinline__ void chol_pivots(double (&a)[16], double& rd, int i, int& bad) {
+  if constexpr (K < 16) {
+    const double akk = bcast16<K>(a[K]);
+    // Off the dependency chain: a non-positive or NaN pivot only raises the flag; the NaNs it breeds are never used
+    // because the caller retries with jitter when *info != 0 (gp-plus_amd/linalg.py::_factor).
+    if (!(akk > 0.0) && !bad) bad = K + 1;
+    // 1/sqrt(pivot) by hardware rsq + two Newton steps, L_KK = pivot * r: a far shorter dependency chain than sqrt
+    // followed by a division, and this chain runs 128 times per leaf
+    double r = __builtin_amdgcn_rsq(akk);
+    r = fma(r * 0.5, fma(-akk * r, r, 1.0), r);
+    r = fma(r * 0.5, fma(-akk * r, r, 1.0), r);
+    const double l = (i == K) ? akk * r : a[K] * r;
+    a[K] = l;
+    rd = (i == K) ? r : rd;
+    chol_update<K, K + 1>(a, l);
+    chol_pivots<K + 1>(a, rd, i, bad);
+  }
+}
+
+// One level of the pair-merge inversion: diagonal blocks of H tiles are already inverted; for every pair (based at
+// tile b = 2H p) the off-diagonal block becomes X21 = -X22 (L21 X11).  4H output tiles, dealt to the 4 waves so that
+// each wave gets the same number of tile products in both phases.
+template <int H>
+__device__ __forceinline__ void merge_level(double* img, int wave, const LaneOff& o) {
+  constexpr int NTILE = 4 * H, PER = (NTILE + 3) / 4;
+  int ti[PER], tj[PER], tb[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int e = wave + 4 * q, p = e / (H * H), rem = e % (H * H), r = rem / H;
+    tb[q] = 2 * H * p;
+    ti[q] = tb[q] + H + r;
+    tj[q] = tb[q] + (rem % H + r) % H;  // rotate the columns so a wave's tiles have different product counts
+  }
+  v4d t[PER];
+  // phase a: T(i,j) = sum_{k=j}^{b+H-1} L(i,k) X(k,j)
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    t[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (wave + 4 * q < NTILE) tile_chain<false>(t[q], img, ti[q], tj[q], tj[q], tb[q] + H - 1, o);
+  }
+  __syncthreads();  // every L(i,k) of this level has been read: the slots may now take T
+#pragma unroll
+  for (int q = 0; q < PER; ++q)
+    if (wave + 4 * q < NTILE) store_acc(img + toff(ti[q], tj[q]), t[q], o);
+  __syncthreads();
+  // phase b: X(i,j) = -sum_{k=b+H}^{i} X(i,k) T(k,j)
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    t[q] = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (wave + 4 * q < NTILE) tile_chain<true>(t[q], img, ti[q], tj[q], tb[q] + H, ti[q], o);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < PER; ++q)
+    if (wave + 4 * q < NTILE) store_acc(img + toff(ti[q], tj[q]), t[q], o);
+  __syncthreads();
+}
+
+// Rows 16s .. 16s+15 of U (= columns of L, strictly below the diagonal; the diagonal itself is stored by the factoring
+// wave) from the LDS image to memory: U[16s+c][j] = L[j][16s+c] for j > 16s+c.  Work item e = (row c, 64-column half),
+// dealt round-robin to `nw` waves; a lane owns one column j, so every store is a contiguous run of a U row.
+__device__ __forceinline__ void write_u_rows(double* __restrict__ A, int64_t lda, int n, int s, int w, int nw, int lane) {
+  extern __shared__ __attribute__((aligned(16))) double img[];
+  const int halves = (s < 4) ? 2 : 1;  // columns 16s .. 127: more than 64 of them only while s < 4
+  for (int e = w; e < 16 * halves; e += nw) {
+    const int c = e & 15, j = 16 * s + 64 * (e >> 4) + lane;
+    if (j < n && j > 16 * s + c) A[(int64_t)(16 * s + c) * lda + j] = img[toff(j >> 4, s) + tix(j & 15, c)];
+  }
+}
+
+// 64 x 64 block (rows r0.., columns c0..) of the result from the LDS image to memory: inv(L) where col <= row, its
+// transpose above the diagonal.  A lane owns two consecutive columns (one 16-byte store), half a wave one row, and
+// each wave keeps four row pairs in flight.
+__device__ __forceinline__ void write_linv_block(double* __restrict__ Linv, int64_t ldi, int n, int r0, int c0, int wave,
+                                                 int lane) {
+  extern __shared__ __attribute__((aligned(16))) double img[];
+  const int col = c0 + 2 * (lane & 31), J = col >> 4, cc = col & 15;  // column tile, (even) column inside it
+  const int triJ = J * (J + 1) / 2;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    double v[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = r0 + 32 * pass + 8 * u + 2 * wave + (lane >> 5);
+      const int I = row >> 4, rr = row & 15;
+      const int lo_base = (I * (I + 1) / 2 + J) * TSZ + rr * 16, hi_base = (triJ + I) * TSZ + (rr ^ (cc >> 1));
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int c = cc + e;
+        const bool lower = (J < I) || (J == I && c <= rr);
+        v[u][e] = img[lower ? lo_base + (c ^ (rr >> 1)) : hi_base + c * 16];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int row = r0 + 32 * pass + 8 * u + 2 * wave + (lane >> 5);
+      double* dst = Linv + (int64_t)row * ldi + col;
+      if (row < n && col + 1 < n) *reinterpret_cast<v2d*>(dst) = (v2d){v[u][0], v[u][1]};
+      else if (row < n && col < n) dst[0] = v[u][0];
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
                                                           int64_t ldi, int n, int32_t* info, int row_offset) {
   // ONE 36-tile image of exactly 72 KiB: LDS is allocated contiguously, so on the look-ahead stream the leaf can only
-  // start beside a running GEMM work-group if it fits the 72.5 KiB slot a finished GEMM work-group leaves behind.  Slot (i,j) holds, in turn: the parked raw tile, L(i,j) (off-diagonal) or inv(L_jj) (diagonal),
-  // and finally inv(L)(i,j): L(i,j) is consumed exactly at the merge level that overwrites it.
-  extern __shared__ __attribute__((aligned(16))) double lds[];
-  double* Limg = lds;
-  double* Ximg = lds;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // start beside a running GEMM work-group if it fits the 72.5 KiB slot a finished GEMM work-group leaves behind.
+  // Slot (i,j) holds, in turn: the parked raw tile; L(i,j) (off-diagonal) or L_jj with its diagonal replaced by the
+  // reciprocals 1/L_cc (diagonal); and finally inv(L)(i,j): L(i,j) is consumed exactly at the merge level that
+  // overwrites it.
+  extern __shared__ __attribute__((aligned(16))) double img[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane >> 4, lc = lane & 15;
+  const LaneOff off = lane_offsets(lane);
 
   // tile ownership: lower tiles enumerated column-major (j outer), dealt round-robin to the 4 waves
   int ti[SLOTS], tj[SLOTS];
@@ -87,170 +294,122 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
     }
   }
 
+  STAMP(0);
   for (int s = 0; s < 8; ++s) {
+    STAMP(1 + 5 * s);
     // (1) park column s
 #pragma unroll
     for (int q = 0; q < SLOTS; ++q)
-      if (tj[q] == s) store_acc(Limg + toff(ti[q], s), acc[q], lane);
+      if (tj[q] == s) store_acc(img + toff(ti[q], s), acc[q], off);
     __syncthreads();
 
-    // (2) wave 0: factor + invert the diagonal tile.  lane (l & 15) owns row i of L and column i of X.
+    STAMP(2 + 5 * s);
+    double* D = img + toff(s, s);
+    // (2) wave 0: factor the diagonal tile.  lane (l & 15) owns row i; the four 16-lane rows of the wave carry
+    // identical copies, so the row_newbcast broadcasts need no cross-row traffic.
     if (wave == 0) {
-      double* D = Limg + toff(s, s);
       const int i = lc;
-      double a[16], x[16], rd[16];
+      double a[16], rd = 0.0;
 #pragma unroll
       for (int c = 0; c < 16; ++c) a[c] = D[tix(i, c)];
       int bad = 0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        double akk = readlane_d(a[k], k);
-        if (!(akk > 0.0)) {
-          if (!bad) bad = k + 1;
-          akk = 1.0;
-        }
-        const double d = sqrt(akk);
-        const double r = 1.0 / d;
-        rd[k] = r;
-        const double l = (i == k) ? d : a[k] * r;
-        a[k] = l;
-#pragma unroll
-        for (int j = k + 1; j < 16; ++j) {
-          const double ljk = readlane_d(l, j);
-          a[j] = fma(-l, ljk, a[j]);
-        }
-      }
+      chol_pivots<0>(a, rd, i, bad);
       if (bad && lane == 0) atomicCAS(info, 0, row_offset + 16 * s + bad);
-      // X = inv(L): lane owns column i;  x[r] = (delta - sum_{k<r} L[r][k] x[k]) / L[r][r]
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        double sacc = (r == i) ? 1.0 : 0.0;
-#pragma unroll
-        for (int k = 0; k < r; ++k) {
-          const double lrk = readlane_d(a[k], r);
-          sacc = fma(-lrk, x[k], sacc);
-        }
-        x[r] = sacc * rd[r];
-      }
       if (lane < 16) {
-        const int grow = 16 * s + i;
-        double* Xd = Ximg + toff(s, s);  // == D: the raw diagonal tile was read into registers above
+        // LDS copy: strict lower L, 1/L_ii on the diagonal (what the substitutions multiply by); the upper part is
+        // never read.  Only the diagonal of U goes to memory from here (one store): the rest of the tile is written
+        // from LDS by the waves that idle during the next factorisation.
 #pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          const double lv = (c <= i) ? a[c] : 0.0;
-          Xd[tix(c, i)] = x[c];  // X[c][i]
-          if (grow < n && c <= i) A[(int64_t)(16 * s + c) * lda + grow] = lv;  // U[col][row] = L[row][col]
-        }
+        for (int c = 0; c < 16; ++c) D[tix(i, c)] = (c == i) ? rd : a[c];
+        double lii = a[0];
+#pragma unroll
+        for (int c = 1; c < 16; ++c) lii = (c == i) ? a[c] : lii;
+        const int g = 16 * s + i;
+        if (g < n) A[(int64_t)g * lda + g] = lii;
       }
+    } else if (s > 0) {
+      write_u_rows(A, lda, n, s - 1, wave - 1, 3, lane);
+    }
+    STAMP(3 + 5 * s);
+    __syncthreads();
+
+    STAMP(4 + 5 * s);
+    // (3) panel: row R of the block (one lane per row) solves x L_ss^T = b by forward substitution, right-looking so
+    // that the updates of one column are independent instructions
+    if (tid < NB && tid >= 16 * (s + 1)) {
+      const int R = tid;
+      double* P = img + toff(R >> 4, s);
+      double x[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) x[c] = P[tix(R & 15, c)];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        x[c] *= D[tix(c, c)];
+#pragma unroll
+        for (int q = c + 1; q < 16; ++q) x[q] = fma(-x[c], D[tix(q, c)], x[q]);
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) P[tix(R & 15, c)] = x[c];
     }
     __syncthreads();
 
-    // (3) panel: L(i,s) = raw(i,s) * X_ss^T
+    STAMP(5 + 5 * s);
+    // (4) trailing update acc(i,j) -= L(i,s) L(j,s)^T; a wave's tiles of columns > s are its slots q0 .. 8 (column-major
+    // deal), fragments of slot q+1 are requested before the MFMAs of slot q
+    // (slots are sorted by column, so "slot q is active" implies "slot q+1 is active")
     {
-      const double* Xd = Ximg + toff(s, s);
-      double bx[4];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) bx[kk] = frag_rk(Xd, 4 * kk, lane);
+      Frag f[2];
+      if (tj[0] > s) load_frag<true, false>(f[0], img + toff(ti[0], s), img + toff(tj[0], s), off);
 #pragma unroll
       for (int q = 0; q < SLOTS; ++q) {
-        if (tj[q] == s && ti[q] > s) {
-          double* P = Limg + toff(ti[q], s);
-          v4d o = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) o = __builtin_amdgcn_mfma_f64_16x16x4f64(frag_rk(P, 4 * kk, lane), bx[kk], o, 0, 0, 0);
-          store_acc(P, o, lane);
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * ti[q] + lr + 4 * r;
-            if (row < n) A[(int64_t)(16 * s + lc) * lda + row] = o[r];  // U[col][row] = L[row][col]
-          }
+        constexpr int LAST = SLOTS - 1;
+        const int qn = q < LAST ? q + 1 : LAST;
+        if (tj[q] > s) {  // request slot q+1, multiply slot q: one basic block (see tile_chain)
+          if (q < LAST) load_frag<true, false>(f[qn & 1], img + toff(ti[qn], s), img + toff(tj[qn], s), off);
+          mma_frag(acc[q], f[q & 1]);
+        } else if (q < LAST && tj[qn] > s) {
+          load_frag<true, false>(f[qn & 1], img + toff(ti[qn], s), img + toff(tj[qn], s), off);
         }
       }
     }
-    __syncthreads();
-
-    // (4) trailing update
-#pragma unroll
-    for (int q = 0; q < SLOTS; ++q) {
-      if (tj[q] > s) {
-        const double* Pi = Limg + toff(ti[q], s);
-        const double* Pj = Limg + toff(tj[q], s);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag_rk(Pi, 4 * kk, lane), frag_rk(Pj, 4 * kk, lane), acc[q], 0, 0, 0);
-      }
-    }
   }
+  write_u_rows(A, lda, n, 7, wave, 4, lane);
   __syncthreads();
 
-  // ---- inverse by pair merging: half-size h tiles, pairs based at b = 2h*p -------------------------------
-  for (int h = 1; h <= 4; h <<= 1) {
-    const int ntile = 4 * h;  // output tiles at this level
-    v4d t[4];
-    // phase a: T(i,j) = sum_{k=j}^{b+h-1} L(i,k) X(k,j)
+  STAMP(41);
+  // ---- inverse of the 8 diagonal tiles, two per wave (lane groups 0 and 1), lane per column ---------------------
+  if (lr < 2) {
+    double* Dt = img + toff(wave + 4 * lr, wave + 4 * lr);
+    const int j = lc;
+    double x[16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = wave + 4 * q;
-      t[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-      if (e < ntile) {
-        const int p = e / (h * h), rem = e - p * h * h;
-        const int b = 2 * h * p, i = b + h + rem / h, j = b + rem % h;
-        for (int k = j; k < b + h; ++k) {
-          const double* Lt = Limg + toff(i, k);
-          const double* Xt = Ximg + toff(k, j);
+    for (int r = 0; r < 16; ++r) x[r] = (r == j) ? 1.0 : 0.0;
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
-            t[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(frag_rk(Lt, 4 * kk, lane), frag_kn(Xt, 4 * kk, lane), t[q], 0, 0, 0);
-        }
-      }
+    for (int r = 0; r < 16; ++r) {
+      x[r] *= Dt[tix(r, r)];
+#pragma unroll
+      for (int k = r + 1; k < 16; ++k) x[k] = fma(-Dt[tix(k, r)], x[r], x[k]);
     }
-    __syncthreads();  // every L(i,k) of this level has been read: the slots may now take T
+    // every lane of the wave has finished reading its tile before any of them overwrites it (one wave, in order)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = wave + 4 * q;
-      if (e < ntile) {
-        const int p = e / (h * h), rem = e - p * h * h;
-        const int b = 2 * h * p, i = b + h + rem / h, j = b + rem % h;
-        store_acc(Ximg + toff(i, j), t[q], lane);
-      }
-    }
-    __syncthreads();
-    // phase b: X(i,j) = -sum_{k=b+h}^{i} X(i,k) T(k,j)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = wave + 4 * q;
-      t[q] = (v4d){0.0, 0.0, 0.0, 0.0};
-      if (e < ntile) {
-        const int p = e / (h * h), rem = e - p * h * h;
-        const int b = 2 * h * p, i = b + h + rem / h, j = b + rem % h;
-        for (int k = b + h; k <= i; ++k) {
-          const double* Xa = Ximg + toff(i, k);
-          const double* Tt = Ximg + toff(k, j);
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk)
-            t[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(-frag_rk(Xa, 4 * kk, lane), frag_kn(Tt, 4 * kk, lane), t[q], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = wave + 4 * q;
-      if (e < ntile) {
-        const int p = e / (h * h), rem = e - p * h * h;
-        const int b = 2 * h * p, i = b + h + rem / h, j = b + rem % h;
-        store_acc(Ximg + toff(i, j), t[q], lane);
-      }
-    }
-    __syncthreads();
+    for (int r = 0; r < 16; ++r) Dt[tix(r, j)] = x[r];
   }
+  __syncthreads();
+  STAMP(44);
 
-  // write inv(L) into the lower triangle of the block and its transpose into the strict upper triangle
-  for (int e = tid; e < n * n; e += 256) {
-    const int row = e / n, col = e - row * n;
-    const int hi = row > col ? row : col, lo = row > col ? col : row;
-    Linv[(int64_t)row * ldi + col] = Ximg[toff(hi >> 4, lo >> 4) + tix(hi & 15, lo & 15)];
-  }
+  // ---- pair merging at tile level: 16 -> 32 -> 64 -> 128 ------------------------------------------------------------
+  merge_level<1>(img, wave, off);
+  merge_level<2>(img, wave, off);
+  // the two 64 x 64 diagonal blocks of the result are final: their stores drain behind the last level's MFMAs (a
+  // single CU moves the 128 KiB result at only ~16 B/clk, so unhidden it is 8% of the kernel)
+  write_linv_block(Linv, ldi, n, 0, 0, wave, lane);
+  write_linv_block(Linv, ldi, n, 64, 64, wave, lane);
+  merge_level<4>(img, wave, off);
+
+  STAMP(42);
+  write_linv_block(Linv, ldi, n, 64, 0, wave, lane);
+  write_linv_block(Linv, ldi, n, 0, 64, wave, lane);
+  STAMP(43);
 }
 
 }  // namespace
