@@ -155,7 +155,7 @@ hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv
 // (single work-group, 72 KiB LDS) leaf of the next panel until the update drains (measured: the leaf "ran" for 5.8 ms).
 // So the two internal streams get DISJOINT CU sets through CU masks: PANEL_CUS compute units run the latency-bound
 // diagonal-block factorisations, the remaining ones the wide trsm and trailing updates.
-constexpr int PANEL_CUS = 16;
+constexpr int PANEL_CUS_DEFAULT = 16;
 hipError_t ensure_streams(gpp_handle_s* h) {
   if (h->cu_split < 0) {
     hipDeviceProp_t prop;
@@ -163,6 +163,8 @@ hipError_t ensure_streams(gpp_handle_s* h) {
     if (e != hipSuccess) return e;
     const int ncu = prop.multiProcessorCount;
     h->cu_split = 0;
+    int PANEL_CUS = PANEL_CUS_DEFAULT;
+    if (const char* e = getenv("GPP_PANEL_CUS")) PANEL_CUS = atoi(e);  // experiment knob
     if (ncu >= 4 * PANEL_CUS && ncu <= 1024) {
       uint32_t mp[32] = {0}, mu[32] = {0};
       const int words = (ncu + 31) / 32;
@@ -249,6 +251,7 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
       GemmArgs gt = mk(cm.Li + o * cm.ldi + o, cm.ldi, cm.A + o * cm.ld + (o + nb), cm.ld, T + o * ldt + (o + nb), ldt, nb,
                        rem, nb, 1.0, 0.0);
       gt.a_mask = 1; gt.khi_mode = 1;
+      gt.row_reverse = 1;  // K grows with the row tile: longest tiles first, so the launch does not end on them
       HIP_TRY(gpp_launch_gemm(cu.s, 2, gt, 1));
       HIP_TRY(hipMemcpy2DAsync(cm.A + o * cm.ld + (o + nb), cm.ld * sizeof(double), T + o * ldt + (o + nb),
                                ldt * sizeof(double), rem * sizeof(double), nb, hipMemcpyDeviceToDevice, cu.s));

@@ -142,7 +142,12 @@ __device__ __forceinline__ void load_fast(const double* __restrict__ ubase, cons
 // variants with a k-contiguous operand are off the hot path (prediction, tests) and take the registers they need.
 // TAG only changes the kernel's NAME: the single N^3/3-flop LAUUM launch runs as <2,64,64,1> so that profilers report
 // it on its own line (the roofline entry of bench.py), apart from the ~1300 launches of the recursions.
-template <int VAR, int WTM, int WTN, int TAG = 0>
+// PF = number of K chunks whose global loads are in flight at once (register-staged).  The big tile keeps PF = 1: its
+// MFMA phase (64 accumulators per lane, 2 work-groups per CU) already covers a load round trip.  The small tiles of
+// the recursions' leaves have almost no MFMA work per chunk, so with PF = 1 every chunk costs one full memory round
+// trip (~0.6 us from L2).  Measured on MI355X with PF = 4 / 8 on the small tiles: no gain (hipcc turns the predicated
+// loads of those variants into branchy code whose waits are not exact), so every launch currently uses PF = 1.
+template <int VAR, int WTM, int WTN, int TAG = 0, int PF = 1>
 __global__ __launch_bounds__(256, (VAR == 2 || WTM < 64) ? 2 : 1) void gpp_gemm_f64(GemmArgs p) {
   constexpr bool A_KC = (VAR != 2);
   constexpr bool B_KC = (VAR == 0);
@@ -214,8 +219,9 @@ __global__ __launch_bounds__(256, (VAR == 2 || WTM < 64) ? 2 : 1) void gpp_gemm_
 #pragma unroll
     for (int b = 0; b < CB; ++b) acc[a][b] = 0.0;
 
-  v2d ra[TM / 32], rb[TN / 32];
-  unsigned ka = 0, kb_ = 0;
+  v2d ra[PF][TM / 32], rb[PF][TN / 32];
+  unsigned ka[PF], kb_[PF];
+  bool fast[PF];
   unsigned offa[TM / 32], offb[TN / 32];
   thread_offsets<TM, A_KC>(p.lda, tid, offa);
   thread_offsets<TN, B_KC>(p.ldb, tid, offb);
@@ -224,71 +230,88 @@ __global__ __launch_bounds__(256, (VAR == 2 || WTM < 64) ? 2 : 1) void gpp_gemm_
   const double* __restrict__ ubaseB = B_KC ? B + (int64_t)col0 * p.ldb : B + col0;
   const int64_t stepA = A_KC ? 1 : p.lda, stepB = B_KC ? 1 : p.ldb;  // elements per unit of k
 
-  bool fast = false;
-  auto stage_load = [&](int kb) {
-    // (the lean path is enabled for the row-contiguous TN variant only: with a k-contiguous operand the extra live
-    //  registers push hipcc over the 256-VGPR budget of 2 waves/SIMD and the spills cost more than the VALU saved)
-    fast = (VAR == 2) && chunk_is_interior<TM>(row0, p.M, kb, khi, p.a_mask) &&
-           chunk_is_interior<TN>(col0, p.N, kb, khi, p.b_mask);
-    if (fast) {
-      load_fast<TM>(ubaseA + (int64_t)kb * stepA, offa, ra);
-      load_fast<TN>(ubaseB + (int64_t)kb * stepB, offb, rb);
-    } else {
-      ka = A_KC ? load_kc<TM>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra)
-                : load_mc<TM>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra);
-      kb_ = B_KC ? load_kc<TN>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb)
-                 : load_mc<TN>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb);
-    }
-  };
-  auto stage_store = [&](double* da, double* db) {
-    if (fast) {
-      if (A_KC) store_kc<TM, false>(da, tid, ra, 0); else store_mc<TM, false>(da, tid, ra, 0);
-      if (B_KC) store_kc<TN, false>(db, tid, rb, 0); else store_mc<TN, false>(db, tid, rb, 0);
-    } else {
-      if (A_KC) store_kc<TM, true>(da, tid, ra, ka); else store_mc<TM, true>(da, tid, ra, ka);
-      if (B_KC) store_kc<TN, true>(db, tid, rb, kb_); else store_mc<TN, true>(db, tid, rb, kb_);
-    }
-  };
+  // (the lean path is enabled for the row-contiguous TN variant only: with a k-contiguous operand the extra live
+  //  registers push hipcc over the 256-VGPR budget of 2 waves/SIMD and the spills cost more than the VALU saved)
+#define GPP_STAGE_LOAD(slot, kb)                                                                                   \
+  do {                                                                                                             \
+    const int kb__ = (kb);                                                                                         \
+    fast[slot] = (VAR == 2) && chunk_is_interior<TM>(row0, p.M, kb__, khi, p.a_mask) &&                            \
+                 chunk_is_interior<TN>(col0, p.N, kb__, khi, p.b_mask);                                            \
+    if (fast[slot]) {                                                                                              \
+      load_fast<TM>(ubaseA + (int64_t)kb__ * stepA, offa, ra[slot]);                                               \
+      load_fast<TN>(ubaseB + (int64_t)kb__ * stepB, offb, rb[slot]);                                               \
+    } else {                                                                                                       \
+      ka[slot] = A_KC ? load_kc<TM>(A, p.lda, p.M, row0, kb__, khi, p.a_mask, tid, ra[slot])                       \
+                      : load_mc<TM>(A, p.lda, p.M, row0, kb__, khi, p.a_mask, tid, ra[slot]);                      \
+      kb_[slot] = B_KC ? load_kc<TN>(B, p.ldb, p.N, col0, kb__, khi, p.b_mask, tid, rb[slot])                      \
+                       : load_mc<TN>(B, p.ldb, p.N, col0, kb__, khi, p.b_mask, tid, rb[slot]);                     \
+    }                                                                                                              \
+  } while (0)
+#define GPP_STAGE_STORE(slot, da, db)                                                                              \
+  do {                                                                                                             \
+    if (fast[slot]) {                                                                                              \
+      if (A_KC) store_kc<TM, false>(da, tid, ra[slot], 0); else store_mc<TM, false>(da, tid, ra[slot], 0);         \
+      if (B_KC) store_kc<TN, false>(db, tid, rb[slot], 0); else store_mc<TN, false>(db, tid, rb[slot], 0);         \
+    } else {                                                                                                       \
+      if (A_KC) store_kc<TM, true>(da, tid, ra[slot], ka[slot]); else store_mc<TM, true>(da, tid, ra[slot], ka[slot]); \
+      if (B_KC) store_kc<TN, true>(db, tid, rb[slot], kb_[slot]); else store_mc<TN, true>(db, tid, rb[slot], kb_[slot]); \
+    }                                                                                                              \
+  } while (0)
 
   // chunk c covers k in [kpos(c), kpos(c)+16).  With k_reverse the chunks run from the top of the range down, so that
   // tiles whose ranges END together (klo differs per column tile, e.g. X^T * lower-triangular) sweep the shared
-  // operand in lockstep and hit in L2 instead of each streaming its own k rows.
-  auto kpos = [&](int c) { return p.k_reverse ? klo + (nch - 1 - c) * BK : klo + c * BK; };
+  // operand in lockstep and hit in L2 instead of each streaming its own k rows.  Requests past the last chunk re-read
+  // the last chunk (never used): every path then issues the same number of loads and the compiler's vmcnt waits
+  // stay exact.
+  auto kpos = [&](int c) {
+    c = c < nch ? c : nch - 1;
+    return p.k_reverse ? klo + (nch - 1 - c) * BK : klo + c * BK;
+  };
   if (nch > 0) {
-    stage_load(kpos(0));
-    stage_store(smem, smem + OPSZ);
+#pragma unroll
+    for (int u = 0; u < PF; ++u) GPP_STAGE_LOAD(u, kpos(u));
+    GPP_STAGE_STORE(0, smem, smem + OPSZ);
   }
   __syncthreads();
 
-  for (int c = 0; c < nch; ++c) {
-    const int cur = c & 1;
-    const bool more = (c + 1 < nch);
-    if (more) stage_load(kpos(c + 1));
-    // A fragment: lane (i = l&3, k = l>>4), same address in the 4 column groups (l>>2)&3 -> LDS broadcast
-    const double* sa = smem + (cur * 2 + 0) * OPSZ + (A_KC ? (wm + (lane & 3)) * LDK + lk : wm + (lane & 3) + lk * LDA);
-    const double* sb = smem + (cur * 2 + 1) * OPSZ + (B_KC ? (wn + li) * LDK + lk : wn + li + lk * LDB);
+  // Iteration c: request chunk c+PF into the register slot chunk c just left, multiply chunk c from LDS, move chunk
+  // c+1 (requested PF-1 iterations ago) from registers to the other LDS buffer.  Unrolled by PF so slots are static.
+  for (int c0 = 0; c0 < nch; c0 += PF) {
 #pragma unroll
-    for (int kk = 0; kk < BK / 4; ++kk) {
-      double bf[CB];
+    for (int u = 0; u < PF; ++u) {
+      const int c = c0 + u;
+      if (c >= nch) break;
+      const int cur = c & 1;
+      const bool more = (c + 1 < nch);
+      if (PF > 1 || more) GPP_STAGE_LOAD(u, kpos(c + PF));
+      // A fragment: lane (i = l&3, k = l>>4), same address in the 4 column groups (l>>2)&3 -> LDS broadcast
+      const double* sa = smem + (cur * 2 + 0) * OPSZ + (A_KC ? (wm + (lane & 3)) * LDK + lk : wm + (lane & 3) + lk * LDA);
+      const double* sb = smem + (cur * 2 + 1) * OPSZ + (B_KC ? (wn + li) * LDK + lk : wn + li + lk * LDB);
 #pragma unroll
-      for (int b = 0; b < CB; ++b) bf[b] = B_KC ? sb[16 * b * LDK + kk * 4] : sb[kk * 4 * LDB + 16 * b];
-      // A fragments in groups of <= 8 row blocks: bounds the live registers (acc + staging already take ~170)
-      constexpr int AG = RB < 8 ? RB : 8;
+      for (int kk = 0; kk < BK / 4; ++kk) {
+        double bf[CB];
 #pragma unroll
-      for (int a0 = 0; a0 < RB; a0 += AG) {
-        double af[AG];
+        for (int b = 0; b < CB; ++b) bf[b] = B_KC ? sb[16 * b * LDK + kk * 4] : sb[kk * 4 * LDB + 16 * b];
+        // A fragments in groups of <= 8 row blocks: bounds the live registers (acc + staging already take ~170)
+        constexpr int AG = RB < 8 ? RB : 8;
 #pragma unroll
-        for (int a = 0; a < AG; ++a) af[a] = A_KC ? sa[4 * (a0 + a) * LDK + kk * 4] : sa[kk * 4 * LDA + 4 * (a0 + a)];
+        for (int a0 = 0; a0 < RB; a0 += AG) {
+          double af[AG];
 #pragma unroll
-        for (int a = 0; a < AG; ++a)
+          for (int a = 0; a < AG; ++a) af[a] = A_KC ? sa[4 * (a0 + a) * LDK + kk * 4] : sa[kk * 4 * LDA + 4 * (a0 + a)];
 #pragma unroll
-          for (int b = 0; b < CB; ++b)
-            acc[a0 + a][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[b], acc[a0 + a][b], 0, 0, 0);
+          for (int a = 0; a < AG; ++a)
+#pragma unroll
+            for (int b = 0; b < CB; ++b)
+              acc[a0 + a][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[b], acc[a0 + a][b], 0, 0, 0);
+        }
       }
+      if (more) GPP_STAGE_STORE((u + 1) % PF, smem + ((cur ^ 1) * 2 + 0) * OPSZ, smem + ((cur ^ 1) * 2 + 1) * OPSZ);
+      __syncthreads();
     }
-    if (more) stage_store(smem + ((cur ^ 1) * 2 + 0) * OPSZ, smem + ((cur ^ 1) * 2 + 1) * OPSZ);
-    __syncthreads();
   }
+#undef GPP_STAGE_LOAD
+#undef GPP_STAGE_STORE
 
   // epilogue: slab (a,b) holds C[row0+wm+4a+(l>>4)][col0+wn+16b+(l&15)].  The beta path first issues all C loads of a
   // group of slabs (clamped addresses, no branches around loads) and only then combines and stores.

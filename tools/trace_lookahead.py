@@ -2,7 +2,7 @@
 and how much of the potrf span each queue covers."""
 import sys, glob
 import pandas as pd, numpy as np
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]
 df = pd.read_csv(f)
 df['dur'] = (df.End_Timestamp - df.Start_Timestamp) / 1e3
 df = df.sort_values('Start_Timestamp').reset_index(drop=True)
@@ -36,3 +36,12 @@ iv = sorted(zip(upd.s, upd.e)); gaps = []
 for (s0, e0), (s1, e1) in zip(iv[:-1], iv[1:]):
     if s1 - e0 > 0.05: gaps.append((round(e0, 2), round(s1 - e0, 2)))
 print('update-queue gaps (start, length ms):', gaps)
+# per-kernel list of the update queue in the last part of the factorisation
+if len(sys.argv) > 2:
+    t_from = float(sys.argv[2])
+    sub = upd[upd.s >= t_from]
+    prev_e = None
+    for _, r in sub.iterrows():
+        gap = 0.0 if prev_e is None else r.s - prev_e
+        print('%7.2f  +%5.2f  %6.3f ms  wgs %6d  %s' % (r.s, gap, r.e - r.s, r.Grid_Size_X // max(r.Workgroup_Size_X, 1), r.Kernel_Name[:60]))
+        prev_e = r.e
