@@ -351,14 +351,17 @@ __global__ __launch_bounds__(256, (VAR == 2 || WTM < 64) ? 2 : 1) void gpp_gemm_
   }
 }
 
+#ifndef GPP_PF_SMALL
+#define GPP_PF_SMALL 1
+#endif
 template <int VAR>
 hipError_t launch_var(hipStream_t s, int tm, int tn, dim3 grid, const GemmArgs& a) {
   if (tm == 128 && tn == 128 && a.tag == 1 && VAR == 2)
     hipLaunchKernelGGL((gpp_gemm_f64<2, 64, 64, 1>), grid, dim3(256), 0, s, a);
   else if (tm == 128 && tn == 128) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 64, 64>), grid, dim3(256), 0, s, a);
-  else if (tm == 64 && tn == 64) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 32, 32>), grid, dim3(256), 0, s, a);
-  else if (tm == 32 && tn == 32) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 16, 16>), grid, dim3(256), 0, s, a);
-  else if (tm == 128 && tn == 32) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 64, 16>), grid, dim3(256), 0, s, a);
+  else if (tm == 64 && tn == 64) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 32, 32, 0, GPP_PF_SMALL>), grid, dim3(256), 0, s, a);
+  else if (tm == 32 && tn == 32) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 16, 16, 0, GPP_PF_SMALL>), grid, dim3(256), 0, s, a);
+  else if (tm == 128 && tn == 32) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 64, 16, 0, GPP_PF_SMALL>), grid, dim3(256), 0, s, a);
   else return hipErrorInvalidValue;
   return hipGetLastError();
 }

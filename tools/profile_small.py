@@ -1,0 +1,24 @@
+"""cProfile of the loss+grad step at C1 size (N=500) through the GP_Plus API: where the host time goes.  Dev tool."""
+import os, sys, time, cProfile, pstats
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from gpplus_amd.gpcore import ExactMarginalLogLikelihood
+from gpplus_amd.models import GP_Plus
+from gpplus_amd.preprocessing import standard
+from gpplus_amd.test_functions.analytical import borehole
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+X, y = borehole(n=10000, random_state=12345); X = torch.tensor(X[:N]); y = torch.tensor(y[:N]); X, _, _ = standard(X, {})
+m = GP_Plus(X, y, dtype=torch.float64, device='cuda')
+m.train(); mll = ExactMarginalLogLikelihood(m.likelihood, m)
+params = [p for p in m.parameters() if p.requires_grad]
+def step():
+    for p in params: p.grad = None
+    loss = -mll(m(*m.train_inputs), m.train_targets); loss.backward(); return loss
+for _ in range(5): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for _ in range(50): step()
+torch.cuda.synchronize(); print('ms/eval %.3f' % ((time.perf_counter() - t0) / 50 * 1e3))
+pr = cProfile.Profile(); pr.enable()
+for _ in range(50): step()
+torch.cuda.synchronize(); pr.disable()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(35)
