@@ -205,6 +205,14 @@ def main():
         stage_rate = {k: flops[k] / (stage_ms[k] * 1e-3) / 1e12 for k in flops if k in stage_ms}
         lauum_tflops = stage_rate.get("lauum", 0.0)
         value = world * args.steps / elapsed
+        # HBM-side bytes of the roofline kernel come from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+        # cannot run inside this process); they only apply to the size they were collected at
+        traffic, traffic_src = None, None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_lauum_pmc.json")
+        if N == 20000 and os.path.exists(pmc):
+            with open(pmc) as fh:
+                rec = json.load(fh)
+            traffic, traffic_src = rec["traffic_bytes_per_launch"], "profiles/r01_lauum_pmc.json: " + rec["note"]
         out = {
             "metric": "MLL evals/sec (fwd+grad), NxN exact GP, N=20k d=8",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -215,7 +223,8 @@ def main():
                        "N": N, "d": D_C2, "loss": float(loss.item()), "streams_per_gpu": S},
             "roofline": {"bound": "mfma", "kernel": "gpp_gemm_f64<2, 64, 64, 1, 1> (LAUUM: Kinv = Linv^T Linv, the one lower-triangular TN launch)",
                          "achieved": lauum_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": lauum_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": None,
+                         "frac": lauum_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "B/launch",
+                         "traffic_source": traffic_src,
                          "flops_per_launch": N ** 3 / 3, "ms_per_launch": stage_ms.get("lauum")},
             "stages": {"ms": stage_ms, "tflops": stage_rate,
                        "eval_tflops_N3": N ** 3 / (elapsed / args.steps) / 1e12},
