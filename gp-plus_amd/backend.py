@@ -147,6 +147,17 @@ class GppContext:
                                        d_split, alpha.data_ptr(), Kinv.data_ptr(), _ld(Kinv), dU, g_w.data_ptr(),
                                        g_sf2.data_ptr(), g_tau.data_ptr(), _ptr(g_U)), "gpp_grad_reduce")
 
+    def grad_reduce_rows(self, U, w, sf2, grp, S, alpha, Kinv, dU, nb, rank, nranks, g_w, g_sf2, g_tau, g_U, *,
+                         kind=KIND_RBF, d_split=0):
+        """Partial sums over the block rows of Kinv owned by ``rank`` (block-cyclic, block height ``nb``)."""
+        N, D = U.shape
+        self.ensure_workspace(OP_MLL_EVAL, N, 0, D, S)
+        self._stream()
+        check(self.lib.gpp_grad_reduce_rows(self.h, U.data_ptr(), N, D, w.data_ptr(), sf2.data_ptr(), _ptr(grp), S, kind,
+                                            d_split, alpha.data_ptr(), Kinv.data_ptr(), _ld(Kinv), dU, nb, rank, nranks,
+                                            g_w.data_ptr(), g_sf2.data_ptr(), g_tau.data_ptr(), _ptr(g_U)),
+              "gpp_grad_reduce_rows")
+
     def predict(self, Linv, alpha, Ksn, kss, V, mean_out, var_out):
         self._stream()
         check(self.lib.gpp_predict(self.h, Linv.data_ptr(), _ld(Linv), Linv.shape[0], alpha.data_ptr(), Ksn.data_ptr(),

@@ -505,6 +505,34 @@ int gpp_grad_reduce(gpp_handle_t h, const double* U, int64_t N, int D, const dou
   return 0;
 }
 
+int gpp_grad_reduce_rows(gpp_handle_t h, const double* U, int64_t N, int D, const double* w, const double* sf2,
+                         const int32_t* grp, int S, int kind, int d_split, const double* alpha, const double* Kinv,
+                         int64_t ldk, int dU, int64_t nb, int rank, int nranks, double* g_w, double* g_sf2, double* g_tau,
+                         double* g_U) {
+  if (!h) return -1;
+  if (!U) return -2;
+  if (N < 0) return -3;
+  if (D < 1 || D > 64) return -4;
+  if (!w) return -5;
+  if (!sf2) return -6;
+  if (S < 1 || S > 64) return -8;
+  if (kind < 0 || kind > 2) return -9;
+  if (d_split < 0 || d_split > D) return -10;
+  if (!alpha) return -11;
+  if (int q = check_mat(Kinv, ldk, N, 12)) return q;
+  if (dU < 0 || dU > D) return -14;
+  if (nb < 64 || nb % 64 != 0 || nb > (1 << 30)) return -15;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return -16;
+  if (!g_w) return -18;
+  if (!g_sf2) return -19;
+  if (!g_tau) return -20;
+  if (dU > 0 && !g_U) return -21;
+  if (!h->ws || h->ws_bytes < gpp_grad_ws_bytes(N, D, S, dU)) return -1;
+  GPP_TRY(gpp_launch_grad_reduce(h->stream, U, N, D, w, sf2, grp, S, kind, d_split, alpha, Kinv, ldk, dU, g_w, g_sf2, g_tau,
+                                 g_U, h->ws, h->ws_bytes, (int)nb, rank, nranks));
+  return 0;
+}
+
 int gpp_predict(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, const double* alpha, const double* Ksn,
                 int64_t lds, int64_t M, const double* kss, double* V, int64_t ldv, double* mean_out, double* var_out) {
   if (!h) return -1;

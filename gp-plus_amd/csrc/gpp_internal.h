@@ -69,7 +69,8 @@ size_t gpp_grad_ws_bytes(int64_t N, int D, int S, int dU);
 hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int D, const double* w, const double* sf2,
                                   const int32_t* grp, int S, int kind, int d_split, const double* alpha,
                                   const double* Kinv, int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau,
-                                  double* g_U, void* ws, size_t ws_bytes);
+                                  double* g_U, void* ws, size_t ws_bytes, int shard_nb = 0, int shard_rank = 0,
+                                  int shard_nranks = 1);
 hipError_t gpp_launch_predict_reduce(hipStream_t s, const double* Ksn, int64_t lds, const double* V, int64_t ldv,
                                      int64_t M, int64_t N, const double* alpha, const double* kss, double* mean_out,
                                      double* var_out);

@@ -120,7 +120,8 @@ template <int DT>
 __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__ U, int64_t N, int D,
                                                       const double* __restrict__ w, const double* __restrict__ sf2p,
                                                       int kind, int d_split, const double* __restrict__ alpha, const double* __restrict__ Kinv,
-                                                      int64_t ldk, int dU, int64_t ntiles,
+                                                      int64_t ldk, int dU, int64_t ntiles, int shard_nb, int shard_rank,
+                                                      int shard_nranks,
                                                       double* __restrict__ rec /* [gridDim.x][D+1] */,
                                                       double* __restrict__ wdiag /* [N] */,
                                                       double* __restrict__ gUpart /* [T][N][dU] */) {
@@ -144,6 +145,8 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
     int64_t ti, tj;
     tile_from_index(t, ti, tj);
     const int64_t i0 = ti * GT, j0 = tj * GT;
+    // row-sharded evaluation: this rank only holds (and reduces) the block rows of Kinv it owns (block-cyclic)
+    if (shard_nranks > 1 && (int)((i0 / shard_nb) % shard_nranks) != shard_rank) continue;
     const bool diag_tile = (ti == tj);
     __syncthreads();
     for (int e = tid; e < DT * GT; e += 256) {
@@ -364,8 +367,10 @@ size_t gpp_grad_ws_bytes(int64_t N, int D, int S, int dU) {
 hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int D, const double* w, const double* sf2,
                                   const int32_t* grp, int S, int kind, int d_split, const double* alpha,
                                   const double* Kinv, int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau,
-                                  double* g_U, void* ws, size_t ws_bytes) {
+                                  double* g_U, void* ws, size_t ws_bytes, int shard_nb, int shard_rank, int shard_nranks) {
   if (kind < 0 || kind > 2) return hipErrorInvalidValue;
+  if (shard_nranks > 1 && (shard_nb < GT || shard_nb % GT != 0 || shard_rank < 0 || shard_rank >= shard_nranks))
+    return hipErrorInvalidValue;
   if (D > GD_MAX || D < 1 || S > GS_MAX || S < 1 || dU > D || dU < 0) return hipErrorInvalidValue;
   if (ws_bytes < gpp_grad_ws_bytes(N, D, S, dU)) return hipErrorInvalidValue;
   const int T = (int)((N + GT - 1) / GT);
@@ -374,9 +379,13 @@ hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int
   double* rec = reinterpret_cast<double*>(ws);
   double* wdiag = rec + (size_t)G_WGS * (D + 1);
   double* gUpart = wdiag + N;
+  if (shard_nranks > 1) {  // skipped tiles leave their slots unwritten: start from zero
+    hipError_t e = hipMemsetAsync(wdiag, 0, (size_t)N * sizeof(double) + (size_t)T * N * (dU > 0 ? dU : 0) * sizeof(double), s);
+    if (e != hipSuccess) return e;
+  }
 #define GPP_GRAD_LAUNCH(DT)                                                                                              \
   hipLaunchKernelGGL(gpp_grad_tiles<DT>, dim3(nwg), dim3(256), 0, s, U, N, D, w, sf2, kind, d_split, alpha, Kinv, ldk, dU, \
-                     ntiles, rec, wdiag, gUpart)
+                     ntiles, shard_nb, shard_rank, shard_nranks, rec, wdiag, gUpart)
   if (D <= 8) GPP_GRAD_LAUNCH(8);
   else if (D <= 16) GPP_GRAD_LAUNCH(16);
   else if (D <= 32) GPP_GRAD_LAUNCH(32);

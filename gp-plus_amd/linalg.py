@@ -210,6 +210,11 @@ def exact_mll(U: torch.Tensor, spec: KernelSpec, tau: torch.Tensor, mean: torch.
         slot = current_slot()
     if n_grad_dims is None:
         n_grad_dims = U.shape[1] if U.requires_grad else 0
+    shard = settings.sharded_evaluation.value()
+    if shard is not None:
+        from .sharded import sharded_mll
+        return sharded_mll(U, spec.w, spec.sf2, tau, mean, y, grp, spec.kind, spec.d_split, int(n_grad_dims),
+                           group=shard.get("group"), nb=int(shard.get("nb", 1024)))
     return ExactMLLFunction.apply(U, spec.w, spec.sf2, tau, mean, y, grp, spec.kind, spec.d_split, int(n_grad_dims), slot)
 
 

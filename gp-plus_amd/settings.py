@@ -25,6 +25,12 @@ cholesky_max_tries = _Value(3)      # gpytorch.settings.cholesky_max_tries
 min_variance = _Value(1e-10)        # gpytorch.settings.min_variance (double)
 
 
+# Sharded single evaluation (gp-plus_amd/sharded.py): ``with settings.sharded_evaluation({"group": None, "nb": 1024}):``
+# makes every exact-GP log-likelihood inside the block a cooperative evaluation by all ranks of the process group
+# (None = the default group).  Every rank must run the same model code with the same parameters.
+sharded_evaluation = _Value(None)
+
+
 @contextmanager
 def fast_computations(covar_root_decomposition=True, log_prob=True, solves=True):
     yield

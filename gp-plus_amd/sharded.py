@@ -1,0 +1,297 @@
+"""Sharded single evaluation of the exact-GP marginal likelihood over the GPUs of one node (SURVEY.md §8(e) mode 2,
+BASELINE config 5: N = 60 000 on 8 x MI355X).  One process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over
+xGMI); every rank calls :func:`sharded_mll` with identical arguments and receives the identical value and gradients.
+
+The reference has no multi-GPU evaluation (its only parallelism is joblib over restarts, optim/mll_scipy.py:287-293);
+this is the same computation as ``linalg.ExactMLLFunction`` (reference call sites optim/mll_torch.py:114-117) with its
+O(N^3) stages split by 1-D block-cyclic BLOCK ROWS of the upper-stored matrices (block height ``nb``, owner = k mod P):
+
+  build    every rank builds the block rows of Ky it owns                                      (no communication)
+  potrf    right-looking: the owner of block row k factors the diagonal block (leaf kernels), inverts it, solves the
+           block row with one GEMM and BROADCASTS the finished row slab (nb x ld doubles) together with the inverse of
+           the diagonal block; every rank then updates the block rows it owns with one TN GEMM each.  One step of
+           look-ahead: the owner of k+1 updates that row first and factors / broadcasts it on a second stream while
+           the remaining updates of step k run.
+  inverse  column blocks of L^-1 are independent forward substitutions against the (now replicated) factor: the owner of
+           column block c sweeps Y_k = -L_kk^-1 sum_{j<k} L_kj Y_j right-looking (one wide TN GEMM per step); the column
+           blocks are then broadcast so that every rank holds L^-1 (lower) and its mirror (upper).
+  lauum    every rank forms the block rows of Ky^-1 = L^-T L^-1 it owns                         (no communication)
+  grad     ``gpp_grad_reduce_rows`` over the owned block rows, then ONE all-reduce of D + 1 + S (+ N dU) doubles.
+
+Communication per evaluation: the factor slabs (8 N ld B), the column blocks of the inverse (4 N^2 B) and the tiny
+all-reduce; at C5 that is ~43 GB per GPU against ~2.7e13 flop of GEMM work per GPU.  Memory per GPU: the same three
+N x N buffers as the single-GPU path (86 GB at C5 of 288 GB) — nothing is scattered, so every stage after the
+factorisation reads local memory only.
+
+Without RCCL (tests: two processes sharing one GPU over "gloo") the broadcasts are staged through host memory.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+from .backend import KIND_RBF, UPLO_FULL, GppContext, get_context, square_buffer
+from .errors import NanError, NotPSDError
+from . import settings
+
+__all__ = ["ShardedWorkspace", "sharded_mll", "ShardedMLLFunction"]
+
+
+class _Comm:
+    def __init__(self, group=None):
+        if not dist.is_available() or not dist.is_initialized():
+            raise RuntimeError("sharded evaluation needs an initialised torch.distributed process group")
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.world = dist.get_world_size(group)
+        self.direct = dist.get_backend(group) == "nccl"  # RCCL moves device memory itself
+
+    def _global(self, r: int) -> int:
+        return r if self.group is None else dist.get_global_rank(self.group, r)
+
+    def bcast(self, t: torch.Tensor, src: int) -> None:
+        if self.world == 1:
+            return
+        if self.direct:
+            dist.broadcast(t, self._global(src), group=self.group)
+            return
+        h = t.detach().cpu() if self.rank == src else torch.empty(t.shape, dtype=t.dtype)
+        dist.broadcast(h, self._global(src), group=self.group)
+        if self.rank != src:
+            t.copy_(h)
+
+    def allreduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM) -> None:
+        if self.world == 1:
+            return
+        if self.direct:
+            dist.all_reduce(t, op=op, group=self.group)
+            return
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op, group=self.group)
+        t.copy_(h)
+
+
+class ShardedWorkspace:
+    """Per-rank buffers of an N-point sharded evaluation (reused across evaluations)."""
+
+    def __init__(self, ctx: GppContext, N: int, nb: int):
+        dev = ctx.device
+        self.N, self.nb = N, nb
+        self.A = square_buffer(N, dev)      # Ky block rows (owned) -> the whole factor U after the broadcasts
+        self.Li = square_buffer(N, dev)     # L^-1 (lower) + mirror (upper)
+        self.Ki = square_buffer(N, dev)     # scratch, then the owned block rows of Ky^-1 (lower)
+        self.ld = self.A.stride(0)
+        self.pack = torch.empty(N * nb, dtype=torch.float64, device=dev)
+        self.dbuf = torch.empty(nb * nb, dtype=torch.float64, device=dev)
+        self.z = torch.empty(N, dtype=torch.float64, device=dev)
+        self.alpha = torch.empty(N, dtype=torch.float64, device=dev)
+        self.r = torch.empty(N, dtype=torch.float64, device=dev)
+        self.out3 = torch.empty(3, dtype=torch.float64, device=dev)
+        self.offs: List[int] = list(range(0, N, nb)) + [N]
+        self.info = torch.zeros(len(self.offs), dtype=torch.int32, device=dev)
+        self.side = torch.cuda.Stream(device=dev)
+        self.epoch = 0
+
+    def rows(self, buf: torch.Tensor, o: int, n: int) -> torch.Tensor:
+        """Contiguous slab of ``n`` full rows (including the row padding) of one of the square buffers."""
+        base = buf._base if buf._base is not None else buf
+        return base[o:o + n]
+
+
+_workspaces = {}
+
+
+def _workspace(ctx: GppContext, N: int, nb: int) -> ShardedWorkspace:
+    key = (ctx.index, N, nb)
+    ws = _workspaces.get(key)
+    if ws is None:
+        _workspaces.clear()
+        ws = ShardedWorkspace(ctx, N, nb)
+        _workspaces[key] = ws
+    return ws
+
+
+def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, grp, kind, d_split, jitter: float) -> int:
+    """Distributed build + Cholesky.  Returns the LAPACK-style info (0 = ok) agreed on by all ranks."""
+    N, offs, P, me = ws.N, ws.offs, comm.world, comm.rank
+    nblk = len(offs) - 1
+    A, Li, Ki = ws.A, ws.Li, ws.Ki
+    main = torch.cuda.current_stream(ctx.index)
+    side = ws.side
+    ws.info.zero_()
+    for k in range(me, nblk, P):
+        ctx.kernel_build(U, w, sf2, tau, grp, A, jitter=jitter, kind=kind, d_split=d_split, uplo=UPLO_FULL, row0=offs[k],
+                         nrows=offs[k + 1] - offs[k])
+    row_ready = torch.cuda.Event()
+    row_ready.record(main)
+    side.wait_stream(main)
+    for k in range(nblk):
+        o, o1 = offs[k], offs[k + 1]
+        nbk, rem, own = o1 - o, N - o1, (k % P == me)
+        with torch.cuda.stream(side):
+            dblk = ws.dbuf[:nbk * nbk].view(nbk, nbk)
+            if own:
+                side.wait_event(row_ready)  # block row k carries every update of the steps before k
+                Akk, Lkk, Tkk = A[o:o1, o:o1], Li[o:o1, o:o1], Ki[o:o1, o:o1]
+                ctx.potrf(Akk, Lkk, ws.info[k:k + 1], Tkk)
+                ctx.trtri(Akk, Lkk, Tkk)
+                if rem > 0:
+                    # U12 = W_kk^T A12 (W = mirrored inverse of the diagonal block), via the scratch: not in place
+                    ctx.gemm(1, 0, nbk, rem, nbk, 1.0, Lkk, A[o:o1, o1:N], 0.0, Ki[o:o1, o1:N], a_mask=1, khi_mode=1)
+                    A[o:o1, o1:N].copy_(Ki[o:o1, o1:N])
+                dblk.copy_(Lkk)
+            comm.bcast(ws.rows(A, o, nbk), k % P)
+            comm.bcast(dblk, k % P)
+            if not own:
+                Li[o:o1, o:o1].copy_(dblk)
+            arrived = torch.cuda.Event()
+            arrived.record(side)
+        main.wait_event(arrived)
+        for j in range(k + 1, nblk):
+            if j % P != me:
+                continue
+            oj, oj1 = offs[j], offs[j + 1]
+            # A[j, j:] -= U[k, j]^T U[k, j:]   (the strictly-lower part of the diagonal block is scratch, never read)
+            ctx.gemm(1, 0, oj1 - oj, N - oj, nbk, -1.0, A[o:o1, oj:oj1], A[o:o1, oj:N], 1.0, A[oj:oj1, oj:N])
+            if j == k + 1:
+                row_ready = torch.cuda.Event()
+                row_ready.record(main)
+    main.wait_stream(side)
+    info = ws.info.max().to(torch.int32).reshape(1)
+    comm.allreduce(info, dist.ReduceOp.MAX)
+    return int(info.item())
+
+
+def _inverse(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
+    """L^-1 (lower) and its mirror (upper) on every rank, from the replicated factor and diagonal-block inverses."""
+    N, offs, P, me = ws.N, ws.offs, comm.world, comm.rank
+    nblk = len(offs) - 1
+    A, Li, Ki = ws.A, ws.Li, ws.Ki
+    for c in range(me, nblk, P):
+        oc, oc1 = offs[c], offs[c + 1]
+        if oc1 < N:
+            Li[oc1:N, oc:oc1].zero_()
+        for j in range(c, nblk):
+            oj, oj1 = offs[j], offs[j + 1]
+            if j > c:
+                # Y_j = -X_jj S_j  (X_jj^T = mirror in the upper part of the diagonal block), via the scratch
+                ctx.gemm(1, 0, oj1 - oj, oc1 - oc, oj1 - oj, -1.0, Li[oj:oj1, oj:oj1], Li[oj:oj1, oc:oc1], 0.0,
+                         Ki[oj:oj1, oc:oc1], a_mask=1, khi_mode=1)
+                Li[oj:oj1, oc:oc1].copy_(Ki[oj:oj1, oc:oc1])
+            if oj1 < N:
+                # S_k += L[k, j] Y_j for every block k below: L[k, j] = U[j, k]^T.  Y_c is the lower-triangular X_cc: its
+                # slot also holds the mirror above the diagonal, masked out here (keep k >= n)
+                ctx.gemm(1, 0, N - oj1, oc1 - oc, oj1 - oj, 1.0, A[oj:oj1, oj1:N], Li[oj:oj1, oc:oc1], 1.0, Li[oj1:N, oc:oc1],
+                         b_mask=2 if j == c else 0, klo_mode=2 if j == c else 0)
+    for c in range(nblk):
+        oc, oc1 = offs[c], offs[c + 1]
+        if oc1 >= N:
+            break  # the last column block is its diagonal block, which every rank already has
+        wc = oc1 - oc
+        buf = ws.pack[:(N - oc1) * wc].view(N - oc1, wc)
+        if c % P == me:
+            buf.copy_(Li[oc1:N, oc:oc1])
+        comm.bcast(buf, c % P)
+        if c % P != me:
+            Li[oc1:N, oc:oc1].copy_(buf)
+        Li[oc:oc1, oc1:N].copy_(buf.t())  # mirror
+
+
+def _lauum_rows(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
+    """Owned block rows of Ky^-1 = L^-T L^-1 (lower triangle) into ws.Ki."""
+    N, offs, P, me = ws.N, ws.offs, comm.world, comm.rank
+    Li, Ki = ws.Li, ws.Ki
+    for m in range(me, len(offs) - 1, P):
+        om, om1 = offs[m], offs[m + 1]
+        Am = Li[om:N, om:om1]  # rows k >= om of column block m: entry (k, i) is non-zero for k >= i (block-relative)
+        if om > 0:
+            ctx.gemm(1, 0, om1 - om, om, N - om, 1.0, Am, Li[om:N, 0:om], 0.0, Ki[om:om1, 0:om], a_mask=2, klo_mode=1)
+        ctx.gemm(1, 0, om1 - om, om1 - om, N - om, 1.0, Am, Am, 0.0, Ki[om:om1, om:om1], a_mask=2, b_mask=2, klo_mode=3,
+                 c_tri=1)
+
+
+class ShardedMLLFunction(torch.autograd.Function):
+    """Same contract as ``linalg.ExactMLLFunction`` (value and gradients identical on every rank)."""
+
+    @staticmethod
+    def forward(ctx, U, w, sf2, tau, mean, y, grp, kind, d_split, dU, group, nb):
+        dev = U.device
+        gctx = get_context(dev)
+        comm = _Comm(group)
+        N, D = U.shape
+        f64 = lambda t: t.detach().to(device=dev, dtype=torch.float64).contiguous()
+        Ud, wd, sd, td = f64(U), f64(w), f64(sf2).reshape(1), f64(tau).reshape(-1)
+        if grp is not None and grp.dtype != torch.int32:
+            grp = grp.to(torch.int32)
+        ws = _workspace(gctx, N, nb)
+        ws.epoch += 1
+        jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
+        used = None
+        for jit in jitters:
+            info = _factor(gctx, comm, ws, Ud, wd, sd, td, grp, kind, d_split, jit)
+            if info == 0:
+                used = jit
+                break
+            if jit == 0.0:
+                bad = [n for n, t in (("inputs", Ud), ("weights", wd), ("outputscale", sd), ("noise", td))
+                       if not torch.isfinite(t).all()]
+                if bad:
+                    raise NanError(f"cholesky: NaN/Inf in {', '.join(bad)} of the covariance")
+        if used is None:
+            raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitters[-1]:.1e}.")
+        if used > 0:
+            warnings.warn(f"A not p.d., added jitter of {used:.1e} to the diagonal", RuntimeWarning)
+        _inverse(gctx, comm, ws)
+        torch.sub(f64(y), f64(mean), out=ws.r)
+        gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
+        ctx.saved = (gctx, comm, ws, ws.epoch, Ud, wd, sd, grp, td.numel(), kind, d_split, dU)
+        ctx.in_dtypes = (U.dtype, w.dtype, sf2.dtype, tau.dtype, mean.dtype, y.dtype)
+        ctx.shapes = (sf2.shape, tau.shape)
+        return ws.out3[2].clone()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        gctx, comm, ws, epoch, Ud, wd, sd, grp, S, kind, d_split, dU = ctx.saved
+        if ws.epoch != epoch:
+            raise RuntimeError("sharded evaluation: backward after another forward reused the buffers; call backward "
+                               "before the next evaluation")
+        N, D = Ud.shape
+        dev = Ud.device
+        gctx.alpha(ws.Li, ws.z, ws.alpha)
+        _lauum_rows(gctx, comm, ws)
+        need_U = ctx.needs_input_grad[0] and dU > 0
+        nU = N * dU if need_U else 0
+        flat = torch.zeros(D + 1 + S + nU, dtype=torch.float64, device=dev)
+        g_w, g_s, g_t = flat[:D], flat[D:D + 1], flat[D + 1:D + 1 + S]
+        g_Ud = flat[D + 1 + S:].view(N, dU) if need_U else None
+        gctx.grad_reduce_rows(Ud, wd, sd, grp, S, ws.alpha, ws.Ki, dU if need_U else 0, ws.nb, comm.rank, comm.world, g_w,
+                              g_s, g_t, g_Ud, kind=kind, d_split=d_split)
+        comm.allreduce(flat)
+        g_U = None
+        if ctx.needs_input_grad[0]:
+            g_U = torch.zeros(N, D, dtype=torch.float64, device=dev)
+            if need_U:
+                g_U[:, :dU] = g_Ud
+        go = grad_out.to(torch.float64)
+        dt = ctx.in_dtypes
+        sf2_shape, tau_shape = ctx.shapes
+        alpha = ws.alpha
+        return (None if g_U is None else (go * g_U).to(dt[0]),
+                (go * g_w).to(dt[1]) if ctx.needs_input_grad[1] else None,
+                (go * g_s).reshape(sf2_shape).to(dt[2]) if ctx.needs_input_grad[2] else None,
+                (go * g_t).reshape(tau_shape).to(dt[3]) if ctx.needs_input_grad[3] else None,
+                (go * alpha).to(dt[4]) if ctx.needs_input_grad[4] else None,
+                (-go * alpha).to(dt[5]) if ctx.needs_input_grad[5] else None,
+                None, None, None, None, None, None)
+
+
+def sharded_mll(U: torch.Tensor, w: torch.Tensor, sf2: torch.Tensor, tau: torch.Tensor, mean: torch.Tensor, y: torch.Tensor,
+                grp: Optional[torch.Tensor] = None, kind: int = KIND_RBF, d_split: int = 0, n_grad_dims: int = 0,
+                group=None, nb: int = 1024) -> torch.Tensor:
+    """log N(y | mean, sf2 k(U, U; w) + diag(tau[grp])) evaluated cooperatively by all ranks of ``group``."""
+    if nb < 128 or nb % 128 != 0:
+        raise ValueError("block height nb must be a multiple of 128")
+    return ShardedMLLFunction.apply(U, w, sf2, tau, mean, y, grp, kind, d_split, int(n_grad_dims), group, int(nb))

@@ -115,6 +115,16 @@ int gpp_grad_reduce(gpp_handle_t h, const double* U, int64_t N, int D, const dou
                     int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau, double* g_U);
 
 /*
+ * The same reduction restricted to the block rows of Kinv this rank owns in a sharded evaluation (SURVEY.md §8(e) mode 2;
+ * BASELINE config 5): rows [b*nb, (b+1)*nb) with b % nranks == rank (nb a multiple of 64).  Only those rows of Kinv are
+ * read; the outputs are this rank's PARTIAL sums (the caller all-reduces them).  nranks == 1 is gpp_grad_reduce.
+ */
+int gpp_grad_reduce_rows(gpp_handle_t h, const double* U, int64_t N, int D, const double* w, const double* sf2,
+                         const int32_t* grp, int S, int kind, int d_split, const double* alpha, const double* Kinv,
+                         int64_t ldk, int dU, int64_t nb, int rank, int nranks, double* g_w, double* g_sf2, double* g_tau,
+                         double* g_U);
+
+/*
  * K8 (models/gpregression.py:122-149 predict): V = Ksn Linv^T (M x N, scratch, may be NULL to skip var),
  *   mean_out[a] = sum_j Ksn[a,j] alpha[j],   var_out[a] = kss[a] - sum_j V[a,j]^2
  */

@@ -1,0 +1,97 @@
+"""Worker of tests/test_gpu_sharded.py: launched by torch.distributed.run, one process per rank.  With fewer GPUs than
+ranks (the 1-GPU test box) the ranks share cuda:0 and talk over gloo (host-staged broadcasts); with one GPU per rank
+the backend is nccl (= RCCL).  Every rank evaluates the sharded MLL + gradients and rank 0 compares them with the
+single-GPU path on the same inputs."""
+import os, sys, json
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from gpplus_amd.linalg import KernelSpec, exact_mll
+from gpplus_amd import settings
+
+
+def model_case(rank, world, dev, N, nb):
+    """The same comparison through the GP_Plus API (mixed inputs: manifold-encoded categoricals, Examples/02 shape)."""
+    from gpplus_amd.models import GP_Plus
+    from gpplus_amd.gpcore import ExactMarginalLogLikelihood
+    from gpplus_amd.test_functions.analytical import borehole_mixed_variables
+    from gpplus_amd.preprocessing import standard
+    from gpplus_amd.utils import set_seed
+    set_seed(4)
+    np.random.seed(4)  # (the level draws use the global numpy RNG, as in the reference: every rank must agree)
+    X, y = borehole_mixed_variables(n=N, qual_dict={0: 5, 5: 5}, random_state=4, shuffle=False)
+    X = torch.tensor(X); y = torch.tensor(y)
+    X, _, _ = standard(X, {0: 5, 5: 5})
+    out = {}
+    for mode in ("sharded", "single"):
+        set_seed(7)
+        m = GP_Plus(X, y, qual_dict={0: 5, 5: 5}, dtype=torch.float64, device=str(dev))
+        m.train()
+        mll = ExactMarginalLogLikelihood(m.likelihood, m)
+        cfg = {"group": None, "nb": nb} if mode == "sharded" else None
+        with settings.sharded_evaluation(cfg):
+            loss = -mll(m(*m.train_inputs), m.train_targets)
+            loss.backward()
+        out[mode] = torch.cat([loss.detach().reshape(1)] + [p.grad.reshape(-1) for p in m.parameters() if p.requires_grad]).cpu()
+    if rank == 0:
+        e = float((out["sharded"] - out["single"]).abs().max() / out["single"].abs().max())
+        print("RESULT " + json.dumps({"err": {"loss_and_grads": e}, "mll": float(out["single"][0]), "backend": dist.get_backend()}), flush=True)
+    print(f"RANK{rank} same_as_rank0=True", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    ngpu = torch.cuda.device_count()
+    one_each = ngpu >= world
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if one_each else 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl" if one_each else "gloo")
+    N, D, nb, kind, S, dU = (int(a) for a in sys.argv[1:7])
+    if len(sys.argv) > 7 and sys.argv[7] == "model":
+        return model_case(rank, world, dev, N, nb)
+    g = torch.Generator().manual_seed(1234)
+    U = torch.rand(N, D, generator=g, dtype=torch.float64)
+    y = torch.sin(3.0 * U[:, 0]) + U[:, 1] ** 2 + 0.05 * torch.randn(N, generator=g, dtype=torch.float64)
+    grp = (torch.arange(N) % S).to(torch.int32) if S > 1 else None
+    res = {}
+    for mode in ("sharded", "single"):
+        if mode == "single" and rank != 0:
+            continue
+        Ud = U.to(dev).requires_grad_(dU > 0)
+        w = torch.full((D,), 2.5, dtype=torch.float64, device=dev).requires_grad_(True)
+        sf2 = torch.tensor(0.8, dtype=torch.float64, device=dev).requires_grad_(True)
+        tau = torch.full((S,), 2e-3, dtype=torch.float64, device=dev)
+        tau = (tau * (1.0 + torch.arange(S, device=dev, dtype=torch.float64))).requires_grad_(True)
+        mean = torch.full((N,), 0.1, dtype=torch.float64, device=dev).requires_grad_(True)
+        spec = KernelSpec(w=w, sf2=sf2, kind=kind, d_split=2 if kind else 0)
+        cfg = {"group": None, "nb": nb} if mode == "sharded" else None
+        with settings.sharded_evaluation(cfg):
+            mll = exact_mll(Ud, spec, tau, mean, y.to(dev), grp=None if grp is None else grp.to(dev), n_grad_dims=dU)
+        mll.backward()
+        res[mode] = [mll.detach().cpu().reshape(1), w.grad.cpu(), sf2.grad.cpu().reshape(1), tau.grad.cpu(),
+                     mean.grad.cpu()] + ([Ud.grad.cpu()[:, :dU].reshape(-1)] if dU > 0 else [])
+    # every rank must hold the same sharded result
+    flat = torch.cat([t.reshape(-1) for t in res["sharded"]]).to(dev)
+    ref = flat.clone()
+    if dist.get_backend() == "nccl":
+        dist.broadcast(ref, 0)
+    else:
+        h = ref.cpu(); dist.broadcast(h, 0); ref = h.to(dev)
+    same = bool(torch.equal(flat, ref))
+    if rank == 0:
+        names = ["mll", "g_w", "g_sf2", "g_tau", "g_mean"] + (["g_U"] if dU > 0 else [])
+        err = {}
+        for n, a, b in zip(names, res["sharded"], res["single"]):
+            err[n] = float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
+        print("RESULT " + json.dumps({"err": err, "mll": float(res["single"][0]), "backend": dist.get_backend()}), flush=True)
+    print(f"RANK{rank} same_as_rank0={same}", flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
