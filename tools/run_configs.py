@@ -31,6 +31,7 @@ def theta(model, omega=-1.0):
 which = sys.argv[1:] or ['C1', 'C2', 'C3', 'C4', 'C5']
 dev = 'cuda'
 for c in which:
+    torch.manual_seed(0)  # the manifold matrices A are drawn from torch's RNG at construction
     if c == 'C1':
         X, y = borehole(n=10000, random_state=12345); X = torch.tensor(X[:500]); y = torch.tensor(y[:500]); X, _, _ = standard(X, {})
         m = GP_Plus(X, y, dtype=torch.float64, device=dev); reps = 20
