@@ -38,6 +38,20 @@ class ExactGP(GP):
             self.prediction_strategy = None
         return super().train(mode)
 
+    def _ensure_prediction_cache(self, **kwargs):
+        """Factor the training covariance once per eval() phase (gpytorch's prediction strategy caches)."""
+        from ..linalg import factorize
+
+        if self.prediction_strategy is None:
+            with torch.no_grad():
+                train_out = Module.__call__(self, *self.train_inputs, **kwargs)
+                cov = train_out.lazy_covariance_matrix
+                if not isinstance(cov, LazyKernelMatrix):
+                    raise RuntimeError("exact prediction needs the model's forward to return a lazy kernel covariance")
+                noisy = self.likelihood(train_out).lazy_covariance_matrix
+                self.prediction_strategy = factorize(cov.U1, cov.spec, noisy.tau, noisy.grp, train_out.mean, self.train_targets)
+        return self.prediction_strategy
+
     def __call__(self, *args, **kwargs):
         inputs = [a.unsqueeze(-1) if torch.is_tensor(a) and a.ndimension() == 1 else a for a in args]
         if self.training:
@@ -50,13 +64,7 @@ class ExactGP(GP):
         from ..linalg import factorize, predict_from_cache, cross_kernel
 
         with torch.no_grad():
-            if self.prediction_strategy is None:
-                train_out = Module.__call__(self, *self.train_inputs, **kwargs)
-                cov = train_out.lazy_covariance_matrix
-                if not isinstance(cov, LazyKernelMatrix):
-                    raise RuntimeError("exact prediction needs the model's forward to return a lazy kernel covariance")
-                noisy = self.likelihood(train_out).lazy_covariance_matrix
-                self.prediction_strategy = factorize(cov.U1, cov.spec, noisy.tau, noisy.grp, train_out.mean, self.train_targets)
+            self._ensure_prediction_cache(**kwargs)
             cache = self.prediction_strategy
             test_out = Module.__call__(self, *inputs, **kwargs)
             tcov = test_out.lazy_covariance_matrix

@@ -310,3 +310,42 @@ def test_matern_models_against_oracle(gpu_ctx, kclass, mixed):
     if not mixed:
         np.testing.assert_allclose(mean.cpu().numpy(), om.numpy(), rtol=RTOL_PRED, atol=1e-7)
         np.testing.assert_allclose(std.cpu().numpy(), os_.numpy(), rtol=RTOL_PRED, atol=1e-7)
+
+
+def test_loocv_and_noise_continuation(gpu_ctx):
+    """LOOCV error from the cached factorisation (+ gpp_lauum for diag(Ky^-1)) against dense numpy
+    algebra on the oracle's covariance, and the noise-continuation driver (optim/mll_noise_continuation.py:45-244)."""
+    from oracle.gp_oracle import OracleGP
+    from gpplus_amd.optim import MLLObjective, fit_model_continuation, loocv_rrmse
+    from gpplus_amd.utils import set_seed
+
+    fx = load("c1_borehole_n500.npz")
+    X, y = fx["Xtrain"][:160], fx["ytrain"][:160]
+    sub = {k: v for k, v in fx.items()}
+    sub["Xtrain"], sub["ytrain"] = X, y
+    m = build(sub, "theta1")
+    # LOOCV: e_i = (Ky^-1 r)_i / (Ky^-1)_ii on the oracle's dense covariance
+    o = OracleGP(X, y)
+    for k in list(o.params):
+        o.params[k] = torch.as_tensor(fx[f"theta1::param::{k}"], dtype=torch.float64)
+    with torch.no_grad():
+        mean, cov = o.forward(o.train_x)
+        Ky = (cov + torch.diag(o.noise_vector(o.train_x))).numpy()
+        r = (o.y_sc - mean).numpy()
+    Kinv = np.linalg.inv(Ky)
+    ref = float(np.sqrt(np.mean(((Kinv @ r) / np.diag(Kinv)) ** 2)))
+    got = loocv_rrmse(m)
+    assert abs(got - ref) <= 1e-7 * ref, (got, ref)
+
+    # continuation: noise fixed at each level, decreasing levels, model left at the best level's optimum
+    set_seed(5)
+    m.train()
+    nll, hist = fit_model_continuation(m, num_restarts=0, options={"maxiter": 15}, initial_noise_var=1.0, verbose=False)
+    assert not m.likelihood.raw_noise.requires_grad
+    levels = [float(v.reshape(-1)[0]) for v in hist["noise_history"]]
+    assert len(levels) >= 2 and all(a > b for a, b in zip(levels, levels[1:]))
+    assert len(hist["nll_history"]) == len(levels) == len(hist["optimization_history"]) and hist["loocv_history"][0] == "NLL"
+    assert nll == min(hist["nll_history"])
+    obj = MLLObjective(m, True, [0, 0])
+    f_now = obj.fun(obj.pack_parameters(), return_grad=False)
+    assert np.isfinite(f_now)
