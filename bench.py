@@ -221,7 +221,7 @@ def main():
             "config": {"workload": f"C2: synthetic Borehole (Sobol seed 0, unique rows, z-scored) N={N} d={D_C2} fp64, "
                                    "GP_Plus Rough_RBF exact GP at theta1, one replica per GPU (restart-parallel)",
                        "N": N, "d": D_C2, "loss": float(loss.item()), "streams_per_gpu": S},
-            "roofline": {"bound": "mfma", "kernel": "gpp_gemm_f64<2, 64, 64, 1, 1> (LAUUM: Kinv = Linv^T Linv, the one lower-triangular TN launch)",
+            "roofline": {"bound": "mfma", "kernel": "gpp_gemm_f64<2, 64, 64, 1, 16, 2> (LAUUM: Kinv = Linv^T Linv, the one lower-triangular TN launch)",
                          "achieved": lauum_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": lauum_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "B/launch",
                          "traffic_source": traffic_src,

@@ -85,10 +85,36 @@ hipError_t trsm_rec(const Ctx& c, int64_t c0, int64_t m, int64_t o, int64_t n) {
   return trsm_rec(c, c0, m, o + n1, n2);
 }
 
+// Right-looking factorisation of a block of up to BLK_MAX rows (every N below the look-ahead threshold, and the look-ahead's diagonal blocks) in steps of one leaf: leaf, ONE in-place panel solve over
+// all remaining columns, ONE rank-128 update of the remaining upper triangle (which stays in L2 at this size).  3 launches
+// per 128 rows where the recursion needs 4, and none of them narrower than the block: 0.70 -> 0.57 ms for 1024 rows, 3.4 -> 3.0 ms for 3968.
+constexpr int64_t BLK_MAX = 4096;
+hipError_t potrf_blk(const Ctx& c, int64_t o, int64_t n) {
+  for (int64_t j0 = 0; j0 < n; j0 += NBLK) {
+    const int64_t nb = std::min<int64_t>(NBLK, n - j0), oo = o + j0, rem = n - j0 - nb;
+    hipError_t e = gpp_launch_leaf(c.s, c.A + oo * c.ld + oo, c.ld, c.Li + oo * c.ldi + oo, c.ldi, (int)nb, c.info, (int)oo);
+    if (e != hipSuccess) return e;
+    if (rem == 0) break;
+    double* Bp = c.A + oo * c.ld + (oo + nb);  // block row oo, columns to the right of the leaf
+    GemmArgs g = mk(c.Li + oo * c.ldi + oo, c.ldi, Bp, c.ld, Bp, c.ld, nb, rem, nb, 1.0, 0.0);
+    g.a_mask = 1;
+    e = gpp_launch_gemm(c.s, 2, g, 1, NBLK, 32);
+    if (e != hipSuccess) return e;
+    GemmArgs u = mk(Bp, c.ld, Bp, c.ld, c.A + (oo + nb) * c.ld + (oo + nb), c.ld, rem, rem, nb, -1.0, 1.0);
+    u.c_lower = 2;
+    static const int ut = getenv("GPP_BLK_UPD_TILE") ? atoi(getenv("GPP_BLK_UPD_TILE")) : 32;  // K = 128: small tiles win (measured)
+    e = gpp_launch_gemm(c.s, 2, u, 1, ut, ut);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 hipError_t potrf_rec(const Ctx& c, int64_t o, int64_t n) {
   if (n <= 0) return hipSuccess;
   if (n <= NBLK)
     return gpp_launch_leaf(c.s, c.A + o * c.ld + o, c.ld, c.Li + o * c.ldi + o, c.ldi, (int)n, c.info, (int)o);
+  static const int64_t blk_max = getenv("GPP_BLK_MAX") ? atol(getenv("GPP_BLK_MAX")) : BLK_MAX;  // experiment knob
+  if (n <= blk_max) return potrf_blk(c, o, n);
   const int64_t n1 = split(n), n2 = n - n1;
   hipError_t e = potrf_rec(c, o, n1);
   if (e != hipSuccess) return e;
@@ -573,7 +599,9 @@ int gpp_gemm(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64
   if (c_tri < 0 || c_tri > 2 || (c_tri && M != N)) return -19;
   GemmArgs g = mk(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta);
   g.a_mask = a_mask; g.b_mask = b_mask; g.klo_mode = klo_mode; g.khi_mode = khi_mode; g.c_lower = c_tri;
-  GPP_TRY(gpp_launch_gemm(h->stream, variant, g, 1));
+  int ftm = 0, ftn = 0;
+  if (const char* e = getenv("GPP_GEMM_TILE")) sscanf(e, "%d,%d", &ftm, &ftn);  // dev knob (tools/gemm_small_probe.py)
+  GPP_TRY(gpp_launch_gemm(h->stream, variant, g, 1, ftm, ftn));
   return 0;
 }
 

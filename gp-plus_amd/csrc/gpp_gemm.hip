@@ -23,15 +23,15 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 namespace {
 
-constexpr int BK = 16;
+constexpr int BK16 = 16;  // K chunk of the big tile and of every k-contiguous ("KC") operand
 // LDS layouts.  Row-contiguous operands ("MC", stored [k][row] in memory) are staged as [k][T+16]: 16-byte aligned
 // rows for ds_write_b128, and the two k-rows a 32-lane ds_read_b64 group touches fall in different bank halves.
 // k-contiguous operands ("KC", stored [row][k]) are staged UNtransposed as [row][18]: every thread writes its 16-byte
 // vector with one ds_write_b128 (8 lanes = one 128-byte row), and with the 144-byte row stride both fragment reads
 // are conflict free: A lanes (i=0..3, k, k+1) hit slots {18i + k}, B lanes (c=0..15, k, k+1) hit 18c + k mod 32,
 // which enumerates all 32 8-byte slots.
-constexpr int ldt_mc(int T) { return T + 16; }
-constexpr int LDK = BK + 2;  // [row][k] chunks of k-contiguous operands: 144-byte rows, see below
+constexpr int ldt_mc(int T, int BK = 16) { return BK == 16 ? T + 16 : T + 4; }
+constexpr int LDK = BK16 + 2;  // [row][k] chunks of k-contiguous operands: 144-byte rows, see below
 
 // Staging is split in two so that the global loads of chunk c+1 stay in flight across the MFMAs of chunk c:
 //   load_*  : computes the keep-predicates (range + triangular mask; no loaded data involved) and issues one
@@ -39,7 +39,9 @@ constexpr int LDK = BK + 2;  // [row][k] chunks of k-contiguous operands: 144-by
 //             double past kend/R stays inside the allocation: ld is even and >= the extent (gpp.h).
 //   store_* : after the MFMAs, zeroes the dropped elements by select and writes the chunk to LDS.
 __device__ __forceinline__ bool keep_elem(int mask, int k, int row) {
-  return mask == 0 || (mask == 1 ? k <= row : k >= row);
+  // bitwise on purpose: no short-circuit branches between the loads of a chunk (a branch ends the basic block, and
+  // hipcc then waits for the loads issued so far: the 20 vectors of a 128-row chunk arrived one L2 trip at a time)
+  return (mask == 0) | ((mask == 1) & (k <= row)) | ((mask == 2) & (k >= row));
 }
 
 // Operand stored [row][k] (k contiguous): T rows x 16 k per chunk, T/32 16-byte vectors per thread.
@@ -47,19 +49,21 @@ template <int T>
 __device__ __forceinline__ unsigned load_kc(const double* __restrict__ P, int64_t ld, int R, int r0, int kb, int kend,
                                             int mask, int tid, v2d (&reg)[T / 32]) {
   unsigned keep = 0;
+  const double* ptr[T / 32];
 #pragma unroll
   for (int i = 0; i < T / 32; ++i) {
     const int v = tid + 256 * i;
     const int gr = r0 + (v >> 3);
     const int gk = kb + ((v & 7) << 1);
-    const bool v0 = (gr < R) && (gk < kend);
-    const bool k0 = v0 && keep_elem(mask, gk, gr);
-    const bool k1 = v0 && (gk + 1 < kend) && keep_elem(mask, gk + 1, gr);
+    const bool v0 = (gr < R) & (gk < kend);
+    const bool k0 = v0 & keep_elem(mask, gk, gr);
+    const bool k1 = v0 & (gk + 1 < kend) & keep_elem(mask, gk + 1, gr);
     keep |= (k0 ? 1u : 0u) << (2 * i);
     keep |= (k1 ? 1u : 0u) << (2 * i + 1);
-    const double* p = v0 ? P + (int64_t)gr * ld + gk : P;
-    reg[i] = *reinterpret_cast<const v2d*>(p);
+    ptr[i] = v0 ? P + (int64_t)gr * ld + gk : P;
   }
+#pragma unroll
+  for (int i = 0; i < T / 32; ++i) reg[i] = *reinterpret_cast<const v2d*>(ptr[i]);
   return keep;
 }
 template <int T, bool SEL>
@@ -76,37 +80,40 @@ __device__ __forceinline__ void store_kc(double* __restrict__ s, int tid, const 
   }
 }
 
-// Operand stored [k][row] (row contiguous): 16 k x T rows per chunk.
-template <int T>
+// Operand stored [k][row] (row contiguous): BK k x T rows per chunk, BK * T / 512 16-byte vectors per thread.
+template <int T, int BK>
 __device__ __forceinline__ unsigned load_mc(const double* __restrict__ P, int64_t ld, int R, int r0, int kb, int kend,
-                                            int mask, int tid, v2d (&reg)[T / 32]) {
+                                            int mask, int tid, v2d (&reg)[BK * T / 512]) {
+  constexpr int NV = BK * T / 512;
   unsigned keep = 0;
+  const double* ptr[NV];
 #pragma unroll
-  for (int i = 0; i < T / 32; ++i) {
+  for (int i = 0; i < NV; ++i) {
     const int v = tid + 256 * i;
     const int gk = kb + v / (T / 2);
     const int gr = r0 + ((v % (T / 2)) << 1);
-    const bool v0 = (gk < kend) && (gr < R);
-    const bool k0 = v0 && keep_elem(mask, gk, gr);
-    const bool k1 = v0 && (gr + 1 < R) && keep_elem(mask, gk, gr + 1);
+    const bool v0 = (gk < kend) & (gr < R);
+    const bool k0 = v0 & keep_elem(mask, gk, gr);
+    const bool k1 = v0 & (gr + 1 < R) & keep_elem(mask, gk, gr + 1);
     keep |= (k0 ? 1u : 0u) << (2 * i);
     keep |= (k1 ? 1u : 0u) << (2 * i + 1);
-    const double* p = v0 ? P + (int64_t)gk * ld + gr : P;
-    reg[i] = *reinterpret_cast<const v2d*>(p);
+    ptr[i] = v0 ? P + (int64_t)gk * ld + gr : P;
   }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) reg[i] = *reinterpret_cast<const v2d*>(ptr[i]);  // all requests back to back
   return keep;
 }
-template <int T, bool SEL>
-__device__ __forceinline__ void store_mc(double* __restrict__ s, int tid, const v2d (&reg)[T / 32], unsigned keep) {
+template <int T, int BK, bool SEL>
+__device__ __forceinline__ void store_mc(double* __restrict__ s, int tid, const v2d (&reg)[BK * T / 512], unsigned keep) {
 #pragma unroll
-  for (int i = 0; i < T / 32; ++i) {
+  for (int i = 0; i < BK * T / 512; ++i) {
     const int v = tid + 256 * i;
     v2d t = reg[i];
     if (SEL) {
       t.x = ((keep >> (2 * i)) & 1u) ? t.x : 0.0;
       t.y = ((keep >> (2 * i + 1)) & 1u) ? t.y : 0.0;
     }
-    *reinterpret_cast<v2d*>(s + (v / (T / 2)) * ldt_mc(T) + ((v % (T / 2)) << 1)) = t;
+    *reinterpret_cast<v2d*>(s + (v / (T / 2)) * ldt_mc(T, BK) + ((v % (T / 2)) << 1)) = t;
   }
 }
 
@@ -115,26 +122,45 @@ __device__ __forceinline__ void store_mc(double* __restrict__ s, int tid, const 
 // test), staging needs no predicates at all: one load per vector from  uniform_base + per-thread 32-bit byte offset
 // (SGPR-base addressing), and plain LDS stores.  This removes ~3/4 of the VALU instructions that otherwise compete
 // with the MFMAs for the SIMD's issue port.
-template <int T>
+template <int T, int BK>
 __device__ __forceinline__ bool chunk_is_interior(int r0, int R, int kb, int kend, int mask) {
   if (r0 + T > R || kb + BK > kend) return false;
   if (mask == 1) return kb + BK - 1 <= r0;      // keep k <= row holds for every row >= r0
   if (mask == 2) return kb >= r0 + T - 1;       // keep k >= row holds for every row <  r0 + T
   return true;
 }
-template <int T, bool KC>
-__device__ __forceinline__ void thread_offsets(int64_t ld, int tid, unsigned (&off)[T / 32]) {
+// In-range chunk of a row-contiguous operand that the triangular mask cuts: same lean loads as an interior chunk, the
+// keep bits come from the indices alone.
+template <int T, int BK>
+__device__ __forceinline__ bool chunk_in_range(int r0, int R, int kb, int kend) {
+  return r0 + T <= R && kb + BK <= kend;
+}
+template <int T, int BK>
+__device__ __forceinline__ unsigned mask_bits_mc(int r0, int kb, int mask, int tid) {
+  unsigned keep = 0;
 #pragma unroll
-  for (int i = 0; i < T / 32; ++i) {
+  for (int i = 0; i < BK * T / 512; ++i) {
+    const int v = tid + 256 * i;
+    const int gk = kb + v / (T / 2);
+    const int gr = r0 + ((v % (T / 2)) << 1);
+    keep |= (keep_elem(mask, gk, gr) ? 1u : 0u) << (2 * i);
+    keep |= (keep_elem(mask, gk, gr + 1) ? 1u : 0u) << (2 * i + 1);
+  }
+  return keep;
+}
+template <int T, bool KC, int BK>
+__device__ __forceinline__ void thread_offsets(int64_t ld, int tid, unsigned (&off)[BK * T / 512]) {
+#pragma unroll
+  for (int i = 0; i < BK * T / 512; ++i) {
     const int v = tid + 256 * i;
     if (KC) off[i] = (unsigned)(((int64_t)(v >> 3) * ld + ((v & 7) << 1)) * 8);
     else off[i] = (unsigned)(((int64_t)(v / (T / 2)) * ld + ((v % (T / 2)) << 1)) * 8);
   }
 }
-template <int T>
-__device__ __forceinline__ void load_fast(const double* __restrict__ ubase, const unsigned (&off)[T / 32], v2d (&reg)[T / 32]) {
+template <int NV>
+__device__ __forceinline__ void load_fast(const double* __restrict__ ubase, const unsigned (&off)[NV], v2d (&reg)[NV]) {
 #pragma unroll
-  for (int i = 0; i < T / 32; ++i)
+  for (int i = 0; i < NV; ++i)
     reg[i] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(ubase) + off[i]);
 }
 
@@ -142,21 +168,24 @@ __device__ __forceinline__ void load_fast(const double* __restrict__ ubase, cons
 // variants with a k-contiguous operand are off the hot path (prediction, tests) and take the registers they need.
 // TAG only changes the kernel's NAME: the single N^3/3-flop LAUUM launch runs as <2,64,64,1> so that profilers report
 // it on its own line (the roofline entry of bench.py), apart from the ~1300 launches of the recursions.
-// PF = number of K chunks whose global loads are in flight at once (register-staged).  The big tile keeps PF = 1: its
-// MFMA phase (64 accumulators per lane, 2 work-groups per CU) already covers a load round trip.  The small tiles of
-// the recursions' leaves have almost no MFMA work per chunk, so with PF = 1 every chunk costs one full memory round
-// trip (~0.6 us from L2).  Measured on MI355X with PF = 4 / 8 on the small tiles: no gain (hipcc turns the predicated
-// loads of those variants into branchy code whose waits are not exact), so every launch currently uses PF = 1.
-template <int VAR, int WTM, int WTN, int TAG = 0, int PF = 1>
-__global__ __launch_bounds__(256, (VAR == 2 || WTM < 64) ? 2 : 1) void gpp_gemm_f64(GemmArgs p) {
+// BK = K chunk, NBUF = LDS buffers per operand.  The big tile runs (16, 2): its MFMA phase (64 accumulators per lane,
+// 2 work-groups per CU) covers a load round trip and one barrier per chunk suffices.  The small tiles of the recursions'
+// leaves have almost no MFMA work per 16-wide chunk, so every chunk cost one full L2 round trip (~0.6 us: a K = 128
+// product took 8-20 us); they run (64, 1): four times fewer round trips, the next chunk's loads in flight in
+// registers during the MFMAs, two barriers per chunk.  (k-contiguous operands, VAR != 2, only exist with BK = 16.)
+template <int VAR, int WTM, int WTN, int TAG = 0, int BK = 16, int NBUF = 2>
+__global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM < 64) ? 2 : 1) void gpp_gemm_f64(GemmArgs p) {
+  static_assert(BK == 16 || VAR == 2, "wide K chunks are implemented for row-contiguous (TN) operands only");
+  static_assert(BK % 16 == 0 && (NBUF == 1 || NBUF == 2), "bad staging parameters");
   constexpr bool A_KC = (VAR != 2);
   constexpr bool B_KC = (VAR == 0);
   constexpr int TM = 2 * WTM, TN = 2 * WTN;  // work-group tile: TM rows x TN columns (2 x 2 waves)
-  constexpr int LDA = ldt_mc(TM), LDB = ldt_mc(TN);  // strides of [k][row] chunks (MC operands)
+  constexpr int LDA = ldt_mc(TM, BK), LDB = ldt_mc(TN, BK);  // strides of [k][row] chunks (MC operands)
   constexpr int TX = TM > TN ? TM : TN;
-  constexpr int OPSZ = (BK * ldt_mc(TX) > TX * LDK) ? BK * ldt_mc(TX) : TX * LDK;  // doubles per staged operand chunk
+  constexpr int OPSZ = (BK * ldt_mc(TX, BK) > TX * LDK) ? BK * ldt_mc(TX, BK) : TX * LDK;  // doubles per staged chunk
+  constexpr int NVA = BK * TM / 512, NVB = BK * TN / 512;  // 16-byte vectors per thread and chunk
   constexpr int RB = WTM / 4, CB = WTN / 16;
-  __shared__ __attribute__((aligned(16))) double smem[2 * 2 * OPSZ];
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // NBUF * 2 * OPSZ doubles (see gemm_lds_bytes)
 
   int tm, tn;
   if (p.swz) {
@@ -219,99 +248,98 @@ __global__ __launch_bounds__(256, (VAR == 2 || WTM < 64) ? 2 : 1) void gpp_gemm_
 #pragma unroll
     for (int b = 0; b < CB; ++b) acc[a][b] = 0.0;
 
-  v2d ra[PF][TM / 32], rb[PF][TN / 32];
-  unsigned ka[PF], kb_[PF];
-  bool fast[PF];
-  unsigned offa[TM / 32], offb[TN / 32];
-  thread_offsets<TM, A_KC>(p.lda, tid, offa);
-  thread_offsets<TN, B_KC>(p.ldb, tid, offb);
+  v2d ra[NVA], rb[NVB];
+  unsigned ka = 0, kb_ = 0;
+  unsigned offa[NVA], offb[NVB];
+  thread_offsets<TM, A_KC, BK>(p.lda, tid, offa);
+  thread_offsets<TN, B_KC, BK>(p.ldb, tid, offb);
   // uniform bases of the tile's first chunk row/column block; advanced by a scalar per chunk
   const double* __restrict__ ubaseA = A_KC ? A + (int64_t)row0 * p.lda : A + row0;
   const double* __restrict__ ubaseB = B_KC ? B + (int64_t)col0 * p.ldb : B + col0;
   const int64_t stepA = A_KC ? 1 : p.lda, stepB = B_KC ? 1 : p.ldb;  // elements per unit of k
 
-  // (the lean path is enabled for the row-contiguous TN variant only: with a k-contiguous operand the extra live
-  //  registers push hipcc over the 256-VGPR budget of 2 waves/SIMD and the spills cost more than the VALU saved)
-#define GPP_STAGE_LOAD(slot, kb)                                                                                   \
-  do {                                                                                                             \
-    const int kb__ = (kb);                                                                                         \
-    fast[slot] = (VAR == 2) && chunk_is_interior<TM>(row0, p.M, kb__, khi, p.a_mask) &&                            \
-                 chunk_is_interior<TN>(col0, p.N, kb__, khi, p.b_mask);                                            \
-    if (fast[slot]) {                                                                                              \
-      load_fast<TM>(ubaseA + (int64_t)kb__ * stepA, offa, ra[slot]);                                               \
-      load_fast<TN>(ubaseB + (int64_t)kb__ * stepB, offb, rb[slot]);                                               \
-    } else {                                                                                                       \
-      ka[slot] = A_KC ? load_kc<TM>(A, p.lda, p.M, row0, kb__, khi, p.a_mask, tid, ra[slot])                       \
-                      : load_mc<TM>(A, p.lda, p.M, row0, kb__, khi, p.a_mask, tid, ra[slot]);                      \
-      kb_[slot] = B_KC ? load_kc<TN>(B, p.ldb, p.N, col0, kb__, khi, p.b_mask, tid, rb[slot])                      \
-                       : load_mc<TN>(B, p.ldb, p.N, col0, kb__, khi, p.b_mask, tid, rb[slot]);                     \
-    }                                                                                                              \
-  } while (0)
-#define GPP_STAGE_STORE(slot, da, db)                                                                              \
-  do {                                                                                                             \
-    if (fast[slot]) {                                                                                              \
-      if (A_KC) store_kc<TM, false>(da, tid, ra[slot], 0); else store_mc<TM, false>(da, tid, ra[slot], 0);         \
-      if (B_KC) store_kc<TN, false>(db, tid, rb[slot], 0); else store_mc<TN, false>(db, tid, rb[slot], 0);         \
-    } else {                                                                                                       \
-      if (A_KC) store_kc<TM, true>(da, tid, ra[slot], ka[slot]); else store_mc<TM, true>(da, tid, ra[slot], ka[slot]); \
-      if (B_KC) store_kc<TN, true>(db, tid, rb[slot], kb_[slot]); else store_mc<TN, true>(db, tid, rb[slot], kb_[slot]); \
-    }                                                                                                              \
-  } while (0)
-
-  // chunk c covers k in [kpos(c), kpos(c)+16).  With k_reverse the chunks run from the top of the range down, so that
-  // tiles whose ranges END together (klo differs per column tile, e.g. X^T * lower-triangular) sweep the shared
-  // operand in lockstep and hit in L2 instead of each streaming its own k rows.  Requests past the last chunk re-read
-  // the last chunk (never used): every path then issues the same number of loads and the compiler's vmcnt waits
-  // stay exact.
-  auto kpos = [&](int c) {
-    c = c < nch ? c : nch - 1;
-    return p.k_reverse ? klo + (nch - 1 - c) * BK : klo + c * BK;
+  // Per operand and chunk, work-group uniform: 0 = edge (predicated loads, select on store), 1 = interior (lean loads,
+  // plain stores), 2 = in range but cut by the triangular mask (lean loads, select on store).  The lean paths exist for
+  // the row-contiguous TN variant only: with a k-contiguous operand the extra live registers push hipcc over the
+  // 256-VGPR budget of 2 waves/SIMD and the spills cost more than the VALU saved.
+  int pa = 0, pb = 0;
+  auto stage_load = [&](int kb) {
+    pa = pb = 0;
+    if constexpr (VAR == 2) {
+      if (chunk_in_range<TM, BK>(row0, p.M, kb, khi)) pa = chunk_is_interior<TM, BK>(row0, p.M, kb, khi, p.a_mask) ? 1 : 2;
+      if (chunk_in_range<TN, BK>(col0, p.N, kb, khi)) pb = chunk_is_interior<TN, BK>(col0, p.N, kb, khi, p.b_mask) ? 1 : 2;
+    }
+    if (pa) {
+      load_fast<NVA>(ubaseA + (int64_t)kb * stepA, offa, ra);
+      if (pa == 2) ka = mask_bits_mc<TM, BK>(row0, kb, p.a_mask, tid);
+    } else {
+      if constexpr (A_KC) ka = load_kc<TM>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra);
+      else ka = load_mc<TM, BK>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra);
+    }
+    if (pb) {
+      load_fast<NVB>(ubaseB + (int64_t)kb * stepB, offb, rb);
+      if (pb == 2) kb_ = mask_bits_mc<TN, BK>(col0, kb, p.b_mask, tid);
+    } else {
+      if constexpr (B_KC) kb_ = load_kc<TN>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb);
+      else kb_ = load_mc<TN, BK>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb);
+    }
   };
+  auto stage_store = [&](double* da, double* db) {
+    if (pa == 1) {
+      if constexpr (A_KC) store_kc<TM, false>(da, tid, ra, 0); else store_mc<TM, BK, false>(da, tid, ra, 0);
+    } else {
+      if constexpr (A_KC) store_kc<TM, true>(da, tid, ra, ka); else store_mc<TM, BK, true>(da, tid, ra, ka);
+    }
+    if (pb == 1) {
+      if constexpr (B_KC) store_kc<TN, false>(db, tid, rb, 0); else store_mc<TN, BK, false>(db, tid, rb, 0);
+    } else {
+      if constexpr (B_KC) store_kc<TN, true>(db, tid, rb, kb_); else store_mc<TN, BK, true>(db, tid, rb, kb_);
+    }
+  };
+
+  // chunk c covers k in [kpos(c), kpos(c)+BK).  With k_reverse the chunks run from the top of the range down, so that
+  // tiles whose ranges END together (klo differs per column tile, e.g. X^T * lower-triangular) sweep the shared
+  // operand in lockstep and hit in L2 instead of each streaming its own k rows.
+  auto kpos = [&](int c) { return p.k_reverse ? klo + (nch - 1 - c) * BK : klo + c * BK; };
   if (nch > 0) {
-#pragma unroll
-    for (int u = 0; u < PF; ++u) GPP_STAGE_LOAD(u, kpos(u));
-    GPP_STAGE_STORE(0, smem, smem + OPSZ);
+    stage_load(kpos(0));
+    stage_store(smem, smem + OPSZ);
   }
   __syncthreads();
 
-  // Iteration c: request chunk c+PF into the register slot chunk c just left, multiply chunk c from LDS, move chunk
-  // c+1 (requested PF-1 iterations ago) from registers to the other LDS buffer.  Unrolled by PF so slots are static.
-  for (int c0 = 0; c0 < nch; c0 += PF) {
+  for (int c = 0; c < nch; ++c) {
+    const int cur = (NBUF == 2) ? (c & 1) : 0;
+    const bool more = (c + 1 < nch);
+    if (more) stage_load(kpos(c + 1));
+    // A fragment: lane (i = l&3, k = l>>4), same address in the 4 column groups (l>>2)&3 -> LDS broadcast
+    const double* sa = smem + (cur * 2 + 0) * OPSZ + (A_KC ? (wm + (lane & 3)) * LDK + lk : wm + (lane & 3) + lk * LDA);
+    const double* sb = smem + (cur * 2 + 1) * OPSZ + (B_KC ? (wn + li) * LDK + lk : wn + li + lk * LDB);
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int c = c0 + u;
-      if (c >= nch) break;
-      const int cur = c & 1;
-      const bool more = (c + 1 < nch);
-      if (PF > 1 || more) GPP_STAGE_LOAD(u, kpos(c + PF));
-      // A fragment: lane (i = l&3, k = l>>4), same address in the 4 column groups (l>>2)&3 -> LDS broadcast
-      const double* sa = smem + (cur * 2 + 0) * OPSZ + (A_KC ? (wm + (lane & 3)) * LDK + lk : wm + (lane & 3) + lk * LDA);
-      const double* sb = smem + (cur * 2 + 1) * OPSZ + (B_KC ? (wn + li) * LDK + lk : wn + li + lk * LDB);
+    for (int kk = 0; kk < BK / 4; ++kk) {
+      double bf[CB];
 #pragma unroll
-      for (int kk = 0; kk < BK / 4; ++kk) {
-        double bf[CB];
+      for (int b = 0; b < CB; ++b) bf[b] = B_KC ? sb[16 * b * LDK + kk * 4] : sb[kk * 4 * LDB + 16 * b];
+      // A fragments in groups of <= 8 row blocks: bounds the live registers (acc + staging already take ~170)
+      constexpr int AG = RB < 8 ? RB : 8;
 #pragma unroll
-        for (int b = 0; b < CB; ++b) bf[b] = B_KC ? sb[16 * b * LDK + kk * 4] : sb[kk * 4 * LDB + 16 * b];
-        // A fragments in groups of <= 8 row blocks: bounds the live registers (acc + staging already take ~170)
-        constexpr int AG = RB < 8 ? RB : 8;
+      for (int a0 = 0; a0 < RB; a0 += AG) {
+        double af[AG];
 #pragma unroll
-        for (int a0 = 0; a0 < RB; a0 += AG) {
-          double af[AG];
+        for (int a = 0; a < AG; ++a) af[a] = A_KC ? sa[4 * (a0 + a) * LDK + kk * 4] : sa[kk * 4 * LDA + 4 * (a0 + a)];
 #pragma unroll
-          for (int a = 0; a < AG; ++a) af[a] = A_KC ? sa[4 * (a0 + a) * LDK + kk * 4] : sa[kk * 4 * LDA + 4 * (a0 + a)];
+        for (int a = 0; a < AG; ++a)
 #pragma unroll
-          for (int a = 0; a < AG; ++a)
-#pragma unroll
-            for (int b = 0; b < CB; ++b)
-              acc[a0 + a][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[b], acc[a0 + a][b], 0, 0, 0);
-        }
+          for (int b = 0; b < CB; ++b)
+            acc[a0 + a][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[b], acc[a0 + a][b], 0, 0, 0);
       }
-      if (more) GPP_STAGE_STORE((u + 1) % PF, smem + ((cur ^ 1) * 2 + 0) * OPSZ, smem + ((cur ^ 1) * 2 + 1) * OPSZ);
-      __syncthreads();
     }
+    if (NBUF == 1) __syncthreads();  // everyone has read this chunk: the single buffer may take the next one
+    if (more) {
+      const int nxt = (NBUF == 2) ? (cur ^ 1) : 0;
+      stage_store(smem + (nxt * 2 + 0) * OPSZ, smem + (nxt * 2 + 1) * OPSZ);
+    }
+    __syncthreads();
   }
-#undef GPP_STAGE_LOAD
-#undef GPP_STAGE_STORE
 
   // epilogue: slab (a,b) holds C[row0+wm+4a+(l>>4)][col0+wn+16b+(l&15)].  The beta path first issues all C loads of a
   // group of slabs (clamped addresses, no branches around loads) and only then combines and stores.
@@ -351,19 +379,41 @@ __global__ __launch_bounds__(256, (VAR == 2 || WTM < 64) ? 2 : 1) void gpp_gemm_
   }
 }
 
-#ifndef GPP_PF_SMALL
-#define GPP_PF_SMALL 1
+// LDS bytes of an instantiation (dynamic: the wide-chunk variants exceed the 64 KiB static limit)
+constexpr size_t gemm_lds_bytes(int var, int tm, int tn, int bk, int nbuf) {
+  const int tx = tm > tn ? tm : tn;
+  const int mc = bk * ldt_mc(tx, bk), kc = tx * LDK;
+  return (size_t)nbuf * 2 * ((var != 2 && kc > mc) ? kc : mc) * sizeof(double);
+}
+template <int VAR, int WTM, int WTN, int TAG, int BK, int NBUF>
+hipError_t launch_inst(hipStream_t s, dim3 grid, const GemmArgs& a) {
+  constexpr size_t bytes = gemm_lds_bytes(VAR, 2 * WTM, 2 * WTN, BK, NBUF);
+  auto* fn = gpp_gemm_f64<VAR, WTM, WTN, TAG, BK, NBUF>;
+  if (bytes > 48 * 1024) {
+    static bool attr_set = false;  // per instantiation
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e != hipSuccess) return e;
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), bytes, s, a);
+  return hipGetLastError();
+}
+// small tiles: wide K chunks for the row-contiguous variant, the classic staging otherwise
+#ifndef GPP_SMALL_BK
+#define GPP_SMALL_BK 64
 #endif
 template <int VAR>
 hipError_t launch_var(hipStream_t s, int tm, int tn, dim3 grid, const GemmArgs& a) {
-  if (tm == 128 && tn == 128 && a.tag == 1 && VAR == 2)
-    hipLaunchKernelGGL((gpp_gemm_f64<2, 64, 64, 1>), grid, dim3(256), 0, s, a);
-  else if (tm == 128 && tn == 128) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 64, 64>), grid, dim3(256), 0, s, a);
-  else if (tm == 64 && tn == 64) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 32, 32, 0, GPP_PF_SMALL>), grid, dim3(256), 0, s, a);
-  else if (tm == 32 && tn == 32) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 16, 16, 0, GPP_PF_SMALL>), grid, dim3(256), 0, s, a);
-  else if (tm == 128 && tn == 32) hipLaunchKernelGGL((gpp_gemm_f64<VAR, 64, 16, 0, GPP_PF_SMALL>), grid, dim3(256), 0, s, a);
-  else return hipErrorInvalidValue;
-  return hipGetLastError();
+  constexpr int SBK = (VAR == 2) ? GPP_SMALL_BK : 16;
+  constexpr int SNB = (VAR == 2 && GPP_SMALL_BK > 16) ? 1 : 2;
+  if (tm == 128 && tn == 128 && a.tag == 1 && VAR == 2) return launch_inst<2, 64, 64, 1, 16, 2>(s, grid, a);
+  if (tm == 128 && tn == 128) return launch_inst<VAR, 64, 64, 0, 16, 2>(s, grid, a);
+  if (tm == 64 && tn == 64) return launch_inst<VAR, 32, 32, 0, SBK, SNB>(s, grid, a);
+  if (tm == 32 && tn == 32) return launch_inst<VAR, 16, 16, 0, SBK, SNB>(s, grid, a);
+  if (tm == 128 && tn == 32) return launch_inst<VAR, 64, 16, 0, SBK, SNB>(s, grid, a);
+  return hipErrorInvalidValue;
 }
 
 }  // namespace
