@@ -23,6 +23,9 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 namespace {
 
+#ifndef GPP_PIPE_FRAGS
+#define GPP_PIPE_FRAGS 0
+#endif
 constexpr int BK16 = 16;  // K chunk of the big tile and of every k-contiguous ("KC") operand
 // LDS layouts.  Row-contiguous operands ("MC", stored [k][row] in memory) are staged as [k][T+16]: 16-byte aligned
 // rows for ds_write_b128, and the two k-rows a 32-lane ds_read_b64 group touches fall in different bank halves.
@@ -307,13 +310,38 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
   }
   __syncthreads();
 
-  for (int c = 0; c < nch; ++c) {
-    const int cur = (NBUF == 2) ? (c & 1) : 0;
-    const bool more = (c + 1 < nch);
-    if (more) stage_load(kpos(c + 1));
+  auto compute = [&](int cur) {
     // A fragment: lane (i = l&3, k = l>>4), same address in the 4 column groups (l>>2)&3 -> LDS broadcast
     const double* sa = smem + (cur * 2 + 0) * OPSZ + (A_KC ? (wm + (lane & 3)) * LDK + lk : wm + (lane & 3) + lk * LDA);
     const double* sb = smem + (cur * 2 + 1) * OPSZ + (B_KC ? (wn + li) * LDK + lk : wn + li + lk * LDB);
+    if constexpr (VAR == 2 && RB == 16 && CB == 4 && BK == 16 && GPP_PIPE_FRAGS) {
+      // Big tile: 16 phases per chunk (4 k-steps x 4 groups of 4 row blocks), each 4 A fragment reads and 16 MFMAs.
+      // The A fragments of phase ph+1 (and, two phases ahead of a new k-step, its B fragments) are requested before the
+      // MFMAs of phase ph into the other register set, so no LDS latency sits between two MFMA groups (+8 VGPRs).
+      double afr[2][4], bfr[2][4];
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bfr[0][b] = sb[16 * b];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) afr[0][a] = sa[4 * a];
+#pragma unroll
+      for (int ph = 0; ph < 16; ++ph) {
+        const int kk = ph >> 2, g = ph & 3;
+        if (ph + 1 < 16) {
+          const int kn = (ph + 1) >> 2, gn = (ph + 1) & 3;
+#pragma unroll
+          for (int a = 0; a < 4; ++a) afr[(ph + 1) & 1][a] = sa[kn * 4 * LDA + 4 * (4 * gn + a)];
+        }
+        if (g == 1 && kk + 1 < 4) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) bfr[(kk + 1) & 1][b] = sb[(kk + 1) * 4 * LDB + 16 * b];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b)
+            acc[4 * g + a][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(afr[ph & 1][a], bfr[kk & 1][b], acc[4 * g + a][b], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
       double bf[CB];
@@ -333,13 +361,63 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
             acc[a0 + a][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[b], acc[a0 + a][b], 0, 0, 0);
       }
     }
+    }
+  };
+
+  // Chunks whose loads are interior for BOTH operands form one contiguous range of k (each operand's condition is an
+  // interval in kb).  Iterations that prefetch such a chunk run a branch-free body (lean loads, plain stores): one basic
+  // block, so the compiler can spread the memory instructions over the MFMAs and the wave spends no issue slots on
+  // the path selection (~100 scalar instructions per chunk).
+  int ca = 0, cb = 0;  // clean iterations: ca <= c < cb
+  // (big tile only: the small tiles run a handful of chunks per launch and lose more to the second loop's code)
+  constexpr bool SPLIT = (VAR == 2 && RB == 16 && CB == 4 && BK == 16);
+  if constexpr (SPLIT) {
+    if (row0 + TM <= p.M && col0 + TN <= p.N && nch > 1) {
+      int k_lo = klo, k_hi = khi;  // chunk [kb, kb+BK) is interior iff k_lo <= kb and kb + BK <= k_hi
+      if (p.a_mask == 1) k_hi = min(k_hi, row0 + 1);
+      if (p.a_mask == 2) k_lo = max(k_lo, row0 + TM - 1);
+      if (p.b_mask == 1) k_hi = min(k_hi, col0 + 1);
+      if (p.b_mask == 2) k_lo = max(k_lo, col0 + TN - 1);
+      // chunk positions are klo + j*BK, j = c (forward) or nch-1-c (reverse)
+      int j_lo = (k_lo - klo + BK - 1) / BK, j_hi = (k_hi - klo) / BK;  // interior positions j_lo <= j < j_hi
+      j_lo = max(j_lo, 0);
+      j_hi = min(j_hi, nch);
+      if (j_hi > j_lo) {
+        const int ci_lo = p.k_reverse ? nch - j_hi : j_lo, ci_hi = p.k_reverse ? nch - j_lo : j_hi;  // chunk indices
+        ca = max(ci_lo - 1, 0);          // iteration c prefetches chunk c + 1
+        cb = min(ci_hi - 1, nch - 1);
+        if (cb < ca) ca = cb = 0;
+      }
+    }
+  }
+  auto general_iter = [&](int c) {
+    const int cur = (NBUF == 2) ? (c & 1) : 0;
+    const bool more = (c + 1 < nch);
+    if (more) stage_load(kpos(c + 1));
+    compute(cur);
     if (NBUF == 1) __syncthreads();  // everyone has read this chunk: the single buffer may take the next one
     if (more) {
       const int nxt = (NBUF == 2) ? (cur ^ 1) : 0;
       stage_store(smem + (nxt * 2 + 0) * OPSZ, smem + (nxt * 2 + 1) * OPSZ);
     }
     __syncthreads();
+  };
+  int c = 0;
+  for (; c < ca; ++c) general_iter(c);
+  if constexpr (SPLIT) {
+    for (; c < cb; ++c) {
+      const int cur = (NBUF == 2) ? (c & 1) : 0, nxt = (NBUF == 2) ? (cur ^ 1) : 0;
+      const int kb = kpos(c + 1);
+      load_fast<NVA>(ubaseA + (int64_t)kb * stepA, offa, ra);
+      load_fast<NVB>(ubaseB + (int64_t)kb * stepB, offb, rb);
+      compute(cur);
+      if (NBUF == 1) __syncthreads();
+      store_mc<TM, BK, false>(smem + (nxt * 2 + 0) * OPSZ, tid, ra, 0);
+      store_mc<TN, BK, false>(smem + (nxt * 2 + 1) * OPSZ, tid, rb, 0);
+      __syncthreads();
+    }
   }
+  for (; c < nch; ++c) general_iter(c);
 
   // epilogue: slab (a,b) holds C[row0+wm+4a+(l>>4)][col0+wn+16b+(l&15)].  The beta path first issues all C loads of a
   // group of slabs (clamped addresses, no branches around loads) and only then combines and stores.

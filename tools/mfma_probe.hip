@@ -86,6 +86,8 @@ int main() {
   MF(4, 4, 1.0, 10000); MF(8, 4, 1.0, 5000); MF(4, 8, 1.0, 5000); MF(2, 8, 1.0, 10000); MF(8, 3, 1.0, 5000); MF(16, 3, 1.0, 2500);
 #define M4(N, BPC, SC, IT) run("mfma4x4x4 acc=" #N " wg/cu=" #BPC, [](double* o, Stamp* s, int it, int nb) { probe_mfma4<N><<<nb, 256>>>(o, s, it, SC); }, CU * BPC, N * 512.0, IT, N)
   M4(4, 1, 1.0, 20000); M4(8, 2, 1.0, 10000); M4(8, 4, 1.0, 10000);
+  // long unrolled bodies: is the 4x4x4 shortfall (68 of 78.6 TF) loop overhead?  and does the operand scale matter (power)?
+  M4(64, 1, 1.0, 4000); M4(64, 2, 1.0, 2000); M4(64, 2, 0.0, 2000); M4(32, 2, 1.0, 4000); M4(16, 2, 1.0, 8000);
 #define FM(N, BPC, SC, IT) run("fma acc=" #N " wg/cu=" #BPC " scale=" #SC, [](double* o, Stamp* s, int it, int nb) { probe_fma<N><<<nb, 256>>>(o, s, it, SC); }, CU * BPC, N * 128.0, IT, N)
   FM(8, 1, 1.0, 100000); FM(8, 2, 1.0, 100000); FM(8, 4, 1.0, 100000); FM(8, 4, 0.0, 100000);
   return 0;
