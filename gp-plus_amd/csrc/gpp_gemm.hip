@@ -23,9 +23,6 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 
 namespace {
 
-#ifndef GPP_PIPE_FRAGS
-#define GPP_PIPE_FRAGS 0
-#endif
 constexpr int BK16 = 16;  // K chunk of the big tile and of every k-contiguous ("KC") operand
 // LDS layouts.  Row-contiguous operands ("MC", stored [k][row] in memory) are staged as [k][T+16]: 16-byte aligned
 // rows for ds_write_b128, and the two k-rows a 32-lane ds_read_b64 group touches fall in different bank halves.
@@ -314,40 +311,14 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
     // A fragment: lane (i = l&3, k = l>>4), same address in the 4 column groups (l>>2)&3 -> LDS broadcast
     const double* sa = smem + (cur * 2 + 0) * OPSZ + (A_KC ? (wm + (lane & 3)) * LDK + lk : wm + (lane & 3) + lk * LDA);
     const double* sb = smem + (cur * 2 + 1) * OPSZ + (B_KC ? (wn + li) * LDK + lk : wn + li + lk * LDB);
-    if constexpr (VAR == 2 && RB == 16 && CB == 4 && BK == 16 && GPP_PIPE_FRAGS) {
-      // Big tile: 16 phases per chunk (4 k-steps x 4 groups of 4 row blocks), each 4 A fragment reads and 16 MFMAs.
-      // The A fragments of phase ph+1 (and, two phases ahead of a new k-step, its B fragments) are requested before the
-      // MFMAs of phase ph into the other register set, so no LDS latency sits between two MFMA groups (+8 VGPRs).
-      double afr[2][4], bfr[2][4];
-#pragma unroll
-      for (int b = 0; b < 4; ++b) bfr[0][b] = sb[16 * b];
-#pragma unroll
-      for (int a = 0; a < 4; ++a) afr[0][a] = sa[4 * a];
-#pragma unroll
-      for (int ph = 0; ph < 16; ++ph) {
-        const int kk = ph >> 2, g = ph & 3;
-        if (ph + 1 < 16) {
-          const int kn = (ph + 1) >> 2, gn = (ph + 1) & 3;
-#pragma unroll
-          for (int a = 0; a < 4; ++a) afr[(ph + 1) & 1][a] = sa[kn * 4 * LDA + 4 * (4 * gn + a)];
-        }
-        if (g == 1 && kk + 1 < 4) {
-#pragma unroll
-          for (int b = 0; b < 4; ++b) bfr[(kk + 1) & 1][b] = sb[(kk + 1) * 4 * LDB + 16 * b];
-        }
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b)
-            acc[4 * g + a][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(afr[ph & 1][a], bfr[kk & 1][b], acc[4 * g + a][b], 0, 0, 0);
-      }
-    } else {
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
       double bf[CB];
 #pragma unroll
       for (int b = 0; b < CB; ++b) bf[b] = B_KC ? sb[16 * b * LDK + kk * 4] : sb[kk * 4 * LDB + 16 * b];
-      // A fragments in groups of <= 8 row blocks: bounds the live registers (acc + staging already take ~170)
+      // A fragments in groups of <= 8 row blocks: bounds the live registers (acc + staging already take ~170).
+      // (Requesting the next group's fragments before this group's MFMAs, from a second register set, was measured:
+      //  no gain — the LDS latency is already covered by the other wave of the SIMD.)
       constexpr int AG = RB < 8 ? RB : 8;
 #pragma unroll
       for (int a0 = 0; a0 < RB; a0 += AG) {
@@ -360,7 +331,6 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
           for (int b = 0; b < CB; ++b)
             acc[a0 + a][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[b], acc[a0 + a][b], 0, 0, 0);
       }
-    }
     }
   };
 
@@ -410,7 +380,7 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
       const int kb = kpos(c + 1);
       load_fast<NVA>(ubaseA + (int64_t)kb * stepA, offa, ra);
       load_fast<NVB>(ubaseB + (int64_t)kb * stepB, offb, rb);
-      compute(cur);
+      compute(cur);  // (s_setprio around this phase: LAUUM +4 %, the look-ahead factorisation -3 %: not adopted)
       if (NBUF == 1) __syncthreads();
       store_mc<TM, BK, false>(smem + (nxt * 2 + 0) * OPSZ, tid, ra, 0);
       store_mc<TN, BK, false>(smem + (nxt * 2 + 1) * OPSZ, tid, rb, 0);
