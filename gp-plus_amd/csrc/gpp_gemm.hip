@@ -438,11 +438,14 @@ hipError_t launch_inst(hipStream_t s, dim3 grid, const GemmArgs& a) {
   constexpr size_t bytes = gemm_lds_bytes(VAR, 2 * WTM, 2 * WTN, BK, NBUF);
   auto* fn = gpp_gemm_f64<VAR, WTM, WTN, TAG, BK, NBUF>;
   if (bytes > 48 * 1024) {
-    static bool attr_set = false;  // per instantiation
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    static bool attr_set[64] = {false};  // per instantiation and device (function attributes are per device)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
       if (e != hipSuccess) return e;
-      attr_set = true;
+      if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
   }
   hipLaunchKernelGGL(fn, grid, dim3(256), bytes, s, a);

@@ -418,13 +418,16 @@ hipError_t gpp_launch_leaf(hipStream_t s, double* A, int64_t lda, double* Linv, 
                            int row_offset) {
   if (n <= 0) return hipSuccess;
   if (n > NB) return hipErrorInvalidValue;
-  static bool attr_set = false;
+  static bool attr_set[64] = {false};  // per device (function attributes are per device)
   const size_t shmem = (size_t)NT * TSZ * sizeof(double);
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gpp_leaf_potrf_inv),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gpp_leaf_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)shmem);
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL(gpp_leaf_potrf_inv, dim3(1), dim3(256), shmem, s, A, lda, Linv, ldi, n, info, row_offset);
   return hipGetLastError();

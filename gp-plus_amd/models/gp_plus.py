@@ -229,14 +229,17 @@ class GP_Plus(GPR):
         if len(self.qual_kernel_columns) == 0:
             return x.to(dev), 0
         i = len(self.qual_kernel_columns) - 1  # the reference embeds only the last group
-        key = (x.data_ptr(), tuple(x.shape), x._version, self.training)
-        zeta_rows = self._cat_cache.get(key)
-        if zeta_rows is None:  # the O(N) lookup runs once per distinct input tensor, not once per forward (B-6)
+        # The O(N) level lookup runs once for the TRAINING inputs (same tensor object every forward of a fit, B-6) and
+        # every time for anything else.  The key is the object's identity, never its address: the caching allocator
+        # hands a freed test batch's address to the next one of the same shape.
+        is_train = self.train_inputs is not None and len(self.train_inputs) > 0 and x is self.train_inputs[0]
+        key = ('train', x._version, self.training) if is_train else None
+        zeta_rows = self._cat_cache.get(key) if key is not None else None
+        if zeta_rows is None:
             xc = x[:, self.qual_kernel_columns[i]].clone().type(torch.int64)
             zeta_rows = self.transform_categorical(x=xc, perm_dict=self.perm_dict[i], zeta=self.zeta[i]).to(**self.tkwargs)
-            if len(self._cat_cache) > 8:
-                self._cat_cache.clear()
-            self._cat_cache[key] = zeta_rows
+            if key is not None:
+                self._cat_cache = {key: zeta_rows}
         emb = self.A_matrix[i](zeta_rows)
         x_new = torch.cat([emb, x[..., self.quant_index.long()].to(**self.tkwargs)], dim=-1)
         return x_new, emb.shape[-1]
@@ -399,8 +402,49 @@ class GP_Plus(GPR):
     def visualize_latent(self, *args, **kwargs):
         raise NotImplementedError("plotting (visual/) is out of scope of this build; use get_latent_space()")
 
-    def Sobol(self, *args, **kwargs):
-        raise NotImplementedError("Sobol indices (gp_plus.py:1148-1224) are a post-fit analysis outside this build's scope")
+    def Sobol(self, N: int = 10000, batch: int = 8192):
+        """Main (S) and total (ST) Sobol sensitivity indices of the posterior mean, each of shape (1, p)
+        (gp_plus.py:1148-1224): Saltelli's scheme on a 2p-dimensional Sobol sequence, p + 2 batched predictions of N
+        points each from the cached factorisation (``gpp_cross_kernel`` + ``gpp_predict`` in chunks of ``batch`` rows, so
+        N = 1e5 at N_train = 2e4 never materialises more than batch x N_train doubles).
+
+        Differences from the reference, both forced: the sequence comes from ``scipy.stats.qmc.Sobol`` (unscrambled,
+        origin skipped — the reference's ``sobol_seq`` package is not a dependency of this build), and EVERY categorical
+        column is mapped to its level grid (the reference returns from inside its loop after the first categorical
+        column, and returns nothing at all for a purely quantitative model)."""
+        from scipy.stats import qmc
+
+        if N < 1e5:
+            warnings.warn('Increase N for accuracy!')
+        X = self.train_inputs[0].detach().cpu().to(torch.float64)
+        p = X.shape[1]
+        gen = qmc.Sobol(d=2 * p, scramble=False)
+        gen.fast_forward(1)
+        sequence = torch.from_numpy(gen.random(N))
+        mins, maxs = X.min(dim=0)[0], X.max(dim=0)[0]
+        halves = []
+        for part in (sequence[:, p:], sequence[:, :p]):
+            scaled = mins + (maxs - mins) * part
+            for j, col in enumerate(self.qual_dict_list):
+                scaled[:, col] = (part[:, col] * (self.num_levels_per_var[j] - 1)).round()
+            halves.append(scaled)
+        A, B = halves
+
+        def f(Z):
+            out = [self.predict(Z[i:i + batch], return_std=False).detach().cpu().to(torch.float64).reshape(-1)
+                   for i in range(0, Z.shape[0], batch)]
+            return torch.cat(out).numpy().reshape(-1, 1)
+
+        FA, FB = f(A), f(B)
+        S, ST = np.zeros((p, 1)), np.zeros((p, 1))
+        for i in range(p):
+            ABi = A.clone()
+            ABi[:, i] = B[:, i]
+            Fi = f(ABi)
+            S[i, :] = np.sum(FB * (Fi - FA), axis=0) / N
+            ST[i, :] = np.sum((FA - Fi) ** 2, axis=0) / (2 * N)
+        varY = np.var(np.concatenate([FA, FB]), axis=0)
+        return (S / varY).T, (ST / varY).T
 
     # ---- categorical encoding ---------------------------------------------------------------------------
     def zeta_matrix(self, num_levels, embedding_dim: int, batch_shape=torch.Size()):

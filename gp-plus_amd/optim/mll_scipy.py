@@ -141,9 +141,11 @@ def fit_model_scipy(model, add_prior: bool = True, num_restarts: int = 1, theta0
             theta0_list.extend(samples)
             theta0_list.pop(0)  # as the reference: the incumbent point itself is not among the starts
     out = [_fit_model_from_state(likobj, theta0, jac, defaults, method, constraint, bounds) for theta0 in theta0_list]
-    nlls_opt = [np.inf if isinstance(res, Exception) else res.fun for res in out]
+    # (a start that diverged to a non-finite objective is scored like a failed one; the reference's argmin would pick
+    #  the NaN and load NaN parameters into the model)
+    nlls_opt = [np.inf if isinstance(res, Exception) or not np.isfinite(res.fun) else res.fun for res in out]
     best_idx = int(np.argmin(nlls_opt))
-    if not isinstance(out[best_idx], Exception):
+    if not isinstance(out[best_idx], Exception) and np.isfinite(nlls_opt[best_idx]):
         old = deepcopy(model.state_dict())
         old.update(likobj.unpack_parameters(out[best_idx].x))
         model.load_state_dict(old)

@@ -349,3 +349,105 @@ def test_loocv_and_noise_continuation(gpu_ctx):
     obj = MLLObjective(m, True, [0, 0])
     f_now = obj.fun(obj.pack_parameters(), return_grad=False)
     assert np.isfinite(f_now)
+
+
+def test_bayesian_optimisation_consumers(gpu_ctx):
+    """acquisition functions and the cost-aware multi-fidelity BO loop (bayesian_optimizations/*) on the
+    HIP-backed model: one iteration of the continuous branch and one of the pool branch, plus EI against its closed form."""
+    from gpplus_amd.bayesian_optimizations import AF_EI, AF_HF, AF_LF, BO
+    from gpplus_amd.models import GP_Plus
+    from gpplus_amd.utils import set_seed
+    from scipy.stats import norm
+
+    set_seed(11)
+    rng = np.random.default_rng(3)
+
+    def truth(x, s):  # two sources: the cheap one is a biased version of the expensive one
+        return np.sin(3.0 * x) + 0.5 * x + (0.3 * np.cos(2.0 * x) if s == 1 else 0.0)
+
+    xs = rng.uniform(-2.0, 2.0, 24)
+    src = np.array([0] * 8 + [1] * 16)
+    xmean, xstd = np.array([xs.mean()]), np.array([xs.std()])
+    Xtr = np.stack([(xs - xmean[0]) / xstd[0], src.astype(float)], axis=1)
+    ytr = np.array([truth(x, s) for x, s in zip(xs, src)])
+    costs = {"0": 10.0, "1": 1.0}
+
+    # acquisition functions against their closed forms on one model
+    m = GP_Plus(torch.tensor(Xtr), torch.tensor(ytr), qual_dict={1: 2}, dtype=torch.float64, device="cuda")
+    m.eval()
+    pt = np.array([0.3, 1.0])
+    with torch.no_grad():
+        mu, sd = m.predict(torch.tensor([[(0.3 - xmean[0]) / xstd[0], 1.0]]), return_std=True, include_noise=True)
+    mu, sd = float(mu), float(sd)
+    best = float(ytr.min())
+    u = -(mu - best) / sd
+    cf = lambda v: costs[str(int(v))]
+    assert abs(AF_EI(pt, best, m, xmean, xstd, cf) + sd * (norm.pdf(u) + u * norm.cdf(u)) / 1.0) < 1e-9
+    assert abs(AF_LF(pt, best, m, xmean, xstd, cf) + sd * norm.pdf(u) / 1.0) < 1e-9
+    assert abs(AF_HF(pt, best, m, xmean, xstd, cf) + sd * u / 1.0) < 1e-9
+
+    def gen(_flag, x):  # x: (1, 2) raw coordinate + source
+        x = np.asarray(x, dtype=float).reshape(-1, 2)
+        return torch.tensor([truth(r[0], int(round(r[1]))) for r in x])
+
+    bestf, cum = BO(Xtrain=torch.tensor(Xtr), ytrain=torch.tensor(ytr), costs=costs, l_bound=[-2.0], u_bound=[2.0], xmean=xmean,
+                    xstd=xstd, qual_index={1: 2}, data_gen_func=gen, one_iter=True, max_cost=1e9, n_starts=2,
+                    fit_options={"maxiter": 10})
+    assert bestf.shape == (2,) and cum.shape == (2,) and (cum[1] - cum[0]) in (10.0, 1.0)
+    assert bestf[1] <= bestf[0] + 1e-12   # the incumbent (high-fidelity minimum) never gets worse
+
+    pool_x = rng.uniform(-2.0, 2.0, 60)
+    pool_s = np.array([0] * 20 + [1] * 40)
+    pool = np.stack([(pool_x - xmean[0]) / xstd[0], pool_s.astype(float), [truth(x, s) for x, s in zip(pool_x, pool_s)]], axis=1)
+    bestf2, cum2 = BO(costs=costs, qual_index={1: 2}, data_gen_func=pool, n_train=[6, 10], one_iter=True, max_cost=1e9,
+                      fit_options={"maxiter": 10})
+    assert bestf2.shape == (2,) and (cum2[1] - cum2[0]) in (10.0, 1.0)
+
+
+def test_sobol_indices(gpu_ctx):
+    """Sobol indices from p + 2 batched predictions (gp_plus.py:1148-1224).  For an additive truth
+    y = 2 x0 + x1^2 + (level effect of a categorical x2) the analytic indices follow from the term variances."""
+    import warnings as _w
+    from gpplus_amd.models import GP_Plus
+    from gpplus_amd.optim import fit_model_scipy
+    from gpplus_amd.utils import set_seed
+
+    set_seed(2)
+    rng = np.random.default_rng(0)
+    n = 300
+    X = np.stack([rng.uniform(0, 1, n), rng.uniform(0, 1, n), rng.integers(0, 3, n).astype(float)], axis=1)
+    lev = np.array([0.0, 0.3, 0.6])
+    y = 2.0 * X[:, 0] + X[:, 1] ** 2 + lev[X[:, 2].astype(int)]
+    m = GP_Plus(torch.tensor(X), torch.tensor(y), qual_dict={2: 3}, dtype=torch.float64, device="cuda")
+    fit_model_scipy(m, num_restarts=3, options={"maxiter": 60}, bounds=True)
+    with _w.catch_warnings():
+        _w.simplefilter("ignore")
+        S, ST = m.Sobol(N=8192, batch=3000)
+    assert S.shape == (1, 3) and ST.shape == (1, 3)
+    v = np.array([4.0 / 12.0, 4.0 / 45.0, np.var(lev)])      # Var[2 x0], Var[x1^2], Var[level effect] (uniform levels)
+    ref = v / v.sum()
+    np.testing.assert_allclose(S[0], ref, atol=0.05)
+    np.testing.assert_allclose(ST[0], ref, atol=0.05)          # additive: total = main
+
+
+def test_predict_repeated_batches_with_categoricals(gpu_ctx):
+    """Regression: consecutive predictions on different same-shaped batches (which the caching allocator places at the
+    same address) must each encode their OWN categorical levels."""
+    from gpplus_amd.models import GP_Plus
+
+    rng = np.random.default_rng(5)
+    n = 120
+    X = np.stack([rng.uniform(0, 1, n), rng.integers(0, 3, n).astype(float)], axis=1)
+    y = np.sin(4 * X[:, 0]) + np.array([0.0, 1.0, 2.0])[X[:, 1].astype(int)]
+    m = GP_Plus(torch.tensor(X), torch.tensor(y), qual_dict={1: 3}, dtype=torch.float64, device="cuda")
+    with torch.no_grad():
+        m.likelihood.initialize(noise=1e-4)
+    m.eval()
+    outs = []
+    for lvl in (0.0, 1.0, 2.0, 0.0):
+        Z = torch.tensor([[0.25, lvl], [0.75, lvl]])
+        outs.append(m.predict(Z, return_std=False).cpu().numpy().copy())
+    together = m.predict(torch.tensor([[0.25, 0.0], [0.25, 1.0], [0.25, 2.0]]), return_std=False).cpu().numpy()
+    np.testing.assert_allclose([o[0] for o in outs[:3]], together, rtol=1e-10)
+    np.testing.assert_allclose(outs[3], outs[0], rtol=1e-12)
+    assert abs(outs[1][0] - outs[0][0]) > 0.1 and abs(outs[2][0] - outs[1][0]) > 0.1   # the level effect is visible
