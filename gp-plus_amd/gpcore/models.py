@@ -42,6 +42,8 @@ class ExactGP(GP):
         """Factor the training covariance once per eval() phase (gpytorch's prediction strategy caches)."""
         from ..linalg import factorize
 
+        if self.prediction_strategy is not None and self.prediction_strategy.stale():
+            self.prediction_strategy = None  # another model reused the prediction workspace: factor again
         if self.prediction_strategy is None:
             with torch.no_grad():
                 train_out = Module.__call__(self, *self.train_inputs, **kwargs)

@@ -252,8 +252,14 @@ class FactorCache:
     """Cholesky factor, its inverse and alpha = Ky^-1 (y - m) of the training covariance: the analogue of gpytorch's
     prediction strategy caches (mean_cache / covar_cache) used by models/gpregression.py:122-149."""
 
-    def __init__(self, gctx, L, Linv, alpha, U, spec, jitter):
+    def __init__(self, gctx, L, Linv, alpha, U, spec, jitter, ws=None):
         self.gctx, self.L, self.Linv, self.alpha, self.U, self.spec, self.jitter = gctx, L, Linv, alpha, U, spec, jitter
+        # L and Linv live in the shared prediction workspace: another model's factorisation of the same size overwrites
+        # them.  ``stale()`` tells the owner to factor again instead of predicting from someone else's matrices.
+        self._ws, self._epoch = ws, (ws.epoch if ws is not None else 0)
+
+    def stale(self) -> bool:
+        return self._ws is not None and self._ws.epoch != self._epoch
 
 
 @torch.no_grad()
@@ -272,7 +278,7 @@ def factorize(U, spec: KernelSpec, tau, grp, mean, y) -> FactorCache:
     torch.sub(_as_f64(y, dev), _as_f64(mean, dev), out=ws.r)
     gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
     gctx.alpha(ws.Li, ws.z, ws.alpha)
-    return FactorCache(gctx, ws.A, ws.Li, ws.alpha.clone(), Ud, KernelSpec(wd, sd.reshape(()), spec.kind, spec.d_split), jit)
+    return FactorCache(gctx, ws.A, ws.Li, ws.alpha.clone(), Ud, KernelSpec(wd, sd.reshape(()), spec.kind, spec.d_split), jit, ws)
 
 
 @torch.no_grad()

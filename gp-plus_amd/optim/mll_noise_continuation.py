@@ -34,9 +34,7 @@ def loocv_rrmse(model) -> float:
     from ..linalg import get_workspace
     model.eval()
     with torch.no_grad():
-        if model.prediction_strategy is None:
-            model._ensure_prediction_cache()
-        cache = model.prediction_strategy
+        cache = model._ensure_prediction_cache()
         N = cache.U.shape[0]
         ws = get_workspace(cache.gctx, N, slot=-1)  # the buffers the cache lives in: Ki is free scratch
         cache.gctx.lauum(cache.Linv, ws.Ki)

@@ -451,3 +451,24 @@ def test_predict_repeated_batches_with_categoricals(gpu_ctx):
     np.testing.assert_allclose([o[0] for o in outs[:3]], together, rtol=1e-10)
     np.testing.assert_allclose(outs[3], outs[0], rtol=1e-12)
     assert abs(outs[1][0] - outs[0][0]) > 0.1 and abs(outs[2][0] - outs[1][0]) > 0.1   # the level effect is visible
+
+
+def test_two_models_share_the_prediction_workspace(gpu_ctx):
+    """Regression: two models of the same size predicting alternately must not read each other's cached factor."""
+    from gpplus_amd.models import GP_Plus
+
+    rng = np.random.default_rng(9)
+    X = rng.uniform(0, 1, (90, 2))
+    ya, yb = np.sin(5 * X[:, 0]), np.cos(3 * X[:, 1]) + 2.0
+    ma = GP_Plus(torch.tensor(X), torch.tensor(ya), dtype=torch.float64, device="cuda")
+    mb = GP_Plus(torch.tensor(X), torch.tensor(yb), dtype=torch.float64, device="cuda")
+    for m in (ma, mb):
+        with torch.no_grad():
+            m.likelihood.initialize(noise=1e-4)
+        m.eval()
+    Z = torch.tensor(rng.uniform(0, 1, (7, 2)))
+    a1 = ma.predict(Z, return_std=False).cpu().numpy().copy()
+    b1 = mb.predict(Z, return_std=False).cpu().numpy().copy()
+    a2 = ma.predict(Z, return_std=False).cpu().numpy().copy()
+    np.testing.assert_allclose(a2, a1, rtol=1e-12)
+    assert np.abs(a1 - b1).max() > 0.5
