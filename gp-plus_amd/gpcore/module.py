@@ -86,6 +86,9 @@ class Prior(nn.Module):
         raise NotImplementedError
 
 
+_HALF_LOG_2PI = 0.5 * __import__("math").log(2 * __import__("math").pi)
+
+
 class NormalPrior(Prior):
     """gpytorch.priors.NormalPrior (models/gp_plus.py:279-295,495,1247)."""
 
@@ -101,7 +104,10 @@ class NormalPrior(Prior):
         return torch.distributions.Normal(loc, scale)
 
     def log_prob(self, x):
-        return self._dist(x).log_prob(x)
+        # torch.distributions.Normal.log_prob written out: building the distribution object validates its arguments
+        # with a device sync per tensor, several times per evaluation of a small model
+        loc, scale = self.loc.to(x), self.scale.to(x)
+        return -((x - loc) ** 2) / (2 * scale ** 2) - scale.log() - _HALF_LOG_2PI
 
     def rsample(self, sample_shape=torch.Size([])):
         return self._dist().rsample(sample_shape)
@@ -125,7 +131,10 @@ class LogNormalPrior(Prior):
         return torch.distributions.LogNormal(loc, scale)
 
     def log_prob(self, x):
-        return self._dist(x).log_prob(x)
+        # TransformedDistribution(Normal, ExpTransform).log_prob written out (see NormalPrior.log_prob)
+        loc, scale = self.loc.to(x), self.scale.to(x)
+        lx = x.log()
+        return -((lx - loc) ** 2) / (2 * scale ** 2) - scale.log() - _HALF_LOG_2PI - lx
 
     def rsample(self, sample_shape=torch.Size([])):
         return self._dist().rsample(sample_shape)
