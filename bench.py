@@ -110,6 +110,11 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="independent replicas evaluated concurrently on this GPU (one host thread + HIP stream + "
                          "workspace slot each), the per-GPU form of restart parallelism")
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+                    help="replicas (default): every GPU evaluates its own copy of the C2 problem (restart parallelism, weak "
+                         "scaling).  sharded: ALL GPUs evaluate ONE problem cooperatively (gp-plus_amd/sharded.py, strong "
+                         "scaling; use --n 60000 for the C5 size)")
+    ap.add_argument("--nb", type=int, default=1024, help="block height of the sharded evaluation")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -140,13 +145,17 @@ def main():
         replicas.append((model, ExactMarginalLogLikelihood(model.likelihood, model),
                          [p for p in model.parameters() if p.requires_grad]))
 
+    from gpplus_amd import settings as gpp_settings
+    shard_cfg = {"group": None, "nb": args.nb} if (args.mode == "sharded" and world > 1) else None
+
     def step(k=0):
         model, mll, params = replicas[k]
         for p in params:
             p.grad = None
-        output = model(*model.train_inputs)
-        loss = -mll(output, model.train_targets)
-        loss.backward()
+        with gpp_settings.sharded_evaluation(shard_cfg):
+            output = model(*model.train_inputs)
+            loss = -mll(output, model.train_targets)
+            loss.backward()
         return loss
 
     def run_steps(nsteps):
@@ -203,8 +212,9 @@ def main():
         stage_ms = {k: float(np.mean(v)) for k, v in stages.items()}
         flops = {"potrf": N ** 3 / 3, "trtri": N ** 3 / 3, "lauum": N ** 3 / 3}
         stage_rate = {k: flops[k] / (stage_ms[k] * 1e-3) / 1e12 for k in flops if k in stage_ms}
-        lauum_tflops = stage_rate.get("lauum", 0.0)
-        value = world * args.steps / elapsed
+        lauum_tflops = stage_rate.get("lauum")  # None in sharded mode (no single LAUUM launch there)
+        sharded = shard_cfg is not None
+        value = (1 if sharded else world) * args.steps / elapsed  # sharded: the ranks share every evaluation
         # HBM-side bytes of the roofline kernel come from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
         # cannot run inside this process); they only apply to the size they were collected at
         traffic, traffic_src = None, None
@@ -216,14 +226,17 @@ def main():
         out = {
             "metric": "MLL evals/sec (fwd+grad), NxN exact GP, N=20k d=8",
             "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "strong" if sharded else "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C2: synthetic Borehole (Sobol seed 0, unique rows, z-scored) N={N} d={D_C2} fp64, "
-                                   "GP_Plus Rough_RBF exact GP at theta1, one replica per GPU (restart-parallel)",
+                                   "GP_Plus Rough_RBF exact GP at theta1, " +
+                                   ("ONE evaluation sharded over all GPUs (block-cyclic rows, RCCL panel broadcasts)" if sharded
+                                    else "one replica per GPU (restart-parallel)"),
                        "N": N, "d": D_C2, "loss": float(loss.item()), "streams_per_gpu": S},
             "roofline": {"bound": "mfma", "kernel": "gpp_gemm_f64<2, 64, 64, 1, 16, 2> (LAUUM: Kinv = Linv^T Linv, the one lower-triangular TN launch)",
                          "achieved": lauum_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": lauum_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "B/launch",
+                         "frac": None if lauum_tflops is None else lauum_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "B/launch",
                          "traffic_source": traffic_src,
                          "flops_per_launch": N ** 3 / 3, "ms_per_launch": stage_ms.get("lauum")},
             "stages": {"ms": stage_ms, "tflops": stage_rate,
