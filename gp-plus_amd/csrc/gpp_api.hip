@@ -181,7 +181,7 @@ hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv
 // (single work-group, 72 KiB LDS) leaf of the next panel until the update drains (measured: the leaf "ran" for 5.8 ms).
 // So the two internal streams get DISJOINT CU sets through CU masks: PANEL_CUS compute units run the latency-bound
 // diagonal-block factorisations, the remaining ones the wide trsm and trailing updates.
-constexpr int PANEL_CUS_DEFAULT = 16;
+constexpr int PANEL_CUS_DEFAULT = 32;
 hipError_t ensure_streams(gpp_handle_s* h) {
   if (h->cu_split < 0) {
     hipDeviceProp_t prop;
@@ -191,12 +191,18 @@ hipError_t ensure_streams(gpp_handle_s* h) {
     h->cu_split = 0;
     int PANEL_CUS = PANEL_CUS_DEFAULT;
     if (const char* e = getenv("GPP_PANEL_CUS")) PANEL_CUS = atoi(e);  // experiment knob
-    if (ncu >= 4 * PANEL_CUS && ncu <= 1024) {
+    if (ncu >= 4 * PANEL_CUS && ncu <= 1024 && PANEL_CUS > 0 && !getenv("GPP_NO_CU_SPLIT")) {
       uint32_t mp[32] = {0}, mu[32] = {0};
       const int words = (ncu + 31) / 32;
-      // The FIRST mask bits: consecutive bits fall in different XCDs, so every XCD gives up 2 of its 32 CUs.  Work-groups
-      // are dealt round-robin to the XCDs regardless of how many CUs each has left: taking the 16 CUs from one XCD
-      // (mask bits 0, 8, 16, ...) slows the trailing updates by 60 % (measured: 59 -> 95 ms).
+      // The FIRST mask bits.  Measured (tools/gemm_update_probe.py with GPP_GEMM_ON_UPD=1): a K = 1024 trailing update runs
+      // at 62.3 TFLOP/s on all 256 CUs and at 54.3 / 54.8 / 54.7 with 2 / 16 / 32 CUs masked out — the loss is a step of
+      // 12.5 %, not proportional.  Consecutive mask bits fall in different XCDs and then in different shader engines of an
+      // XCD; work-groups are dealt round-robin to XCDs and to their 4 shader engines regardless of the CUs each has left, so
+      // throughput follows the SMALLEST engine (7 of 8 CUs) as soon as any CU is taken, and stays there until every engine
+      // of every XCD has given one: 32 CUs cost the update stream exactly what 2 do.  (Taking the CUs from one XCD, mask bits
+      // 0, 8, 16, ..., is far worse: 59 -> 95 ms.)  Without masks the leaf needs a CU to itself (its register allocation
+      // does not fit beside a GEMM work-group) and starves; capped at 256 registers it is placed, but every panel launch
+      // then queues behind 300-us GEMM work-groups and the update stream idles 0.55 ms per step: 62 ms vs 59.
       for (int c = 0; c < ncu; ++c) (c < PANEL_CUS ? mp : mu)[c >> 5] |= 1u << (c & 31);
       hipStream_t sp = nullptr, su = nullptr;
       if (hipExtStreamCreateWithCUMask(&sp, words, mp) == hipSuccess &&
@@ -604,6 +610,16 @@ int gpp_gemm(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64
   g.a_mask = a_mask; g.b_mask = b_mask; g.klo_mode = klo_mode; g.khi_mode = khi_mode; g.c_lower = c_tri;
   int ftm = 0, ftn = 0;
   if (const char* e = getenv("GPP_GEMM_TILE")) sscanf(e, "%d,%d", &ftm, &ftn);  // dev knob (tools/gemm_small_probe.py)
+  if (getenv("GPP_GEMM_ON_UPD")) {  // dev knob (tools/gemm_update_probe.py): run on the CU-masked update stream
+    GPP_TRY(ensure_streams(h));
+    hipEvent_t a = next_event(h), b = next_event(h);
+    GPP_TRY(hipEventRecord(a, h->stream));
+    GPP_TRY(hipStreamWaitEvent(h->upd_stream, a, 0));
+    GPP_TRY(gpp_launch_gemm(h->upd_stream, variant, g, 1, ftm, ftn));
+    GPP_TRY(hipEventRecord(b, h->upd_stream));
+    GPP_TRY(hipStreamWaitEvent(h->stream, b, 0));
+    return 0;
+  }
   GPP_TRY(gpp_launch_gemm(h->stream, variant, g, 1, ftm, ftn));
   return 0;
 }
