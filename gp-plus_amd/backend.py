@@ -72,6 +72,17 @@ class GppContext:
         s = torch.cuda.current_stream(self.index).cuda_stream
         check(self.lib.gpp_set_stream(self.h, ctypes.c_void_p(s)), "gpp_set_stream")
 
+    def internal_streams(self):
+        """(latency stream, throughput stream): the handle's CU-masked internal streams as torch streams."""
+        if getattr(self, "_istreams", None) is None:
+            out = []
+            for which in (0, 1):
+                p = ctypes.c_void_p()
+                check(self.lib.gpp_internal_stream(self.h, which, ctypes.byref(p)), "gpp_internal_stream")
+                out.append(torch.cuda.ExternalStream(p.value, device=self.device))
+            self._istreams = tuple(out)
+        return self._istreams
+
     def ensure_workspace(self, op: int, N: int, M: int, D: int, S: int) -> None:
         need = int(self.lib.gpp_workspace_bytes(self.h, op, N, M, D, S))
         if self._ws is None or self._ws.numel() < need:

@@ -374,6 +374,15 @@ int gpp_set_stream(gpp_handle_t h, void* stream) {
   return 0;
 }
 
+int gpp_internal_stream(gpp_handle_t h, int which, void** out) {
+  if (!h) return -1;
+  if (which != 0 && which != 1) return -2;
+  if (!out) return -3;
+  GPP_TRY(ensure_streams(h));
+  *out = reinterpret_cast<void*>(which == 0 ? h->panel_stream : h->upd_stream);
+  return 0;
+}
+
 size_t gpp_workspace_bytes(gpp_handle_t h, int op, int64_t N, int64_t M, int D, int S) {
   (void)h;
   (void)M;

@@ -92,7 +92,6 @@ class ShardedWorkspace:
         self.out3 = torch.empty(3, dtype=torch.float64, device=dev)
         self.offs: List[int] = list(range(0, N, nb)) + [N]
         self.info = torch.zeros(len(self.offs), dtype=torch.int32, device=dev)
-        self.side = torch.cuda.Stream(device=dev)
         self.epoch = 0
 
     def rows(self, buf: torch.Tensor, o: int, n: int) -> torch.Tensor:
@@ -120,14 +119,17 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
     nblk = len(offs) - 1
     A, Li, Ki = ws.A, ws.Li, ws.Ki
     main = torch.cuda.current_stream(ctx.index)
-    side = ws.side
+    # The library's two CU-masked streams: diagonal blocks (single-work-group leaves that need a CU to themselves) are
+    # factored on 32 reserved CUs while the other CUs run the trailing updates — see gpp_api.hip, ensure_streams.
+    side, upd = ctx.internal_streams()
     ws.info.zero_()
     for k in range(me, nblk, P):
         ctx.kernel_build(U, w, sf2, tau, grp, A, jitter=jitter, kind=kind, d_split=d_split, uplo=UPLO_FULL, row0=offs[k],
                          nrows=offs[k + 1] - offs[k])
+    side.wait_stream(main)
+    upd.wait_stream(main)
     row_ready = torch.cuda.Event()
     row_ready.record(main)
-    side.wait_stream(main)
     for k in range(nblk):
         o, o1 = offs[k], offs[k + 1]
         nbk, rem, own = o1 - o, N - o1, (k % P == me)
@@ -149,17 +151,19 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
                 Li[o:o1, o:o1].copy_(dblk)
             arrived = torch.cuda.Event()
             arrived.record(side)
-        main.wait_event(arrived)
-        for j in range(k + 1, nblk):
-            if j % P != me:
-                continue
-            oj, oj1 = offs[j], offs[j + 1]
-            # A[j, j:] -= U[k, j]^T U[k, j:]   (the strictly-lower part of the diagonal block is scratch, never read)
-            ctx.gemm(1, 0, oj1 - oj, N - oj, nbk, -1.0, A[o:o1, oj:oj1], A[o:o1, oj:N], 1.0, A[oj:oj1, oj:N])
-            if j == k + 1:
-                row_ready = torch.cuda.Event()
-                row_ready.record(main)
+        with torch.cuda.stream(upd):
+            upd.wait_event(arrived)
+            for j in range(k + 1, nblk):
+                if j % P != me:
+                    continue
+                oj, oj1 = offs[j], offs[j + 1]
+                # A[j, j:] -= U[k, j]^T U[k, j:]   (the strictly-lower part of the diagonal block is scratch, never read)
+                ctx.gemm(1, 0, oj1 - oj, N - oj, nbk, -1.0, A[o:o1, oj:oj1], A[o:o1, oj:N], 1.0, A[oj:oj1, oj:N])
+                if j == k + 1:
+                    row_ready = torch.cuda.Event()
+                    row_ready.record(upd)
     main.wait_stream(side)
+    main.wait_stream(upd)
     info = ws.info.max().to(torch.int32).reshape(1)
     comm.allreduce(info, dist.ReduceOp.MAX)
     return int(info.item())

@@ -55,6 +55,11 @@ int gpp_create(gpp_handle_t* out, int device);
 int gpp_destroy(gpp_handle_t h);
 /* `stream` is a hipStream_t (passed as void* so this header needs no HIP include). */
 int gpp_set_stream(gpp_handle_t h, void* stream);
+/* The handle's two internal streams with disjoint CU sets (created on first use): which = 0 the latency stream (32 CUs,
+ * one per shader engine) on which gpp_potrf_ws factors diagonal blocks, which = 1 the throughput stream (the other CUs)
+ * of its trailing updates.  A host-side driver that overlaps its own panel factorisations with its own updates (the
+ * sharded evaluation, gp-plus_amd/sharded.py) enqueues on them through gpp_set_stream.  *out receives a hipStream_t. */
+int gpp_internal_stream(gpp_handle_t h, int which, void** out);
 size_t gpp_workspace_bytes(gpp_handle_t h, int op, int64_t N, int64_t M, int D, int S);
 int gpp_set_workspace(gpp_handle_t h, void* ws, size_t bytes);
 
