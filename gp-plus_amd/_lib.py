@@ -37,6 +37,8 @@ _SIGNATURES = {
     "gpp_potrf_ws": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "gpp_trtri": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64]),
     "gpp_lauum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64]),
+    "gpp_syrk_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int]),
+    "gpp_lauum_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int]),
     "gpp_mll_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "gpp_alpha": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "gpp_grad_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
@@ -48,6 +50,9 @@ _SIGNATURES = {
                             c_void_p, c_int64, c_void_p, c_void_p]),
     "gpp_gemm": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, c_void_p,
                          c_int64, c_double, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int]),
+    "gpp_gemm_batched": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, c_int64,
+                                 c_void_p, c_int64, c_int64, c_double, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
+                                 c_int, c_int]),
 }
 
 _lib = None

@@ -138,6 +138,18 @@ class GppContext:
         self._stream()
         check(self.lib.gpp_lauum(self.h, Linv.data_ptr(), Linv.shape[0], _ld(Linv), Kinv.data_ptr(), _ld(Kinv)), "gpp_lauum")
 
+    def syrk_rows(self, Urow, C, nb, first_block, rank, nranks):
+        """C(upper) -= Urow^T Urow on the block rows (height nb) of C this rank owns (block-cyclic), one launch."""
+        self._stream()
+        check(self.lib.gpp_syrk_rows(self.h, Urow.data_ptr(), _ld(Urow), C.data_ptr(), _ld(C), C.shape[0], Urow.shape[0], nb,
+                                     first_block, rank, nranks), "gpp_syrk_rows")
+
+    def lauum_rows(self, Linv, Kinv, rank, nranks):
+        """This rank's cyclic share (128-row tile rows) of Kinv = Linv^T Linv, one launch."""
+        self._stream()
+        check(self.lib.gpp_lauum_rows(self.h, Linv.data_ptr(), Linv.shape[0], _ld(Linv), Kinv.data_ptr(), _ld(Kinv), rank, nranks),
+              "gpp_lauum_rows")
+
     def mll_reduce(self, L, Linv, r, z, out3):
         for t, n in ((r, "r"), (z, "z"), (out3, "out3")):
             _need(t, torch.float64, n)
@@ -180,6 +192,14 @@ class GppContext:
         self._stream()
         check(self.lib.gpp_gemm(self.h, transA, transB, M, N, K, float(alpha), A.data_ptr(), _ld(A), B.data_ptr(), _ld(B),
                                 float(beta), C.data_ptr(), _ld(C), a_mask, b_mask, klo_mode, khi_mode, c_tri), "gpp_gemm")
+
+    def gemm_batched(self, transA, transB, M, N, K, alpha, A, sA, B, sB, beta, C, sC, batch, *, a_mask=0, b_mask=0,
+                     klo_mode=0, khi_mode=0, c_tri=0):
+        """``batch`` products of one shape; A/B/C are the first elements' views, sA/sB/sC element strides between them."""
+        self._stream()
+        check(self.lib.gpp_gemm_batched(self.h, transA, transB, M, N, K, float(alpha), A.data_ptr(), _ld(A), sA, B.data_ptr(),
+                                        _ld(B), sB, float(beta), C.data_ptr(), _ld(C), sC, batch, a_mask, b_mask, klo_mode,
+                                        khi_mode, c_tri), "gpp_gemm_batched")
 
 
 def get_context(device) -> GppContext:

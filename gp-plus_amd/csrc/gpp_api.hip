@@ -499,6 +499,38 @@ int gpp_lauum(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double
   return 0;
 }
 
+int gpp_lauum_rows(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double* Kinv, int64_t ldk, int rank, int nranks) {
+  if (!h) return -1;
+  if (N < 0) return -3;
+  if (int r = check_mat(Linv, ldi, N, 2)) return r;
+  if (int r = check_mat(Kinv, ldk, N, 5)) return r;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return -7;
+  GemmArgs g = mk(Linv, ldi, Linv, ldi, Kinv, ldk, N, N, N, 1.0, 0.0);
+  g.a_mask = 2; g.b_mask = 2; g.klo_mode = 3; g.c_lower = 1; g.tag = 1;
+  g.row_mod = nranks; g.row_off = rank;
+  GPP_TRY(gpp_launch_gemm(h->stream, 2, g, 1, NBLK, NBLK));
+  return 0;
+}
+
+int gpp_syrk_rows(gpp_handle_t h, const double* Urow, int64_t ldu, double* C, int64_t ldc, int64_t Nt, int64_t K, int64_t nb,
+                  int64_t first_block, int rank, int nranks) {
+  if (!h) return -1;
+  if (!Urow || !aligned16(Urow) || (ldu & 1)) return -2;
+  if (!C || !aligned16(C) || (ldc & 1)) return -4;
+  if (Nt < 0 || K < 0) return -6;
+  if (nb < NBLK || nb % NBLK != 0) return -8;
+  if (first_block < 0) return -9;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return -10;
+  if (Nt == 0 || K == 0) return 0;
+  GemmArgs g = mk(Urow, ldu, Urow, ldu, C, ldc, Nt, Nt, K, -1.0, 1.0);
+  g.c_lower = 2;
+  g.own_mod = nranks;
+  g.own_bt = (int)(nb / NBLK);
+  g.own_off = (int)(((first_block - rank) % nranks + nranks) % nranks);
+  GPP_TRY(gpp_launch_gemm(h->stream, 2, g, 1, NBLK, NBLK));
+  return 0;
+}
+
 int gpp_mll_reduce(gpp_handle_t h, const double* U, int64_t ld, const double* Linv, int64_t ldi, int64_t N,
                    const double* r, double* z, double* out3) {
   if (!h) return -1;
@@ -630,6 +662,31 @@ int gpp_gemm(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64
     return 0;
   }
   GPP_TRY(gpp_launch_gemm(h->stream, variant, g, 1, ftm, ftn));
+  return 0;
+}
+
+int gpp_gemm_batched(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+                     int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB, double beta, double* C, int64_t ldc,
+                     int64_t sC, int batch, int a_mask, int b_mask, int klo_mode, int khi_mode, int c_tri) {
+  if (!h) return -1;
+  int variant;
+  if (transA == 0 && transB == 1) variant = 0;
+  else if (transA == 0 && transB == 0) variant = 1;
+  else if (transA == 1 && transB == 0) variant = 2;
+  else return -2;
+  if (M < 0 || N < 0 || K < 0) return -4;
+  if (!A || !aligned16(A) || (lda & 1) || (sA & 1)) return -8;
+  if (!B || !aligned16(B) || (ldb & 1) || (sB & 1)) return -11;
+  if (!C || !aligned16(C) || (ldc & 1) || (sC & 1)) return -15;
+  if (batch < 0 || batch > 65535) return -18;
+  if (a_mask < 0 || a_mask > 2 || b_mask < 0 || b_mask > 2) return -19;
+  if (klo_mode < 0 || klo_mode > 3 || khi_mode < 0 || khi_mode > 2) return -21;
+  if (c_tri < 0 || c_tri > 2 || (c_tri && M != N)) return -23;
+  if (batch == 0) return 0;
+  GemmArgs g = mk(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta);
+  g.a_mask = a_mask; g.b_mask = b_mask; g.klo_mode = klo_mode; g.khi_mode = khi_mode; g.c_lower = c_tri;
+  g.sA = sA; g.sB = sB; g.sC = sC;
+  GPP_TRY(gpp_launch_gemm(h->stream, variant, g, batch));
   return 0;
 }
 

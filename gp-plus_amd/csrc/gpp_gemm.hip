@@ -202,7 +202,16 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
     if ((p.c_lower == 1 && tn > tm) || (p.c_lower == 2 && tn < tm)) return;
   } else {
     const int t = blockIdx.x;
-    if (p.c_lower) {
+    if (p.c_lower == 1 && p.row_mod > 1) {
+      // owned tile rows tm = row_off + row_mod * i, row i has tm + 1 tiles: S(i) = i (row_off + 1) + row_mod i (i-1) / 2
+      const float a = 0.5f * (float)p.row_mod, b = (float)p.row_off + 1.f - a;
+      int i = (int)((-b + sqrtf(b * b + 4.f * a * (float)t)) / (2.f * a));
+      auto S = [&](int q) { return q * (p.row_off + 1) + p.row_mod * (q * (q - 1) / 2); };
+      while (S(i + 1) <= t) ++i;
+      while (S(i) > t) --i;
+      tm = p.row_off + p.row_mod * i;
+      tn = t - S(i);
+    } else if (p.c_lower) {
       tm = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
       while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
       while (tm * (tm + 1) / 2 > t) --tm;
@@ -211,6 +220,7 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
         const int q = tm;
         tm = tn;
         tn = q;
+        if (p.own_mod > 1 && (tm / p.own_bt + p.own_off) % p.own_mod != 0) return;  // another rank's block row
       }
     } else if (p.col_major) {
       // column-major tile order: consecutive work-groups share the column tile (hence the K range when it depends on
@@ -488,6 +498,12 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int
   a.tiles_m = (a.M + tile_m - 1) / tile_m;
   a.tiles_n = (a.N + tile_n - 1) / tile_n;
   int64_t nt = a.c_lower ? (int64_t)a.tiles_m * (a.tiles_m + 1) / 2 : (int64_t)a.tiles_m * a.tiles_n;
+  if (a.c_lower == 1 && a.row_mod > 1) {
+    if (a.row_off < 0 || a.row_off >= a.row_mod) return hipErrorInvalidValue;
+    const int64_t rows = a.tiles_m > a.row_off ? (a.tiles_m - a.row_off + a.row_mod - 1) / a.row_mod : 0;
+    nt = rows * (a.row_off + 1) + (int64_t)a.row_mod * (rows * (rows - 1) / 2);
+    if (nt == 0) return hipSuccess;
+  }
   a.swz = 0;
   // Measured on MI355X (N = 20000): the super-tile mapping LOSES 10-20 % against plain row-major order (row-major
   // already shares each A chunk among 16 and each B chunk among 4 work-groups of an XCD, and the triangular launches

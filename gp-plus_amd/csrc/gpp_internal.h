@@ -43,6 +43,10 @@ struct GemmArgs {
   int col_major;           // enumerate tiles column by column (non-triangular outputs)
   int row_reverse;         // row-major order, last row tile first
   int swz;                 // set by the launcher: XCD-aware 8x8 super-tile mapping of blockIdx -> tile
+  int own_mod, own_off, own_bt;  // c_lower == 2 only: produce the tile rows tm with (tm / own_bt + own_off) % own_mod == 0
+                           // (block-cyclic block rows of own_bt tile rows; own_mod <= 1: all).  Other tiles exit at once.
+  int row_mod, row_off;    // c_lower == 1 only: produce the tile rows tm with tm % row_mod == row_off (row_mod <= 1: all);
+                           // the sharded LAUUM, one launch per rank over its cyclic share of the 128-row tile rows
 };
 // variant: 0 = NT (A[m][k], B[n][k]), 1 = NN (A[m][k], B[k][n]), 2 = TN (A[k][m], B[k][n])
 // tile_m = 0: choose a square tile from the grid size; else force the work-group tile (128x128, 64x64, 32x32, 128x32)

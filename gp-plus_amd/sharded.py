@@ -15,8 +15,8 @@ O(N^3) stages split by 1-D block-cyclic BLOCK ROWS of the upper-stored matrices 
   inverse  column blocks of L^-1 are independent forward substitutions against the (now replicated) factor: the owner of
            column block c sweeps Y_k = -L_kk^-1 sum_{j<k} L_kj Y_j right-looking (one wide TN GEMM per step); the column
            blocks are then broadcast so that every rank holds L^-1 (lower) and its mirror (upper).
-  lauum    every rank forms the block rows of Ky^-1 = L^-T L^-1 it owns                         (no communication)
-  grad     ``gpp_grad_reduce_rows`` over the owned block rows, then ONE all-reduce of D + 1 + S (+ N dU) doubles.
+  lauum    every rank forms its tile-cyclic share (128-row tile rows) of Ky^-1 = L^-T L^-1 in one launch (no communication)
+  grad     ``gpp_grad_reduce_rows`` over the same tile rows, then ONE all-reduce of D + 1 + S (+ N dU) doubles.
 
 Communication per evaluation: the factor slabs (8 N ld B), the column blocks of the inverse (4 N^2 B) and the tiny
 all-reduce; at C5 that is ~43 GB per GPU against ~2.7e13 flop of GEMM work per GPU.  Memory per GPU: the same three
@@ -153,15 +153,15 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
             arrived.record(side)
         with torch.cuda.stream(upd):
             upd.wait_event(arrived)
-            for j in range(k + 1, nblk):
-                if j % P != me:
-                    continue
-                oj, oj1 = offs[j], offs[j + 1]
-                # A[j, j:] -= U[k, j]^T U[k, j:]   (the strictly-lower part of the diagonal block is scratch, never read)
-                ctx.gemm(1, 0, oj1 - oj, N - oj, nbk, -1.0, A[o:o1, oj:oj1], A[o:o1, oj:N], 1.0, A[oj:oj1, oj:N])
-                if j == k + 1:
+            if k + 1 < nblk:
+                # block row k+1 first (its owner factors it next), then every other owned block row in ONE launch
+                o2 = offs[k + 2] if k + 2 <= nblk else N
+                if (k + 1) % P == me:
+                    ctx.gemm(1, 0, o2 - o1, N - o1, nbk, -1.0, A[o:o1, o1:o2], A[o:o1, o1:N], 1.0, A[o1:o2, o1:N])
                     row_ready = torch.cuda.Event()
                     row_ready.record(upd)
+                if o2 < N:
+                    ctx.syrk_rows(A[o:o1, o2:N], A[o2:N, o2:N], ws.nb, k + 2, me, P)
     main.wait_stream(side)
     main.wait_stream(upd)
     info = ws.info.max().to(torch.int32).reshape(1)
@@ -174,22 +174,35 @@ def _inverse(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
     N, offs, P, me = ws.N, ws.offs, comm.world, comm.rank
     nblk = len(offs) - 1
     A, Li, Ki = ws.A, ws.Li, ws.Ki
+    nb, ld = ws.nb, ws.ld
+    Li_base = Li._base if Li._base is not None else Li
+    Ki_base = Ki._base if Ki._base is not None else Ki
     for c in range(me, nblk, P):
         oc, oc1 = offs[c], offs[c + 1]
         if oc1 < N:
             Li[oc1:N, oc:oc1].zero_()
-        for j in range(c, nblk):
-            oj, oj1 = offs[j], offs[j + 1]
-            if j > c:
-                # Y_j = -X_jj S_j  (X_jj^T = mirror in the upper part of the diagonal block), via the scratch
-                ctx.gemm(1, 0, oj1 - oj, oc1 - oc, oj1 - oj, -1.0, Li[oj:oj1, oj:oj1], Li[oj:oj1, oc:oc1], 0.0,
-                         Ki[oj:oj1, oc:oc1], a_mask=1, khi_mode=1)
-                Li[oj:oj1, oc:oc1].copy_(Ki[oj:oj1, oc:oc1])
+    # Forward substitution of all owned column blocks together, one block row j at a time.  The owned blocks left of j
+    # (c = me, me+P, ... < j, all nb wide) sit at the regular column spacing P*nb, so each step is ONE batched launch
+    # per product:  Y_j[c] = -X_jj S_j[c]  (X_jj^T = the mirror in the upper part of the diagonal block), then
+    # S_k[c] += L[k, j] Y_j[c] for every block k below (L[k, j] = U[j, k]^T, shared by the whole batch).
+    oc0 = offs[me] if me < nblk else 0
+    for j in range(nblk):
+        oj, oj1 = offs[j], offs[j + 1]
+        nbj = oj1 - oj
+        nleft = (j - me + P - 1) // P if j > me else 0
+        if nleft > 0:
+            ctx.gemm_batched(1, 0, nbj, nb, nbj, -1.0, Li[oj:oj1, oj:oj1], 0, Li[oj:oj1, oc0:oc0 + nb], P * nb, 0.0,
+                             Ki[oj:oj1, oc0:oc0 + nb], P * nb, nleft, a_mask=1, khi_mode=1)
+            shape, strides, start = (nbj, nleft, nb), (ld, P * nb, 1), oj * ld + oc0
+            Li_base.as_strided(shape, strides, start).copy_(Ki_base.as_strided(shape, strides, start))
             if oj1 < N:
-                # S_k += L[k, j] Y_j for every block k below: L[k, j] = U[j, k]^T.  Y_c is the lower-triangular X_cc: its
-                # slot also holds the mirror above the diagonal, masked out here (keep k >= n)
-                ctx.gemm(1, 0, N - oj1, oc1 - oc, oj1 - oj, 1.0, A[oj:oj1, oj1:N], Li[oj:oj1, oc:oc1], 1.0, Li[oj1:N, oc:oc1],
-                         b_mask=2 if j == c else 0, klo_mode=2 if j == c else 0)
+                ctx.gemm_batched(1, 0, N - oj1, nb, nbj, 1.0, A[oj:oj1, oj1:N], 0, Li[oj:oj1, oc0:oc0 + nb], P * nb, 1.0,
+                                 Li[oj1:N, oc0:oc0 + nb], P * nb, nleft)
+        if j % P == me and oj1 < N:
+            # own column block starts here: Y_j = X_jj itself (lower triangular; its slot also holds the mirror above the
+            # diagonal, masked out: keep k >= n)
+            ctx.gemm(1, 0, N - oj1, nbj, nbj, 1.0, A[oj:oj1, oj1:N], Li[oj:oj1, oj:oj1], 1.0, Li[oj1:N, oj:oj1], b_mask=2,
+                     klo_mode=2)
     for c in range(nblk):
         oc, oc1 = offs[c], offs[c + 1]
         if oc1 >= N:
@@ -205,16 +218,9 @@ def _inverse(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
 
 
 def _lauum_rows(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
-    """Owned block rows of Ky^-1 = L^-T L^-1 (lower triangle) into ws.Ki."""
-    N, offs, P, me = ws.N, ws.offs, comm.world, comm.rank
-    Li, Ki = ws.Li, ws.Ki
-    for m in range(me, len(offs) - 1, P):
-        om, om1 = offs[m], offs[m + 1]
-        Am = Li[om:N, om:om1]  # rows k >= om of column block m: entry (k, i) is non-zero for k >= i (block-relative)
-        if om > 0:
-            ctx.gemm(1, 0, om1 - om, om, N - om, 1.0, Am, Li[om:N, 0:om], 0.0, Ki[om:om1, 0:om], a_mask=2, klo_mode=1)
-        ctx.gemm(1, 0, om1 - om, om1 - om, N - om, 1.0, Am, Am, 0.0, Ki[om:om1, om:om1], a_mask=2, b_mask=2, klo_mode=3,
-                 c_tri=1)
+    """This rank's share of Ky^-1 = L^-T L^-1 (lower triangle) into ws.Ki: the 128-row tile rows t with t % P == rank, in
+    ONE launch of the LAUUM kernel (tile-cyclic: balanced, and as efficient as the single-GPU launch)."""
+    ctx.lauum_rows(ws.Li, ws.Ki, comm.rank, comm.world)
 
 
 class ShardedMLLFunction(torch.autograd.Function):
@@ -271,7 +277,7 @@ class ShardedMLLFunction(torch.autograd.Function):
         flat = torch.zeros(D + 1 + S + nU, dtype=torch.float64, device=dev)
         g_w, g_s, g_t = flat[:D], flat[D:D + 1], flat[D + 1:D + 1 + S]
         g_Ud = flat[D + 1 + S:].view(N, dU) if need_U else None
-        gctx.grad_reduce_rows(Ud, wd, sd, grp, S, ws.alpha, ws.Ki, dU if need_U else 0, ws.nb, comm.rank, comm.world, g_w,
+        gctx.grad_reduce_rows(Ud, wd, sd, grp, S, ws.alpha, ws.Ki, dU if need_U else 0, 128, comm.rank, comm.world, g_w,
                               g_s, g_t, g_Ud, kind=kind, d_split=d_split)
         comm.allreduce(flat)
         g_U = None

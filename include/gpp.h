@@ -99,6 +99,18 @@ int gpp_trtri(gpp_handle_t h, const double* U, int64_t N, int64_t ld, double* Li
 /* Kinv(lower) = Linv^T Linv.  With gpp_trtri this is K7's "K_y^-1" (ATen cholesky_backward, optim/mll_torch.py:117). */
 int gpp_lauum(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double* Kinv, int64_t ldk);
 
+/* Trailing update of a block-row-cyclic sharded factorisation, one launch per rank and step:
+ *   C(upper triangle of Nt x Nt) -= Urow^T Urow   on the block rows (height nb, a multiple of 128) this rank owns,
+ * block row i of C (0-based) being global block row first_block + i, owned when (first_block + i) % nranks == rank.
+ * Urow: K x Nt (the just-factored block row, right of its diagonal block), C: the trailing corner of the matrix. */
+int gpp_syrk_rows(gpp_handle_t h, const double* Urow, int64_t ldu, double* C, int64_t ldc, int64_t Nt, int64_t K, int64_t nb,
+                  int64_t first_block, int rank, int nranks);
+
+/* The share of gpp_lauum owned by one rank of a sharded evaluation: the 128-row tile rows t of Kinv with
+ * t % nranks == rank, in ONE launch (cyclic at tile granularity: every rank gets the same mix of short and long rows).
+ * Linv must be complete on this rank; the other tile rows of Kinv are not touched. */
+int gpp_lauum_rows(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double* Kinv, int64_t ldk, int rank, int nranks);
+
 /*
  * K6 (gpytorch MultivariateNormal.log_prob -> inv_quad_logdet, optim/mll_torch.py:116):
  *   z = Linv r;  out3 = { quad = z'z, logdet = 2 sum log U_ii, mll = -0.5*(quad + logdet + N log 2pi) }
@@ -148,6 +160,12 @@ int gpp_predict(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, cons
 int gpp_gemm(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
              int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int a_mask, int b_mask,
              int klo_mode, int khi_mode, int c_tri);
+
+/* `batch` independent products of the same shape in one launch: element b uses A + b*sA, B + b*sB, C + b*sC (strides in
+ * elements, even; sA = 0 shares A).  Used by the sharded inverse, whose column blocks sit at a regular column spacing. */
+int gpp_gemm_batched(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
+                     int64_t lda, int64_t sA, const double* B, int64_t ldb, int64_t sB, double beta, double* C, int64_t ldc,
+                     int64_t sC, int batch, int a_mask, int b_mask, int klo_mode, int khi_mode, int c_tri);
 
 #ifdef __cplusplus
 }

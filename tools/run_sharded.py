@@ -32,7 +32,7 @@ def main():
         torch.sub(y, mean, out=ws.r); ctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3); ctx.alpha(ws.Li, ws.z, ws.alpha)
         sharded._lauum_rows(ctx, comm, ws); sync(); t3 = time.perf_counter()
         flat = torch.zeros(D + 2, dtype=torch.float64, device=dev)
-        ctx.grad_reduce_rows(U, w, sf2, None, 1, ws.alpha, ws.Ki, 0, nb, comm.rank, comm.world, flat[:D], flat[D:D + 1], flat[D + 1:], None)
+        ctx.grad_reduce_rows(U, w, sf2, None, 1, ws.alpha, ws.Ki, 0, 128, comm.rank, comm.world, flat[:D], flat[D:D + 1], flat[D + 1:], None)
         comm.allreduce(flat); sync(); t4 = time.perf_counter()
         if rank == 0 and rep > 0:
             tot = t4 - t0
