@@ -18,8 +18,8 @@ O(N^3) stages split by 1-D block-cyclic BLOCK ROWS of the upper-stored matrices 
   lauum    every rank forms its tile-cyclic share (128-row tile rows) of Ky^-1 = L^-T L^-1 in one launch (no communication)
   grad     ``gpp_grad_reduce_rows`` over the same tile rows, then ONE all-reduce of D + 1 + S (+ N dU) doubles.
 
-Communication per evaluation: the factor slabs (8 N ld B), the column blocks of the inverse (4 N^2 B) and the tiny
-all-reduce; at C5 that is ~43 GB per GPU against ~2.7e13 flop of GEMM work per GPU.  Memory per GPU: the same three
+Communication per evaluation: the packed factor slabs (4 N^2 B), the column blocks of the inverse (4 N^2 B) and the
+tiny all-reduce; at C5 that is ~29 GB per GPU against ~2.7e13 flop of GEMM work per GPU.  Memory per GPU: the same three
 N x N buffers as the single-GPU path (86 GB at C5 of 288 GB) — nothing is scattered, so every stage after the
 factorisation reads local memory only.
 
@@ -145,9 +145,14 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
                     ctx.gemm(1, 0, nbk, rem, nbk, 1.0, Lkk, A[o:o1, o1:N], 0.0, Ki[o:o1, o1:N], a_mask=1, khi_mode=1)
                     A[o:o1, o1:N].copy_(Ki[o:o1, o1:N])
                 dblk.copy_(Lkk)
-            comm.bcast(ws.rows(A, o, nbk), k % P)
+            # only the meaningful part of the row slab travels (columns o..N, packed): half the xGMI volume of full rows
+            slab = ws.pack[:nbk * (N - o)].view(nbk, N - o)
+            if own:
+                slab.copy_(A[o:o1, o:N])
+            comm.bcast(slab, k % P)
             comm.bcast(dblk, k % P)
             if not own:
+                A[o:o1, o:N].copy_(slab)
                 Li[o:o1, o:o1].copy_(dblk)
             arrived = torch.cuda.Event()
             arrived.record(side)
