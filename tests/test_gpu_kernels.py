@@ -236,3 +236,92 @@ def test_predict(gpu_ctx):
     gpu_ctx.predict(Li, _dev(alpha), dKs, kss, dV, mo, vo)
     np.testing.assert_allclose(mo.cpu().numpy(), mean, rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(vo.cpu().numpy(), var, rtol=1e-6, atol=1e-9)
+
+
+# ---- entry points of the sharded evaluation (gp-plus_amd/sharded.py), one rank at a time ------------------------------
+def test_gemm_batched(gpu_ctx):
+    """gpp_gemm_batched: products at a regular column spacing with a shared A (the layout of the sharded inverse)."""
+    rng = np.random.default_rng(3)
+    K, M, nb, P, nbatch = 96, 200, 128, 3, 4
+    A = rng.standard_normal((K, M))                      # stored K x M (transA = 1)
+    Bfull = rng.standard_normal((K, P * nb * nbatch))    # the batch elements are the column blocks b * P * nb .. + nb
+    C0 = rng.standard_normal((M, P * nb * nbatch))
+    dA, dB, dC = _dev(A), _dev(Bfull), _dev(C0)
+    gpu_ctx.gemm_batched(1, 0, M, nb, K, 0.5, dA, 0, dB[:, :nb], P * nb, 2.0, dC[:, :nb], P * nb, nbatch)
+    ref = C0.copy()
+    for b in range(nbatch):
+        c = slice(b * P * nb, b * P * nb + nb)
+        ref[:, c] = 2.0 * C0[:, c] + 0.5 * A.T @ Bfull[:, c]
+    np.testing.assert_allclose(dC.cpu().numpy(), ref, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("nranks", [1, 2, 3])
+def test_syrk_rows_covers_the_upper_triangle_once(gpu_ctx, nranks):
+    """gpp_syrk_rows: the ranks' launches together apply C(upper) -= U^T U exactly once; each touches only its block rows."""
+    rng = np.random.default_rng(4)
+    K, Nt, nb, first = 160, 1100, 256, 5
+    U = rng.standard_normal((K, Nt))
+    C0 = rng.standard_normal((Nt, Nt))
+    dU = _dev(U)
+    C = _sq(Nt, 0.0)
+    C.copy_(_dev(C0))
+    full = C0 - U.T @ U
+    for r in range(nranks):
+        before = C.cpu().numpy().copy()
+        gpu_ctx.syrk_rows(dU, C, nb, first, r, nranks)
+        after = C.cpu().numpy()
+        for i0 in range(0, Nt, nb):
+            rows = slice(i0, min(i0 + nb, Nt))
+            mine = (first + i0 // nb) % nranks == r
+            blk_ref = np.triu(full)[rows] if mine else None
+            if mine:
+                np.testing.assert_allclose(np.triu(after)[rows][:, i0:], blk_ref[:, i0:], rtol=1e-11, atol=1e-11)
+            else:
+                np.testing.assert_array_equal(after[rows], before[rows])
+    np.testing.assert_allclose(np.triu(C.cpu().numpy()), np.triu(full), rtol=1e-11, atol=1e-11)
+
+
+@pytest.mark.parametrize("nranks", [2, 5])
+def test_lauum_rows_and_grad_reduce_rows(gpu_ctx, nranks):
+    """gpp_lauum_rows / gpp_grad_reduce_rows: the ranks' tile-row shares tile Kinv exactly, and their partial gradient
+    sums add up to gpp_grad_reduce."""
+    n, d, S, dU = 900, 6, 2, 2
+    rng = np.random.default_rng(8)
+    U = rng.standard_normal((n, d))
+    w = rng.uniform(0.05, 0.6, d)
+    tau = rng.uniform(1e-3, 1e-2, S)
+    grp = rng.integers(0, S, n).astype(np.int32)
+    dUm, dw, dgrp = _dev(U), _dev(w), _dev(grp)
+    dsf2 = torch.tensor([0.9], dtype=torch.float64, device="cuda")
+    A, Li, T, Ki = _sq(n), _sq(n), _sq(n), _sq(n)
+    gpu_ctx.kernel_build(dUm, dw, dsf2, _dev(tau), dgrp, A, uplo=2)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gpu_ctx.potrf(A, Li, info)
+    gpu_ctx.trtri(A, Li, T)
+    gpu_ctx.lauum(Li, Ki)
+    Kref = np.tril(Ki.cpu().numpy())
+    al = _dev(rng.standard_normal(n))
+    ref = [torch.empty(d, dtype=torch.float64, device="cuda"), torch.empty(1, dtype=torch.float64, device="cuda"),
+           torch.empty(S, dtype=torch.float64, device="cuda"), torch.empty(n, dU, dtype=torch.float64, device="cuda")]
+    gpu_ctx.grad_reduce(dUm, dw, dsf2, dgrp, S, al, Ki, dU, *ref)
+    acc = [torch.zeros_like(t) for t in ref]
+    Kshare = _sq(n)
+    covered = np.zeros(n, dtype=int)
+    for r in range(nranks):
+        Kshare.fill_(float("nan"))
+        gpu_ctx.lauum_rows(Li, Kshare, r, nranks)
+        got = Kshare.cpu().numpy()
+        for t0 in range(0, n, 128):
+            rows = slice(t0, min(t0 + 128, n))
+            if (t0 // 128) % nranks == r:
+                covered[rows] += 1
+                np.testing.assert_allclose(np.tril(got)[rows], Kref[rows], rtol=1e-12, atol=1e-12)
+            else:
+                assert np.isnan(got[rows]).all()       # another rank's tile rows are not touched
+        part = [torch.empty_like(t) for t in ref]
+        gpu_ctx.grad_reduce_rows(dUm, dw, dsf2, dgrp, S, al, Kshare, dU, 128, r, nranks, *part)
+        for a, p_ in zip(acc, part):
+            a += p_
+    assert (covered == 1).all()
+    for a, t in zip(acc, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), t.cpu().numpy(), rtol=1e-10, atol=1e-10 * float(t.abs().max()))
