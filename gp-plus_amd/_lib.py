@@ -53,6 +53,18 @@ _SIGNATURES = {
     "gpp_gemm_batched": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, c_int64,
                                  c_void_p, c_int64, c_int64, c_double, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int,
                                  c_int, c_int]),
+    "gpp_kernel_build_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+                                         c_double, c_int, c_int, c_int, c_void_p, c_int64, c_int64, c_int]),
+    "gpp_potrf_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int]),
+    "gpp_trtri_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int64,
+                                  c_int64, c_int]),
+    "gpp_lauum_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int]),
+    "gpp_mll_reduce_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p,
+                                       c_void_p, c_void_p, c_int]),
+    "gpp_alpha_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int]),
+    "gpp_grad_reduce_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                        c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_int]),
 }
 
 _lib = None

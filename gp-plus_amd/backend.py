@@ -201,6 +201,67 @@ class GppContext:
                                         _ld(B), sB, float(beta), C.data_ptr(), _ld(C), sC, batch, a_mask, b_mask, klo_mode,
                                         khi_mode, c_tri), "gpp_gemm_batched")
 
+    # -- batched evaluation: tensors carry a leading batch dimension -------------------------------------------
+    # matrices: (B, N, ld) views of a (B, N, ld) allocation ([:, :, :N]); vectors (B, N); parameters (B, D), (B,), (B, S)
+    def batched_buffer(self, B: int, n: int) -> torch.Tensor:
+        ld = max(16, (n + 15) // 16 * 16)
+        return torch.empty((B, n, ld), dtype=torch.float64, device=self.device)[:, :, :n]
+
+    def ensure_workspace_batched(self, B, N, D, S):
+        need = B * int(self.lib.gpp_workspace_bytes(self.h, OP_MLL_EVAL, N, 0, D, S))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+            check(self.lib.gpp_set_workspace(self.h, self._ws.data_ptr(), self._ws.numel()), "gpp_set_workspace")
+
+    def kernel_build_batched(self, U, w, sf2, tau, grp, out, *, jitter=0.0, kind=KIND_RBF, d_split=0, uplo=UPLO_FULL):
+        """U: (N, D) shared or (B, N, D); w: (B, D); sf2: (B,); tau: (B, S) or None; out: (B, N, ld) view."""
+        B, N = out.shape[0], out.shape[1]
+        D = w.shape[1]
+        sU = 0 if U.dim() == 2 else U.stride(0)
+        S = 0 if tau is None else tau.shape[1]
+        self._stream()
+        check(self.lib.gpp_kernel_build_batched(self.h, U.data_ptr(), sU, N, D, w.data_ptr(), sf2.data_ptr(), _ptr(tau),
+                                                _ptr(grp), S, float(jitter), kind, d_split, uplo, out.data_ptr(), out.stride(1),
+                                                out.stride(0), B), "gpp_kernel_build_batched")
+
+    def potrf_batched(self, A, Linv, info):
+        self._stream()
+        check(self.lib.gpp_potrf_batched(self.h, A.data_ptr(), A.shape[1], A.stride(1), A.stride(0), Linv.data_ptr(),
+                                         Linv.stride(1), Linv.stride(0), info.data_ptr(), A.shape[0]), "gpp_potrf_batched")
+
+    def trtri_batched(self, U, Linv, T):
+        self._stream()
+        check(self.lib.gpp_trtri_batched(self.h, U.data_ptr(), U.shape[1], U.stride(1), U.stride(0), Linv.data_ptr(),
+                                         Linv.stride(1), Linv.stride(0), T.data_ptr(), T.stride(1), T.stride(0), U.shape[0]),
+              "gpp_trtri_batched")
+
+    def lauum_batched(self, Linv, Kinv):
+        self._stream()
+        check(self.lib.gpp_lauum_batched(self.h, Linv.data_ptr(), Linv.shape[1], Linv.stride(1), Linv.stride(0), Kinv.data_ptr(),
+                                         Kinv.stride(1), Kinv.stride(0), Linv.shape[0]), "gpp_lauum_batched")
+
+    def mll_reduce_batched(self, L, Linv, r, z, out3):
+        self._stream()
+        check(self.lib.gpp_mll_reduce_batched(self.h, L.data_ptr(), L.stride(1), L.stride(0), Linv.data_ptr(), Linv.stride(1),
+                                              Linv.stride(0), L.shape[1], r.data_ptr(), z.data_ptr(), out3.data_ptr(), L.shape[0]),
+              "gpp_mll_reduce_batched")
+
+    def alpha_batched(self, Linv, z, alpha):
+        self._stream()
+        check(self.lib.gpp_alpha_batched(self.h, Linv.data_ptr(), Linv.stride(1), Linv.stride(0), Linv.shape[1], z.data_ptr(),
+                                         alpha.data_ptr(), Linv.shape[0]), "gpp_alpha_batched")
+
+    def grad_reduce_batched(self, U, w, sf2, grp, S, alpha, Kinv, dU, g_w, g_sf2, g_tau, g_U, *, kind=KIND_RBF, d_split=0):
+        B, N = Kinv.shape[0], Kinv.shape[1]
+        D = w.shape[1]
+        sU = 0 if U.dim() == 2 else U.stride(0)
+        self.ensure_workspace_batched(B, N, D, S)
+        self._stream()
+        check(self.lib.gpp_grad_reduce_batched(self.h, U.data_ptr(), sU, N, D, w.data_ptr(), sf2.data_ptr(), _ptr(grp), S, kind,
+                                               d_split, alpha.data_ptr(), Kinv.data_ptr(), Kinv.stride(1), Kinv.stride(0), dU,
+                                               g_w.data_ptr(), g_sf2.data_ptr(), g_tau.data_ptr(), _ptr(g_U), B),
+              "gpp_grad_reduce_batched")
+
 
 def get_context(device) -> GppContext:
     device = torch.device(device)

@@ -109,6 +109,30 @@ hipError_t potrf_blk(const Ctx& c, int64_t o, int64_t n) {
   return hipSuccess;
 }
 
+// The same leaf-step factorisation for `batch` independent matrices at A + b*sA (inverse leaves at Li + b*sLi, info + b):
+// every launch covers the whole batch, so 64 restarts of a 500-point model cost the latency chain of ONE.
+hipError_t potrf_blk_batched(const Ctx& c, int64_t n, int batch, int64_t sA, int64_t sLi) {
+  for (int64_t j0 = 0; j0 < n; j0 += NBLK) {
+    const int64_t nb = std::min<int64_t>(NBLK, n - j0), oo = j0, rem = n - j0 - nb;
+    hipError_t e = gpp_launch_leaf(c.s, c.A + oo * c.ld + oo, c.ld, c.Li + oo * c.ldi + oo, c.ldi, (int)nb, c.info, (int)oo,
+                                   batch, sA, sLi);
+    if (e != hipSuccess) return e;
+    if (rem == 0) break;
+    double* Bp = c.A + oo * c.ld + (oo + nb);
+    GemmArgs g = mk(c.Li + oo * c.ldi + oo, c.ldi, Bp, c.ld, Bp, c.ld, nb, rem, nb, 1.0, 0.0);
+    g.a_mask = 1;
+    g.sA = sLi; g.sB = sA; g.sC = sA;
+    e = gpp_launch_gemm(c.s, 2, g, batch, NBLK, 32);
+    if (e != hipSuccess) return e;
+    GemmArgs u = mk(Bp, c.ld, Bp, c.ld, c.A + (oo + nb) * c.ld + (oo + nb), c.ld, rem, rem, nb, -1.0, 1.0);
+    u.c_lower = 2;
+    u.sA = sA; u.sB = sA; u.sC = sA;
+    e = gpp_launch_gemm(c.s, 2, u, batch, 32, 32);
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 hipError_t potrf_rec(const Ctx& c, int64_t o, int64_t n) {
   if (n <= 0) return hipSuccess;
   if (n <= NBLK)
@@ -134,7 +158,8 @@ hipError_t potrf_rec(const Ctx& c, int64_t o, int64_t n) {
 //     T21 = U12^T Linv11 ;  Linv21 = -W22^T T21 (+ mirror).  ``skip(b)`` drops pairs that are already merged.
 template <typename Skip>
 hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt,
-                       int64_t base, int64_t n, int64_t s, Skip skip) {
+                       int64_t base, int64_t n, int64_t s, Skip skip, int mbatch = 1, int64_t msU = 0, int64_t msLi = 0,
+                       int64_t msT = 0) {
   const int64_t npairs_full = n / (2 * s);
   const int64_t rem = n - npairs_full * 2 * s;  // leftover rows after the full pairs
   auto launch = [&](int64_t o, int64_t m2, int batch) -> hipError_t {
@@ -143,6 +168,7 @@ hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv
     GemmArgs g1 = mk(U + o * ld + (o + s), ld, Linv + o * ldi + o, ldi, T + (o + s) * ldt + o, ldt, m2, s, s, 1.0, 0.0);
     g1.b_mask = 2; g1.klo_mode = 2; g1.col_major = 1;  // K range depends on the column tile: keep columns together
     g1.sA = pstride_U; g1.sB = pstride_I; g1.sC = pstride_T;
+    g1.batch2 = mbatch; g1.zA = msU; g1.zB = msLi; g1.zC = msT;  // independent matrices (batched evaluation)
     hipError_t e = gpp_launch_gemm(st, 2, g1, batch);
     if (e != hipSuccess) return e;
     // Linv21 = -W22^T * T21  (TN; W22 = mirrored upper part of the (o+s) block: keep k <= m), plus its mirror
@@ -151,6 +177,7 @@ hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv
     g2.a_mask = 1; g2.khi_mode = 1; g2.row_reverse = 1;
     g2.sA = pstride_I; g2.sB = pstride_T; g2.sC = pstride_I;
     g2.C2 = Linv + o * ldi + (o + s); g2.ldc2 = ldi; g2.sC2 = pstride_I;
+    g2.batch2 = mbatch; g2.zA = msLi; g2.zB = msT; g2.zC = msLi; g2.zC2 = msLi;
     return gpp_launch_gemm(st, 2, g2, batch);
   };
   // full pairs: batched over maximal runs of pairs that still need merging
@@ -687,6 +714,126 @@ int gpp_gemm_batched(gpp_handle_t h, int transA, int transB, int64_t M, int64_t 
   g.a_mask = a_mask; g.b_mask = b_mask; g.klo_mode = klo_mode; g.khi_mode = khi_mode; g.c_lower = c_tri;
   g.sA = sA; g.sB = sB; g.sC = sC;
   GPP_TRY(gpp_launch_gemm(h->stream, variant, g, batch));
+  return 0;
+}
+
+// ---- batched evaluation: `batch` independent problems of the same size in every launch ----------------------------
+static int check_batch(int batch, int argi) { return (batch < 1 || batch > 65535) ? -argi : 0; }
+
+int gpp_kernel_build_batched(gpp_handle_t h, const double* U, int64_t sU, int64_t N, int D, const double* w, const double* sf2,
+                             const double* tau, const int32_t* grp, int S, double jitter, int kind, int d_split, int uplo,
+                             double* Ky, int64_t ld, int64_t sK, int batch) {
+  if (!h) return -1;
+  if (!U) return -2;
+  if (N < 0) return -4;
+  if (D < 1 || D > 64) return -5;
+  if (!w) return -6;
+  if (!sf2) return -7;
+  if (tau && S < 1) return -10;
+  if (kind < 0 || kind > 2) return -12;
+  if (d_split < 0 || d_split > D) return -13;
+  if (uplo != GPP_UPLO_FULL && uplo != GPP_UPLO_LOWER && uplo != GPP_UPLO_UPPER) return -14;
+  if (!Ky) return -15;
+  if (ld < N || (sK & 1) || (sU != 0 && sU < N * D)) return -16;
+  if (int r = check_batch(batch, 18)) return r;
+  GPP_TRY(gpp_launch_kernel_build(h->stream, U, N, D, w, sf2, tau, grp, S, jitter, kind, d_split, uplo, Ky, ld, 0, N, batch, sU, sK));
+  return 0;
+}
+
+int gpp_potrf_batched(gpp_handle_t h, double* A, int64_t N, int64_t ld, int64_t sA, double* Linv, int64_t ldi, int64_t sLi,
+                      int32_t* info_dev, int batch) {
+  if (!h) return -1;
+  if (N < 0 || N > BLK_MAX) return -3;  // the batched path is the leaf-step factorisation: small and medium N only
+  if (int r = check_mat(A, ld, N, 2)) return r;
+  if (int r = check_mat(Linv, ldi, N, 6)) return r;
+  if ((sA & 1) || (sLi & 1)) return -5;
+  if (!info_dev) return -9;
+  if (int r = check_batch(batch, 10)) return r;
+  GPP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int32_t) * (size_t)batch, h->stream));
+  Ctx c{h->stream, A, ld, Linv, ldi, info_dev};
+  GPP_TRY(potrf_blk_batched(c, N, batch, sA, sLi));
+  return 0;
+}
+
+int gpp_trtri_batched(gpp_handle_t h, const double* U, int64_t N, int64_t ld, int64_t sA, double* Linv, int64_t ldi,
+                      int64_t sLi, double* T, int64_t ldt, int64_t sT, int batch) {
+  if (!h) return -1;
+  if (N < 0) return -3;
+  if (int r = check_mat(U, ld, N, 2)) return r;
+  if (int r = check_mat(Linv, ldi, N, 6)) return r;
+  if (int r = check_mat(T, ldt, N, 9)) return r;
+  if ((sA & 1) || (sLi & 1) || (sT & 1)) return -5;
+  if (int r = check_batch(batch, 12)) return r;
+  for (int64_t s = NBLK; s < N; s *= 2)
+    GPP_TRY(trtri_level(h->stream, U, ld, Linv, ldi, T, ldt, 0, N, s, [](int64_t) { return false; }, batch, sA, sLi, sT));
+  return 0;
+}
+
+int gpp_lauum_batched(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, int64_t sLi, double* Kinv, int64_t ldk,
+                      int64_t sK, int batch) {
+  if (!h) return -1;
+  if (N < 0) return -3;
+  if (int r = check_mat(Linv, ldi, N, 2)) return r;
+  if (int r = check_mat(Kinv, ldk, N, 6)) return r;
+  if ((sLi & 1) || (sK & 1)) return -5;
+  if (int r = check_batch(batch, 9)) return r;
+  GemmArgs g = mk(Linv, ldi, Linv, ldi, Kinv, ldk, N, N, N, 1.0, 0.0);
+  g.a_mask = 2; g.b_mask = 2; g.klo_mode = 3; g.c_lower = 1;
+  g.sA = sLi; g.sB = sLi; g.sC = sK;
+  GPP_TRY(gpp_launch_gemm(h->stream, 2, g, batch));
+  return 0;
+}
+
+int gpp_mll_reduce_batched(gpp_handle_t h, const double* U, int64_t ld, int64_t sA, const double* Linv, int64_t ldi,
+                           int64_t sLi, int64_t N, const double* r, double* z, double* out3, int batch) {
+  if (!h) return -1;
+  if (N < 0) return -8;
+  if (int q = check_mat(U, ld, N, 2)) return q;
+  if (int q = check_mat(Linv, ldi, N, 5)) return q;
+  if (!r || !aligned16(r) || (N & 1 && batch > 1)) return -9;  // rows of r/z start at b*N: keep them 16-byte aligned
+  if (!z) return -10;
+  if (!out3) return -11;
+  if (int q = check_batch(batch, 12)) return q;
+  GPP_TRY(gpp_launch_trmv_lower(h->stream, Linv, ldi, N, r, z, batch, sLi));
+  GPP_TRY(gpp_launch_mll_scalars(h->stream, U, ld, N, z, out3, batch, sA));
+  return 0;
+}
+
+int gpp_alpha_batched(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t sLi, int64_t N, const double* z, double* alpha,
+                      int batch) {
+  if (!h) return -1;
+  if (N < 0) return -5;
+  if (int q = check_mat(Linv, ldi, N, 2)) return q;
+  if (!z || !aligned16(z) || (N & 1 && batch > 1)) return -6;
+  if (!alpha) return -7;
+  if (int q = check_batch(batch, 8)) return q;
+  GPP_TRY(gpp_launch_trmv_upper(h->stream, Linv, ldi, N, z, alpha, batch, sLi));
+  return 0;
+}
+
+int gpp_grad_reduce_batched(gpp_handle_t h, const double* U, int64_t sU, int64_t N, int D, const double* w, const double* sf2,
+                            const int32_t* grp, int S, int kind, int d_split, const double* alpha, const double* Kinv,
+                            int64_t ldk, int64_t sK, int dU, double* g_w, double* g_sf2, double* g_tau, double* g_U, int batch) {
+  if (!h) return -1;
+  if (!U) return -2;
+  if (N < 0) return -4;
+  if (D < 1 || D > 64) return -5;
+  if (!w) return -6;
+  if (!sf2) return -7;
+  if (S < 1 || S > 64) return -9;
+  if (kind < 0 || kind > 2) return -10;
+  if (d_split < 0 || d_split > D) return -11;
+  if (!alpha) return -12;
+  if (int q = check_mat(Kinv, ldk, N, 13)) return q;
+  if (dU < 0 || dU > D) return -16;
+  if (!g_w) return -17;
+  if (!g_sf2) return -18;
+  if (!g_tau) return -19;
+  if (dU > 0 && !g_U) return -20;
+  if (int q = check_batch(batch, 21)) return q;
+  if (!h->ws || h->ws_bytes < (size_t)batch * gpp_grad_ws_bytes(N, D, S, dU)) return -1;
+  GPP_TRY(gpp_launch_grad_reduce(h->stream, U, N, D, w, sf2, grp, S, kind, d_split, alpha, Kinv, ldk, dU, g_w, g_sf2, g_tau,
+                                 g_U, h->ws, h->ws_bytes, 0, 0, 1, batch, sU, sK));
   return 0;
 }
 

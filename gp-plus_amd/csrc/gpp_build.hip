@@ -37,9 +37,19 @@ __global__ __launch_bounds__(256) void gpp_cov_tile(const double* __restrict__ U
                                                     const double* __restrict__ sf2p, const double* __restrict__ tau,
                                                     const int32_t* __restrict__ grp, double jitter, int kind, int d_split,
                                                     int lower, int add_diag, double* __restrict__ K, int64_t ld,
-                                                    int64_t row0, int tiles_n, int64_t tile_row0) {
+                                                    int64_t row0, int tiles_n, int64_t tile_row0, int64_t sU, int64_t sK,
+                                                    int S) {
   __shared__ double sa[DMAX * TB];
   __shared__ double sb[DMAX * TB];
+  {  // batch element blockIdx.y: its own features (sU = 0: shared), weights, scale, noise levels and output matrix
+    const int64_t b = blockIdx.y;
+    Ua += b * sU;
+    Ub += b * sU;
+    w += b * D;
+    sf2p += b;
+    if (tau) tau += b * S;
+    K += b * sK;
+  }
   int64_t ti, tj;
   {
     const int64_t t = blockIdx.x;
@@ -135,9 +145,9 @@ __global__ __launch_bounds__(256) void gpp_cov_tile(const double* __restrict__ U
 
 hipError_t gpp_launch_kernel_build(hipStream_t s, const double* U, int64_t N, int D, const double* w, const double* sf2,
                                    const double* tau, const int32_t* grp, int S, double jitter, int kind, int d_split,
-                                   int uplo, double* Ky, int64_t ld, int64_t row0, int64_t nrows) {
-  (void)S;
-  if (N <= 0 || nrows <= 0) return hipSuccess;
+                                   int uplo, double* Ky, int64_t ld, int64_t row0, int64_t nrows, int batch, int64_t sU,
+                                   int64_t sK) {
+  if (N <= 0 || nrows <= 0 || batch <= 0) return hipSuccess;
   if (D > DMAX) return hipErrorInvalidValue;
   const int64_t tr0 = row0 / TB;
   const int64_t tr1 = (row0 + nrows + TB - 1) / TB;  // exclusive
@@ -146,8 +156,8 @@ hipError_t gpp_launch_kernel_build(hipStream_t s, const double* U, int64_t N, in
   if (uplo) nt = tr1 * (tr1 + 1) / 2 - tr0 * (tr0 + 1) / 2;
   else nt = (tr1 - tr0) * tiles_n;
   // rows of the last tile row beyond row0+nrows are cut by passing Ma = row0+nrows
-  hipLaunchKernelGGL(gpp_cov_tile, dim3((unsigned)nt), dim3(256), 0, s, U, row0 + nrows, U, N, D, w, sf2, tau, grp, jitter,
-                     kind, d_split, uplo, 1, Ky, ld, row0, tiles_n, tr0);
+  hipLaunchKernelGGL(gpp_cov_tile, dim3((unsigned)nt, (unsigned)batch), dim3(256), 0, s, U, row0 + nrows, U, N, D, w, sf2, tau,
+                     grp, jitter, kind, d_split, uplo, 1, Ky, ld, row0, tiles_n, tr0, sU, sK, S);
   return hipGetLastError();
 }
 
@@ -159,6 +169,6 @@ hipError_t gpp_launch_cross_kernel(hipStream_t s, const double* Ua, int64_t Ma, 
   const int64_t tiles_m = (Ma + TB - 1) / TB;
   hipLaunchKernelGGL(gpp_cov_tile, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, s, Ua, Ma, Ub, Nb, D, w, sf2,
                      (const double*)nullptr, (const int32_t*)nullptr, 0.0, kind, d_split, 0, 0, Kab, ld, (int64_t)0,
-                     tiles_n, (int64_t)0);
+                     tiles_n, (int64_t)0, (int64_t)0, (int64_t)0, 0);
   return hipGetLastError();
 }

@@ -233,9 +233,9 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
       if (p.row_reverse) tm = p.tiles_m - 1 - tm;  // longest K ranges (khi grows with the row) first: short tail
     }
   }
-  const double* __restrict__ A = p.A + (int64_t)blockIdx.y * p.sA;
-  const double* __restrict__ B = p.B + (int64_t)blockIdx.y * p.sB;
-  double* __restrict__ C = p.C + (int64_t)blockIdx.y * p.sC;
+  const double* __restrict__ A = p.A + (int64_t)blockIdx.y * p.sA + (int64_t)blockIdx.z * p.zA;
+  const double* __restrict__ B = p.B + (int64_t)blockIdx.y * p.sB + (int64_t)blockIdx.z * p.zB;
+  double* __restrict__ C = p.C + (int64_t)blockIdx.y * p.sC + (int64_t)blockIdx.z * p.zC;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -430,7 +430,8 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
         if (beta != 0.0) v = fma(beta, cold[a][b], v);
         if (ok) {
           C[(int64_t)m * p.ldc + n] = v;
-          if (p.C2) p.C2[(int64_t)blockIdx.y * p.sC2 + (int64_t)n * p.ldc2 + m] = v;  // mirrored (transposed) copy
+          if (p.C2)  // mirrored (transposed) copy
+            p.C2[(int64_t)blockIdx.y * p.sC2 + (int64_t)blockIdx.z * p.zC2 + (int64_t)n * p.ldc2 + m] = v;
         }
       }
     }
@@ -485,7 +486,7 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int
   if (a.M <= 0 || a.N <= 0 || batch <= 0) return hipSuccess;
   auto ntiles = [&](int T) -> int64_t {
     const int64_t tm = (a.M + T - 1) / T, tn = (a.N + T - 1) / T;
-    return (a.c_lower ? tm * (tm + 1) / 2 : tm * tn) * batch;  // triangular output needs M == N
+    return (a.c_lower ? tm * (tm + 1) / 2 : tm * tn) * batch * (a.batch2 > 1 ? a.batch2 : 1);  // triangular: M == N
   };
   if (tile_m == 0) {
     // enough 128^2 tiles to give every CU a work-group -> big tile; otherwise shrink until the chip is covered
@@ -513,7 +514,8 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int
     nt = ((n_super + 7) / 8) * 8 * 64;
     a.swz = 1;
   }
-  dim3 grid((unsigned)nt, (unsigned)batch, 1);
+  const int batch2 = a.batch2 > 1 ? a.batch2 : 1;
+  dim3 grid((unsigned)nt, (unsigned)batch, (unsigned)batch2);
   switch (variant) {
     case 0: return launch_var<0>(s, tile_m, tile_n, grid, a);
     case 1: return launch_var<1>(s, tile_m, tile_n, grid, a);

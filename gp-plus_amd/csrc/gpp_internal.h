@@ -35,6 +35,8 @@ struct GemmArgs {
   int klo_mode, khi_mode;  // see gpp.h
   int c_lower;             // 0 full, 1 lower triangle only (n <= m), 2 upper triangle only (n >= m)
   int64_t sA, sB, sC;      // batch strides in elements (grid.y = batch)
+  int64_t zA, zB, zC, zC2; // second-level batch strides (grid.z = batch2; 0 batch2 means 1): independent problems
+  int batch2;
   int tiles_m, tiles_n;
   double* C2;              // optional mirrored output: C2[n][m] = C[m][n]
   int64_t ldc2, sC2;
@@ -55,26 +57,35 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a, int ba
 // ---- 128x128 diagonal leaf: Cholesky + triangular inverse in LDS (gpp_leaf.hip) ---------------
 // A holds the UPPER factor (A = U^T U, i.e. L = U^T read/written with swapped indices); the n x n diagonal block of
 // Linv receives inv(L) in its lower triangle and the mirror image inv(L)^T in its strict upper triangle.
+// batch > 1: independent blocks at A + b*sA, Linv + b*sLi, info + b (one work-group each).
 hipError_t gpp_launch_leaf(hipStream_t s, double* A, int64_t lda, double* Linv, int64_t ldi, int n, int32_t* info,
-                           int row_offset);
+                           int row_offset, int batch = 1, int64_t sA = 0, int64_t sLi = 0);
 
 // ---- covariance tiles (gpp_build.hip) ---------------------------------------------------------
+// batch > 1: independent parameter sets b: U + b*sU (sU = 0 shares the features), w + b*D, sf2 + b, tau + b*S, Ky + b*sK.
 hipError_t gpp_launch_kernel_build(hipStream_t s, const double* U, int64_t N, int D, const double* w, const double* sf2,
                                    const double* tau, const int32_t* grp, int S, double jitter, int kind, int d_split,
-                                   int uplo, double* Ky, int64_t ld, int64_t row0, int64_t nrows);
+                                   int uplo, double* Ky, int64_t ld, int64_t row0, int64_t nrows, int batch = 1,
+                                   int64_t sU = 0, int64_t sK = 0);
 hipError_t gpp_launch_cross_kernel(hipStream_t s, const double* Ua, int64_t Ma, const double* Ub, int64_t Nb, int D,
                                    const double* w, const double* sf2, int kind, int d_split, double* Kab, int64_t ld);
 
 // ---- reductions (gpp_reduce.hip) --------------------------------------------------------------
-hipError_t gpp_launch_trmv_lower(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y);
-hipError_t gpp_launch_trmv_upper(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y);
-hipError_t gpp_launch_mll_scalars(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* z, double* out3);
-size_t gpp_grad_ws_bytes(int64_t N, int D, int S, int dU);
+// batch > 1 (all reductions): matrices at + b*sT, vectors at + b*N, out3 at + 3*b
+hipError_t gpp_launch_trmv_lower(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
+                                 int batch = 1, int64_t sT = 0);
+hipError_t gpp_launch_trmv_upper(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
+                                 int batch = 1, int64_t sT = 0);
+hipError_t gpp_launch_mll_scalars(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* z, double* out3,
+                                  int batch = 1, int64_t sL = 0);
+size_t gpp_grad_ws_bytes(int64_t N, int D, int S, int dU);  // per batch element
 hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int D, const double* w, const double* sf2,
                                   const int32_t* grp, int S, int kind, int d_split, const double* alpha,
                                   const double* Kinv, int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau,
                                   double* g_U, void* ws, size_t ws_bytes, int shard_nb = 0, int shard_rank = 0,
-                                  int shard_nranks = 1);
+                                  int shard_nranks = 1, int batch = 1, int64_t sU = 0, int64_t sK = 0);
+// (batch > 1: U + b*sU, w + b*D, sf2 + b, alpha + b*N, Kinv + b*sK; outputs g_w + b*D, g_sf2 + b, g_tau + b*S,
+//  g_U + b*N*dU; the workspace holds batch * gpp_grad_ws_bytes)
 hipError_t gpp_launch_predict_reduce(hipStream_t s, const double* Ksn, int64_t lds, const double* V, int64_t ldv,
                                      int64_t M, int64_t N, const double* alpha, const double* kss, double* mean_out,
                                      double* var_out);

@@ -258,7 +258,11 @@ __device__ __forceinline__ void write_linv_block(double* __restrict__ Linv, int6
 }
 
 __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
-                                                          int64_t ldi, int n, int32_t* info, int row_offset) {
+                                                          int64_t ldi, int n, int32_t* info, int row_offset, int64_t sA,
+                                                          int64_t sLi) {
+  A += (int64_t)blockIdx.x * sA;  // batch element: an independent block
+  Linv += (int64_t)blockIdx.x * sLi;
+  info += blockIdx.x;
   // ONE 36-tile image of exactly 72 KiB: LDS is allocated contiguously, so on the look-ahead stream the leaf can only
   // start beside a running GEMM work-group if it fits the 72.5 KiB slot a finished GEMM work-group leaves behind.
   // Slot (i,j) holds, in turn: the parked raw tile; L(i,j) (off-diagonal) or L_jj with its diagonal replaced by the
@@ -415,8 +419,8 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
 }  // namespace
 
 hipError_t gpp_launch_leaf(hipStream_t s, double* A, int64_t lda, double* Linv, int64_t ldi, int n, int32_t* info,
-                           int row_offset) {
-  if (n <= 0) return hipSuccess;
+                           int row_offset, int batch, int64_t sA, int64_t sLi) {
+  if (n <= 0 || batch <= 0) return hipSuccess;
   if (n > NB) return hipErrorInvalidValue;
   static bool attr_set[64] = {false};  // per device (function attributes are per device)
   const size_t shmem = (size_t)NT * TSZ * sizeof(double);
@@ -429,6 +433,7 @@ hipError_t gpp_launch_leaf(hipStream_t s, double* A, int64_t lda, double* Linv, 
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL(gpp_leaf_potrf_inv, dim3(1), dim3(256), shmem, s, A, lda, Linv, ldi, n, info, row_offset);
+  hipLaunchKernelGGL(gpp_leaf_potrf_inv, dim3((unsigned)batch), dim3(256), shmem, s, A, lda, Linv, ldi, n, info, row_offset, sA,
+                     sLi);
   return hipGetLastError();
 }

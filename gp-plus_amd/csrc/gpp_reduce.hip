@@ -20,10 +20,13 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // y_i = sum_{k<=i} T[i][k] x_k : one wave per row, rows interleaved over waves so long and short rows mix.
 __global__ __launch_bounds__(256) void gpp_trmv_lower(const double* __restrict__ T, int64_t ldt, int64_t N,
-                                                      const double* __restrict__ x, double* __restrict__ y) {
+                                                      const double* __restrict__ x, double* __restrict__ y, int64_t sT) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + wave;
   if (i >= N) return;
+  T += (int64_t)blockIdx.y * sT;  // batch element
+  x += (int64_t)blockIdx.y * N;
+  y += (int64_t)blockIdx.y * N;
   const double* row = T + i * ldt;
   double acc = 0.0;
   const int64_t len = i + 1;
@@ -41,10 +44,13 @@ __global__ __launch_bounds__(256) void gpp_trmv_lower(const double* __restrict__
 
 // y_j = sum_{i>=j} T[j][i] x_i for the UPPER triangle of T: one wave per row (the mirror of gpp_trmv_lower).
 __global__ __launch_bounds__(256) void gpp_trmv_upper(const double* __restrict__ T, int64_t ldt, int64_t N,
-                                                      const double* __restrict__ x, double* __restrict__ y) {
+                                                      const double* __restrict__ x, double* __restrict__ y, int64_t sT) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t j = (int64_t)blockIdx.x * 4 + wave;
   if (j >= N) return;
+  T += (int64_t)blockIdx.y * sT;  // batch element
+  x += (int64_t)blockIdx.y * N;
+  y += (int64_t)blockIdx.y * N;
   const double* row = T + j * ldt;
   double acc = 0.0;
   int64_t k0 = j;
@@ -66,8 +72,11 @@ __global__ __launch_bounds__(256) void gpp_trmv_upper(const double* __restrict__
 
 // out3 = { quad = z'z, logdet = 2 sum log L_ii, mll = -0.5 (quad + logdet + N log 2pi) } : one work-group.
 __global__ __launch_bounds__(1024) void gpp_mll_scalars(const double* __restrict__ L, int64_t ld, int64_t N,
-                                                        const double* __restrict__ z, double* __restrict__ out3) {
+                                                        const double* __restrict__ z, double* __restrict__ out3, int64_t sL) {
   __shared__ double sq[16], sl[16];
+  L += (int64_t)blockIdx.x * sL;  // batch element
+  z += (int64_t)blockIdx.x * N;
+  out3 += 3 * (int64_t)blockIdx.x;
   double q = 0.0, l = 0.0;
   for (int64_t i = threadIdx.x; i < N; i += 1024) {
     const double zi = z[i];
@@ -121,10 +130,21 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
                                                       const double* __restrict__ w, const double* __restrict__ sf2p,
                                                       int kind, int d_split, const double* __restrict__ alpha, const double* __restrict__ Kinv,
                                                       int64_t ldk, int dU, int64_t ntiles, int shard_nb, int shard_rank,
-                                                      int shard_nranks,
+                                                      int shard_nranks, int64_t sU, int64_t sK, int64_t ws_stride,
                                                       double* __restrict__ rec /* [gridDim.x][D+1] */,
                                                       double* __restrict__ wdiag /* [N] */,
                                                       double* __restrict__ gUpart /* [T][N][dU] */) {
+  {  // batch element blockIdx.y: its own parameters, matrices and slice of the workspace
+    const int64_t b = blockIdx.y;
+    U += b * sU;
+    w += b * D;
+    sf2p += b;
+    alpha += b * N;
+    Kinv += b * sK;
+    rec += b * ws_stride;
+    wdiag += b * ws_stride;
+    gUpart += b * ws_stride;
+  }
   __shared__ double sa[DT * GT];  // raw U rows of tile-row ti, [d][r]
   __shared__ double sb[DT * GT];
   __shared__ double sal_a[GT], sal_b[GT];
@@ -282,8 +302,13 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
 __global__ __launch_bounds__(256) void gpp_grad_finish(const double* __restrict__ rec, int nwg, int D, int S,
                                                        const double* __restrict__ wdiag, const int32_t* __restrict__ grp,
                                                        int64_t N, double* __restrict__ g_w, double* __restrict__ g_sf2,
-                                                       double* __restrict__ g_tau) {
+                                                       double* __restrict__ g_tau, int64_t ws_stride) {
   __shared__ double red[256];
+  rec += (int64_t)blockIdx.y * ws_stride;  // batch element
+  wdiag += (int64_t)blockIdx.y * ws_stride;
+  g_w += (int64_t)blockIdx.y * D;
+  g_sf2 += blockIdx.y;
+  g_tau += (int64_t)blockIdx.y * S;
   const int q = blockIdx.x, nrec = D + 1, tid = threadIdx.x;
   double v = 0.0;
   if (q <= D) {
@@ -307,9 +332,11 @@ __global__ __launch_bounds__(256) void gpp_grad_finish(const double* __restrict_
 }
 
 __global__ __launch_bounds__(256) void gpp_gU_finish(const double* __restrict__ gUpart, int64_t N, int dU, int T,
-                                                     double* __restrict__ g_U) {
+                                                     double* __restrict__ g_U, int64_t ws_stride) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (e >= N * dU) return;
+  gUpart += (int64_t)blockIdx.y * ws_stride;  // batch element
+  g_U += (int64_t)blockIdx.y * N * dU;
   double s = 0.0;
   for (int t = 0; t < T; ++t) s += gUpart[(int64_t)t * N * dU + e];
   g_U[e] = s;
@@ -340,20 +367,24 @@ __global__ __launch_bounds__(256) void gpp_predict_rows(const double* __restrict
 
 }  // namespace
 
-hipError_t gpp_launch_trmv_lower(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y) {
-  if (N <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gpp_trmv_lower, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, T, ldt, N, x, y);
+hipError_t gpp_launch_trmv_lower(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
+                                 int batch, int64_t sT) {
+  if (N <= 0 || batch <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gpp_trmv_lower, dim3((unsigned)((N + 3) / 4), (unsigned)batch), dim3(256), 0, s, T, ldt, N, x, y, sT);
   return hipGetLastError();
 }
 
-hipError_t gpp_launch_trmv_upper(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y) {
-  if (N <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gpp_trmv_upper, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, T, ldt, N, x, y);
+hipError_t gpp_launch_trmv_upper(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
+                                 int batch, int64_t sT) {
+  if (N <= 0 || batch <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gpp_trmv_upper, dim3((unsigned)((N + 3) / 4), (unsigned)batch), dim3(256), 0, s, T, ldt, N, x, y, sT);
   return hipGetLastError();
 }
 
-hipError_t gpp_launch_mll_scalars(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* z, double* out3) {
-  hipLaunchKernelGGL(gpp_mll_scalars, dim3(1), dim3(1024), 0, s, L, ld, N, z, out3);
+hipError_t gpp_launch_mll_scalars(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* z, double* out3,
+                                  int batch, int64_t sL) {
+  if (batch <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gpp_mll_scalars, dim3((unsigned)batch), dim3(1024), 0, s, L, ld, N, z, out3, sL);
   return hipGetLastError();
 }
 
@@ -367,12 +398,15 @@ size_t gpp_grad_ws_bytes(int64_t N, int D, int S, int dU) {
 hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int D, const double* w, const double* sf2,
                                   const int32_t* grp, int S, int kind, int d_split, const double* alpha,
                                   const double* Kinv, int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau,
-                                  double* g_U, void* ws, size_t ws_bytes, int shard_nb, int shard_rank, int shard_nranks) {
+                                  double* g_U, void* ws, size_t ws_bytes, int shard_nb, int shard_rank, int shard_nranks,
+                                  int batch, int64_t sU, int64_t sK) {
   if (kind < 0 || kind > 2) return hipErrorInvalidValue;
+  if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
   if (shard_nranks > 1 && (shard_nb < GT || shard_nb % GT != 0 || shard_rank < 0 || shard_rank >= shard_nranks))
     return hipErrorInvalidValue;
   if (D > GD_MAX || D < 1 || S > GS_MAX || S < 1 || dU > D || dU < 0) return hipErrorInvalidValue;
-  if (ws_bytes < gpp_grad_ws_bytes(N, D, S, dU)) return hipErrorInvalidValue;
+  if (ws_bytes < (size_t)batch * gpp_grad_ws_bytes(N, D, S, dU)) return hipErrorInvalidValue;
+  const int64_t ws_stride = (int64_t)(gpp_grad_ws_bytes(N, D, S, dU) / sizeof(double));  // doubles per batch element
   const int T = (int)((N + GT - 1) / GT);
   const int64_t ntiles = (int64_t)T * (T + 1) / 2;
   const int nwg = (int)(ntiles < G_WGS ? ntiles : G_WGS);
@@ -380,20 +414,22 @@ hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int
   double* wdiag = rec + (size_t)G_WGS * (D + 1);
   double* gUpart = wdiag + N;
   if (shard_nranks > 1) {  // skipped tiles leave their slots unwritten: start from zero
-    hipError_t e = hipMemsetAsync(wdiag, 0, (size_t)N * sizeof(double) + (size_t)T * N * (dU > 0 ? dU : 0) * sizeof(double), s);
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)batch * ws_stride * sizeof(double), s);
     if (e != hipSuccess) return e;
   }
 #define GPP_GRAD_LAUNCH(DT)                                                                                              \
-  hipLaunchKernelGGL(gpp_grad_tiles<DT>, dim3(nwg), dim3(256), 0, s, U, N, D, w, sf2, kind, d_split, alpha, Kinv, ldk, dU, \
-                     ntiles, shard_nb, shard_rank, shard_nranks, rec, wdiag, gUpart)
+  hipLaunchKernelGGL(gpp_grad_tiles<DT>, dim3(nwg, batch), dim3(256), 0, s, U, N, D, w, sf2, kind, d_split, alpha, Kinv, ldk, dU, \
+                     ntiles, shard_nb, shard_rank, shard_nranks, sU, sK, ws_stride, rec, wdiag, gUpart)
   if (D <= 8) GPP_GRAD_LAUNCH(8);
   else if (D <= 16) GPP_GRAD_LAUNCH(16);
   else if (D <= 32) GPP_GRAD_LAUNCH(32);
   else GPP_GRAD_LAUNCH(64);
 #undef GPP_GRAD_LAUNCH
-  hipLaunchKernelGGL(gpp_grad_finish, dim3(D + 1 + S), dim3(256), 0, s, rec, nwg, D, S, wdiag, grp, N, g_w, g_sf2, g_tau);
+  hipLaunchKernelGGL(gpp_grad_finish, dim3(D + 1 + S, batch), dim3(256), 0, s, rec, nwg, D, S, wdiag, grp, N, g_w, g_sf2, g_tau,
+                     ws_stride);
   if (dU > 0)
-    hipLaunchKernelGGL(gpp_gU_finish, dim3((unsigned)((N * dU + 255) / 256)), dim3(256), 0, s, gUpart, N, dU, T, g_U);
+    hipLaunchKernelGGL(gpp_gU_finish, dim3((unsigned)((N * dU + 255) / 256), batch), dim3(256), 0, s, gUpart, N, dU, T, g_U,
+                       ws_stride);
   return hipGetLastError();
 }
 

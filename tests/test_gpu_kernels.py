@@ -325,3 +325,57 @@ def test_lauum_rows_and_grad_reduce_rows(gpu_ctx, nranks):
     assert (covered == 1).all()
     for a, t in zip(acc, ref):
         np.testing.assert_allclose(a.cpu().numpy(), t.cpu().numpy(), rtol=1e-10, atol=1e-10 * float(t.abs().max()))
+
+
+@pytest.mark.parametrize("n,d,S,dU,shared", [(300, 5, 1, 0, True), (778, 8, 3, 2, False), (130, 4, 2, 4, False)])
+def test_batched_evaluation_matches_single(gpu_ctx, n, d, S, dU, shared):
+    """The *_batched entry points (B independent problems per launch) against B runs of the single-problem ones."""
+    B = 5
+    rng = np.random.default_rng(n + 1)
+    Ub = rng.standard_normal((1 if shared else B, n, d))
+    w = rng.uniform(0.05, 0.6, (B, d))
+    sf2 = rng.uniform(0.5, 1.5, B)
+    tau = rng.uniform(1e-3, 1e-2, (B, S))
+    grp = rng.integers(0, S, n).astype(np.int32)
+    r = rng.standard_normal((B, n))
+    dU_, dw, ds, dt, dg, dr = _dev(Ub[0] if shared else Ub), _dev(w), _dev(sf2), _dev(tau), _dev(grp), _dev(r)
+    A, Li, Ki = (gpu_ctx.batched_buffer(B, n) for _ in range(3))
+    info = torch.zeros(B, dtype=torch.int32, device="cuda")
+    z = torch.empty(B, n, dtype=torch.float64, device="cuda"); al = torch.empty_like(z)
+    out3 = torch.empty(B, 3, dtype=torch.float64, device="cuda")
+    gw = torch.empty(B, d, dtype=torch.float64, device="cuda"); gs = torch.empty(B, dtype=torch.float64, device="cuda")
+    gt = torch.empty(B, S, dtype=torch.float64, device="cuda")
+    gU = torch.empty(B, n, dU, dtype=torch.float64, device="cuda") if dU else None
+    gpu_ctx.kernel_build_batched(dU_, dw, ds, dt, dg, A, uplo=2)
+    gpu_ctx.potrf_batched(A, Li, info)
+    assert int(info.abs().max().item()) == 0
+    gpu_ctx.trtri_batched(A, Li, Ki)
+    gpu_ctx.mll_reduce_batched(A, Li, dr, z, out3)
+    gpu_ctx.alpha_batched(Li, z, al)
+    gpu_ctx.lauum_batched(Li, Ki)
+    gpu_ctx.grad_reduce_batched(dU_, dw, ds, dg, S, al, Ki, dU, gw, gs, gt, gU)
+    for b in range(B):
+        Us = _dev(Ub[0] if shared else Ub[b])
+        A1, L1, T1, K1 = _sq(n), _sq(n), _sq(n), _sq(n)
+        i1 = torch.zeros(1, dtype=torch.int32, device="cuda")
+        gpu_ctx.kernel_build(Us, dw[b].contiguous(), ds[b:b + 1].contiguous(), dt[b].contiguous(), dg, A1, uplo=2)
+        gpu_ctx.potrf(A1, L1, i1)
+        gpu_ctx.trtri(A1, L1, T1)
+        z1 = torch.empty(n, dtype=torch.float64, device="cuda"); a1 = torch.empty_like(z1)
+        o1 = torch.empty(3, dtype=torch.float64, device="cuda")
+        gpu_ctx.mll_reduce(A1, L1, dr[b].contiguous(), z1, o1)
+        gpu_ctx.alpha(L1, z1, a1)
+        gpu_ctx.lauum(L1, K1)
+        w1 = torch.empty(d, dtype=torch.float64, device="cuda"); s1 = torch.empty(1, dtype=torch.float64, device="cuda")
+        t1 = torch.empty(S, dtype=torch.float64, device="cuda")
+        u1 = torch.empty(n, dU, dtype=torch.float64, device="cuda") if dU else None
+        gpu_ctx.grad_reduce(Us, dw[b].contiguous(), ds[b:b + 1].contiguous(), dg, S, a1, K1, dU, w1, s1, t1, u1)
+        tol = dict(rtol=1e-11, atol=1e-11)
+        np.testing.assert_allclose(out3[b].cpu().numpy(), o1.cpu().numpy(), **tol)
+        np.testing.assert_allclose(al[b].cpu().numpy(), a1.cpu().numpy(), rtol=1e-9, atol=1e-9 * float(a1.abs().max()))
+        np.testing.assert_allclose(np.tril(Ki[b].cpu().numpy()), np.tril(K1.cpu().numpy()), rtol=1e-9, atol=1e-9 * float(K1.abs().max()))
+        np.testing.assert_allclose(gw[b].cpu().numpy(), w1.cpu().numpy(), rtol=1e-9, atol=1e-9 * float(w1.abs().max()))
+        np.testing.assert_allclose(gs[b].item(), s1.item(), rtol=1e-9)
+        np.testing.assert_allclose(gt[b].cpu().numpy(), t1.cpu().numpy(), rtol=1e-9, atol=1e-9 * float(t1.abs().max()))
+        if dU:
+            np.testing.assert_allclose(gU[b].cpu().numpy(), u1.cpu().numpy(), rtol=1e-9, atol=1e-9 * float(u1.abs().max()))
