@@ -60,10 +60,10 @@ _SIGNATURES = {
                                   c_int64, c_int]),
     "gpp_lauum_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int]),
     "gpp_mll_reduce_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_int64, c_void_p,
-                                       c_void_p, c_void_p, c_int]),
-    "gpp_alpha_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int]),
+                                       c_void_p, c_int64, c_void_p, c_int]),
+    "gpp_alpha_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int]),
     "gpp_grad_reduce_batched": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                        c_int, c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
+                                        c_int, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_void_p, c_void_p, c_void_p,
                                         c_void_p, c_int]),
 }
 

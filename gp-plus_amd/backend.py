@@ -202,10 +202,14 @@ class GppContext:
                                         khi_mode, c_tri), "gpp_gemm_batched")
 
     # -- batched evaluation: tensors carry a leading batch dimension -------------------------------------------
-    # matrices: (B, N, ld) views of a (B, N, ld) allocation ([:, :, :N]); vectors (B, N); parameters (B, D), (B,), (B, S)
+    # matrices: (B, N, ld) views of a (B, N, ld) allocation ([:, :, :N]); vectors: (B, N) views of a (B, sv) allocation
+    # with sv even (``batched_vector``); parameters (B, D), (B,), (B, S)
     def batched_buffer(self, B: int, n: int) -> torch.Tensor:
         ld = max(16, (n + 15) // 16 * 16)
         return torch.empty((B, n, ld), dtype=torch.float64, device=self.device)[:, :, :n]
+
+    def batched_vector(self, B: int, n: int) -> torch.Tensor:
+        return torch.empty((B, n + (n & 1)), dtype=torch.float64, device=self.device)[:, :n]
 
     def ensure_workspace_batched(self, B, N, D, S):
         need = B * int(self.lib.gpp_workspace_bytes(self.h, OP_MLL_EVAL, N, 0, D, S))
@@ -243,13 +247,20 @@ class GppContext:
     def mll_reduce_batched(self, L, Linv, r, z, out3):
         self._stream()
         check(self.lib.gpp_mll_reduce_batched(self.h, L.data_ptr(), L.stride(1), L.stride(0), Linv.data_ptr(), Linv.stride(1),
-                                              Linv.stride(0), L.shape[1], r.data_ptr(), z.data_ptr(), out3.data_ptr(), L.shape[0]),
-              "gpp_mll_reduce_batched")
+                                              Linv.stride(0), L.shape[1], r.data_ptr(), z.data_ptr(), self._sv(r, z), out3.data_ptr(),
+                                              L.shape[0]), "gpp_mll_reduce_batched")
+
+    @staticmethod
+    def _sv(*vecs):
+        sv = vecs[0].stride(0)
+        if any(v.stride(0) != sv or v.stride(1) != 1 for v in vecs) or (sv & 1):
+            raise GppError("batched vectors must share one even row stride (use GppContext.batched_vector)")
+        return sv
 
     def alpha_batched(self, Linv, z, alpha):
         self._stream()
         check(self.lib.gpp_alpha_batched(self.h, Linv.data_ptr(), Linv.stride(1), Linv.stride(0), Linv.shape[1], z.data_ptr(),
-                                         alpha.data_ptr(), Linv.shape[0]), "gpp_alpha_batched")
+                                         alpha.data_ptr(), self._sv(z, alpha), Linv.shape[0]), "gpp_alpha_batched")
 
     def grad_reduce_batched(self, U, w, sf2, grp, S, alpha, Kinv, dU, g_w, g_sf2, g_tau, g_U, *, kind=KIND_RBF, d_split=0):
         B, N = Kinv.shape[0], Kinv.shape[1]
@@ -258,7 +269,8 @@ class GppContext:
         self.ensure_workspace_batched(B, N, D, S)
         self._stream()
         check(self.lib.gpp_grad_reduce_batched(self.h, U.data_ptr(), sU, N, D, w.data_ptr(), sf2.data_ptr(), _ptr(grp), S, kind,
-                                               d_split, alpha.data_ptr(), Kinv.data_ptr(), Kinv.stride(1), Kinv.stride(0), dU,
+                                               d_split, alpha.data_ptr(), self._sv(alpha), Kinv.data_ptr(), Kinv.stride(1),
+                                               Kinv.stride(0), dU,
                                                g_w.data_ptr(), g_sf2.data_ptr(), g_tau.data_ptr(), _ptr(g_U), B),
               "gpp_grad_reduce_batched")
 

@@ -785,35 +785,38 @@ int gpp_lauum_batched(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi
 }
 
 int gpp_mll_reduce_batched(gpp_handle_t h, const double* U, int64_t ld, int64_t sA, const double* Linv, int64_t ldi,
-                           int64_t sLi, int64_t N, const double* r, double* z, double* out3, int batch) {
+                           int64_t sLi, int64_t N, const double* r, double* z, int64_t sv, double* out3, int batch) {
   if (!h) return -1;
   if (N < 0) return -8;
   if (int q = check_mat(U, ld, N, 2)) return q;
   if (int q = check_mat(Linv, ldi, N, 5)) return q;
-  if (!r || !aligned16(r) || (N & 1 && batch > 1)) return -9;  // rows of r/z start at b*N: keep them 16-byte aligned
-  if (!z) return -10;
-  if (!out3) return -11;
-  if (int q = check_batch(batch, 12)) return q;
-  GPP_TRY(gpp_launch_trmv_lower(h->stream, Linv, ldi, N, r, z, batch, sLi));
-  GPP_TRY(gpp_launch_mll_scalars(h->stream, U, ld, N, z, out3, batch, sA));
+  if (!r || !aligned16(r)) return -9;
+  if (!z || !aligned16(z)) return -10;
+  if (sv < N || (sv & 1)) return -11;  // rows of r / z / alpha start at b*sv: 16-byte aligned
+  if (!out3) return -12;
+  if (int q = check_batch(batch, 13)) return q;
+  GPP_TRY(gpp_launch_trmv_lower(h->stream, Linv, ldi, N, r, z, batch, sLi, sv));
+  GPP_TRY(gpp_launch_mll_scalars(h->stream, U, ld, N, z, out3, batch, sA, sv));
   return 0;
 }
 
 int gpp_alpha_batched(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t sLi, int64_t N, const double* z, double* alpha,
-                      int batch) {
+                      int64_t sv, int batch) {
   if (!h) return -1;
   if (N < 0) return -5;
   if (int q = check_mat(Linv, ldi, N, 2)) return q;
-  if (!z || !aligned16(z) || (N & 1 && batch > 1)) return -6;
-  if (!alpha) return -7;
-  if (int q = check_batch(batch, 8)) return q;
-  GPP_TRY(gpp_launch_trmv_upper(h->stream, Linv, ldi, N, z, alpha, batch, sLi));
+  if (!z || !aligned16(z)) return -6;
+  if (!alpha || !aligned16(alpha)) return -7;
+  if (sv < N || (sv & 1)) return -8;
+  if (int q = check_batch(batch, 9)) return q;
+  GPP_TRY(gpp_launch_trmv_upper(h->stream, Linv, ldi, N, z, alpha, batch, sLi, sv));
   return 0;
 }
 
 int gpp_grad_reduce_batched(gpp_handle_t h, const double* U, int64_t sU, int64_t N, int D, const double* w, const double* sf2,
-                            const int32_t* grp, int S, int kind, int d_split, const double* alpha, const double* Kinv,
-                            int64_t ldk, int64_t sK, int dU, double* g_w, double* g_sf2, double* g_tau, double* g_U, int batch) {
+                            const int32_t* grp, int S, int kind, int d_split, const double* alpha, int64_t sv,
+                            const double* Kinv, int64_t ldk, int64_t sK, int dU, double* g_w, double* g_sf2, double* g_tau,
+                            double* g_U, int batch) {
   if (!h) return -1;
   if (!U) return -2;
   if (N < 0) return -4;
@@ -830,10 +833,11 @@ int gpp_grad_reduce_batched(gpp_handle_t h, const double* U, int64_t sU, int64_t
   if (!g_sf2) return -18;
   if (!g_tau) return -19;
   if (dU > 0 && !g_U) return -20;
-  if (int q = check_batch(batch, 21)) return q;
+  if (int q = check_batch(batch, 22)) return q;
+  if (sv < N) return -13;
   if (!h->ws || h->ws_bytes < (size_t)batch * gpp_grad_ws_bytes(N, D, S, dU)) return -1;
   GPP_TRY(gpp_launch_grad_reduce(h->stream, U, N, D, w, sf2, grp, S, kind, d_split, alpha, Kinv, ldk, dU, g_w, g_sf2, g_tau,
-                                 g_U, h->ws, h->ws_bytes, 0, 0, 1, batch, sU, sK));
+                                 g_U, h->ws, h->ws_bytes, 0, 0, 1, batch, sU, sK, sv));
   return 0;
 }
 

@@ -71,20 +71,20 @@ hipError_t gpp_launch_cross_kernel(hipStream_t s, const double* Ua, int64_t Ma, 
                                    const double* w, const double* sf2, int kind, int d_split, double* Kab, int64_t ld);
 
 // ---- reductions (gpp_reduce.hip) --------------------------------------------------------------
-// batch > 1 (all reductions): matrices at + b*sT, vectors at + b*N, out3 at + 3*b
+// batch > 1 (all reductions): matrices at + b*sT, vectors at + b*sv (sv even, >= N), out3 at + 3*b
 hipError_t gpp_launch_trmv_lower(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
-                                 int batch = 1, int64_t sT = 0);
+                                 int batch = 1, int64_t sT = 0, int64_t sv = 0);
 hipError_t gpp_launch_trmv_upper(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
-                                 int batch = 1, int64_t sT = 0);
+                                 int batch = 1, int64_t sT = 0, int64_t sv = 0);
 hipError_t gpp_launch_mll_scalars(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* z, double* out3,
-                                  int batch = 1, int64_t sL = 0);
+                                  int batch = 1, int64_t sL = 0, int64_t sv = 0);
 size_t gpp_grad_ws_bytes(int64_t N, int D, int S, int dU);  // per batch element
 hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int D, const double* w, const double* sf2,
                                   const int32_t* grp, int S, int kind, int d_split, const double* alpha,
                                   const double* Kinv, int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau,
                                   double* g_U, void* ws, size_t ws_bytes, int shard_nb = 0, int shard_rank = 0,
-                                  int shard_nranks = 1, int batch = 1, int64_t sU = 0, int64_t sK = 0);
-// (batch > 1: U + b*sU, w + b*D, sf2 + b, alpha + b*N, Kinv + b*sK; outputs g_w + b*D, g_sf2 + b, g_tau + b*S,
+                                  int shard_nranks = 1, int batch = 1, int64_t sU = 0, int64_t sK = 0, int64_t sv = 0);
+// (batch > 1: U + b*sU, w + b*D, sf2 + b, alpha + b*sv, Kinv + b*sK; outputs g_w + b*D, g_sf2 + b, g_tau + b*S,
 //  g_U + b*N*dU; the workspace holds batch * gpp_grad_ws_bytes)
 hipError_t gpp_launch_predict_reduce(hipStream_t s, const double* Ksn, int64_t lds, const double* V, int64_t ldv,
                                      int64_t M, int64_t N, const double* alpha, const double* kss, double* mean_out,

@@ -20,13 +20,14 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 // y_i = sum_{k<=i} T[i][k] x_k : one wave per row, rows interleaved over waves so long and short rows mix.
 __global__ __launch_bounds__(256) void gpp_trmv_lower(const double* __restrict__ T, int64_t ldt, int64_t N,
-                                                      const double* __restrict__ x, double* __restrict__ y, int64_t sT) {
+                                                      const double* __restrict__ x, double* __restrict__ y, int64_t sT,
+                                                      int64_t sv) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + wave;
   if (i >= N) return;
   T += (int64_t)blockIdx.y * sT;  // batch element
-  x += (int64_t)blockIdx.y * N;
-  y += (int64_t)blockIdx.y * N;
+  x += (int64_t)blockIdx.y * sv;
+  y += (int64_t)blockIdx.y * sv;
   const double* row = T + i * ldt;
   double acc = 0.0;
   const int64_t len = i + 1;
@@ -44,13 +45,14 @@ __global__ __launch_bounds__(256) void gpp_trmv_lower(const double* __restrict__
 
 // y_j = sum_{i>=j} T[j][i] x_i for the UPPER triangle of T: one wave per row (the mirror of gpp_trmv_lower).
 __global__ __launch_bounds__(256) void gpp_trmv_upper(const double* __restrict__ T, int64_t ldt, int64_t N,
-                                                      const double* __restrict__ x, double* __restrict__ y, int64_t sT) {
+                                                      const double* __restrict__ x, double* __restrict__ y, int64_t sT,
+                                                      int64_t sv) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t j = (int64_t)blockIdx.x * 4 + wave;
   if (j >= N) return;
   T += (int64_t)blockIdx.y * sT;  // batch element
-  x += (int64_t)blockIdx.y * N;
-  y += (int64_t)blockIdx.y * N;
+  x += (int64_t)blockIdx.y * sv;
+  y += (int64_t)blockIdx.y * sv;
   const double* row = T + j * ldt;
   double acc = 0.0;
   int64_t k0 = j;
@@ -72,10 +74,11 @@ __global__ __launch_bounds__(256) void gpp_trmv_upper(const double* __restrict__
 
 // out3 = { quad = z'z, logdet = 2 sum log L_ii, mll = -0.5 (quad + logdet + N log 2pi) } : one work-group.
 __global__ __launch_bounds__(1024) void gpp_mll_scalars(const double* __restrict__ L, int64_t ld, int64_t N,
-                                                        const double* __restrict__ z, double* __restrict__ out3, int64_t sL) {
+                                                        const double* __restrict__ z, double* __restrict__ out3, int64_t sL,
+                                                        int64_t sv) {
   __shared__ double sq[16], sl[16];
   L += (int64_t)blockIdx.x * sL;  // batch element
-  z += (int64_t)blockIdx.x * N;
+  z += (int64_t)blockIdx.x * sv;
   out3 += 3 * (int64_t)blockIdx.x;
   double q = 0.0, l = 0.0;
   for (int64_t i = threadIdx.x; i < N; i += 1024) {
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
                                                       const double* __restrict__ w, const double* __restrict__ sf2p,
                                                       int kind, int d_split, const double* __restrict__ alpha, const double* __restrict__ Kinv,
                                                       int64_t ldk, int dU, int64_t ntiles, int shard_nb, int shard_rank,
-                                                      int shard_nranks, int64_t sU, int64_t sK, int64_t ws_stride,
+                                                      int shard_nranks, int64_t sU, int64_t sK, int64_t sv, int64_t ws_stride,
                                                       double* __restrict__ rec /* [gridDim.x][D+1] */,
                                                       double* __restrict__ wdiag /* [N] */,
                                                       double* __restrict__ gUpart /* [T][N][dU] */) {
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
     U += b * sU;
     w += b * D;
     sf2p += b;
-    alpha += b * N;
+    alpha += b * sv;
     Kinv += b * sK;
     rec += b * ws_stride;
     wdiag += b * ws_stride;
@@ -368,23 +371,23 @@ __global__ __launch_bounds__(256) void gpp_predict_rows(const double* __restrict
 }  // namespace
 
 hipError_t gpp_launch_trmv_lower(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
-                                 int batch, int64_t sT) {
+                                 int batch, int64_t sT, int64_t sv) {
   if (N <= 0 || batch <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gpp_trmv_lower, dim3((unsigned)((N + 3) / 4), (unsigned)batch), dim3(256), 0, s, T, ldt, N, x, y, sT);
+  hipLaunchKernelGGL(gpp_trmv_lower, dim3((unsigned)((N + 3) / 4), (unsigned)batch), dim3(256), 0, s, T, ldt, N, x, y, sT, sv);
   return hipGetLastError();
 }
 
 hipError_t gpp_launch_trmv_upper(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
-                                 int batch, int64_t sT) {
+                                 int batch, int64_t sT, int64_t sv) {
   if (N <= 0 || batch <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gpp_trmv_upper, dim3((unsigned)((N + 3) / 4), (unsigned)batch), dim3(256), 0, s, T, ldt, N, x, y, sT);
+  hipLaunchKernelGGL(gpp_trmv_upper, dim3((unsigned)((N + 3) / 4), (unsigned)batch), dim3(256), 0, s, T, ldt, N, x, y, sT, sv);
   return hipGetLastError();
 }
 
 hipError_t gpp_launch_mll_scalars(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* z, double* out3,
-                                  int batch, int64_t sL) {
+                                  int batch, int64_t sL, int64_t sv) {
   if (batch <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gpp_mll_scalars, dim3((unsigned)batch), dim3(1024), 0, s, L, ld, N, z, out3, sL);
+  hipLaunchKernelGGL(gpp_mll_scalars, dim3((unsigned)batch), dim3(1024), 0, s, L, ld, N, z, out3, sL, sv);
   return hipGetLastError();
 }
 
@@ -399,7 +402,7 @@ hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int
                                   const int32_t* grp, int S, int kind, int d_split, const double* alpha,
                                   const double* Kinv, int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau,
                                   double* g_U, void* ws, size_t ws_bytes, int shard_nb, int shard_rank, int shard_nranks,
-                                  int batch, int64_t sU, int64_t sK) {
+                                  int batch, int64_t sU, int64_t sK, int64_t sv) {
   if (kind < 0 || kind > 2) return hipErrorInvalidValue;
   if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
   if (shard_nranks > 1 && (shard_nb < GT || shard_nb % GT != 0 || shard_rank < 0 || shard_rank >= shard_nranks))
@@ -419,7 +422,7 @@ hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int
   }
 #define GPP_GRAD_LAUNCH(DT)                                                                                              \
   hipLaunchKernelGGL(gpp_grad_tiles<DT>, dim3(nwg, batch), dim3(256), 0, s, U, N, D, w, sf2, kind, d_split, alpha, Kinv, ldk, dU, \
-                     ntiles, shard_nb, shard_rank, shard_nranks, sU, sK, ws_stride, rec, wdiag, gUpart)
+                     ntiles, shard_nb, shard_rank, shard_nranks, sU, sK, sv, ws_stride, rec, wdiag, gUpart)
   if (D <= 8) GPP_GRAD_LAUNCH(8);
   else if (D <= 16) GPP_GRAD_LAUNCH(16);
   else if (D <= 32) GPP_GRAD_LAUNCH(32);

@@ -170,9 +170,9 @@ int gpp_gemm_batched(gpp_handle_t h, int transA, int transB, int64_t M, int64_t 
 /*
  * Batched evaluation: `batch` independent problems of the SAME size N in every launch (the restarts of a multistart
  * fit, optim/mll_torch.py:99-141, evaluated together instead of one after the other).  Element b uses the matrices at
- * base + b*s? (strides in elements, even), parameters w + b*D, sf2 + b, tau + b*S, vectors r/z/alpha + b*N, out3 + 3*b,
- * info_dev + b, and returns g_w + b*D, g_sf2 + b, g_tau + b*S, g_U + b*N*dU.  sU = 0 shares one feature matrix.  N must
- * be even when batch > 1 (vector rows stay 16-byte aligned) and at most 4096 for gpp_potrf_batched (the leaf-step
+ * base + b*s? (strides in elements, even), parameters w + b*D, sf2 + b, tau + b*S, vectors r/z/alpha + b*sv (sv >= N,
+ * even), out3 + 3*b, info_dev + b, and returns g_w + b*D, g_sf2 + b, g_tau + b*S, g_U + b*N*dU.  sU = 0 shares one
+ * feature matrix.  N is at most 4096 for gpp_potrf_batched (the leaf-step
  * factorisation); gpp_trtri_batched completes the inverse from the 128-blocks, so it follows gpp_potrf_batched
  * directly.  The workspace must hold batch * gpp_workspace_bytes(GPP_OP_MLL_EVAL, ...).
  */
@@ -186,12 +186,13 @@ int gpp_trtri_batched(gpp_handle_t h, const double* U, int64_t N, int64_t ld, in
 int gpp_lauum_batched(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, int64_t sLi, double* Kinv, int64_t ldk,
                       int64_t sK, int batch);
 int gpp_mll_reduce_batched(gpp_handle_t h, const double* U, int64_t ld, int64_t sA, const double* Linv, int64_t ldi,
-                           int64_t sLi, int64_t N, const double* r, double* z, double* out3, int batch);
+                           int64_t sLi, int64_t N, const double* r, double* z, int64_t sv, double* out3, int batch);
 int gpp_alpha_batched(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t sLi, int64_t N, const double* z, double* alpha,
-                      int batch);
+                      int64_t sv, int batch);
 int gpp_grad_reduce_batched(gpp_handle_t h, const double* U, int64_t sU, int64_t N, int D, const double* w, const double* sf2,
-                            const int32_t* grp, int S, int kind, int d_split, const double* alpha, const double* Kinv,
-                            int64_t ldk, int64_t sK, int dU, double* g_w, double* g_sf2, double* g_tau, double* g_U, int batch);
+                            const int32_t* grp, int S, int kind, int d_split, const double* alpha, int64_t sv,
+                            const double* Kinv, int64_t ldk, int64_t sK, int dU, double* g_w, double* g_sf2, double* g_tau,
+                            double* g_U, int batch);
 
 #ifdef __cplusplus
 }

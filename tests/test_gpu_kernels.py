@@ -327,7 +327,7 @@ def test_lauum_rows_and_grad_reduce_rows(gpu_ctx, nranks):
         np.testing.assert_allclose(a.cpu().numpy(), t.cpu().numpy(), rtol=1e-10, atol=1e-10 * float(t.abs().max()))
 
 
-@pytest.mark.parametrize("n,d,S,dU,shared", [(300, 5, 1, 0, True), (778, 8, 3, 2, False), (130, 4, 2, 4, False)])
+@pytest.mark.parametrize("n,d,S,dU,shared", [(300, 5, 1, 0, True), (777, 8, 3, 2, False), (130, 4, 2, 4, False)])
 def test_batched_evaluation_matches_single(gpu_ctx, n, d, S, dU, shared):
     """The *_batched entry points (B independent problems per launch) against B runs of the single-problem ones."""
     B = 5
@@ -338,10 +338,11 @@ def test_batched_evaluation_matches_single(gpu_ctx, n, d, S, dU, shared):
     tau = rng.uniform(1e-3, 1e-2, (B, S))
     grp = rng.integers(0, S, n).astype(np.int32)
     r = rng.standard_normal((B, n))
-    dU_, dw, ds, dt, dg, dr = _dev(Ub[0] if shared else Ub), _dev(w), _dev(sf2), _dev(tau), _dev(grp), _dev(r)
+    dU_, dw, ds, dt, dg = _dev(Ub[0] if shared else Ub), _dev(w), _dev(sf2), _dev(tau), _dev(grp)
     A, Li, Ki = (gpu_ctx.batched_buffer(B, n) for _ in range(3))
     info = torch.zeros(B, dtype=torch.int32, device="cuda")
-    z = torch.empty(B, n, dtype=torch.float64, device="cuda"); al = torch.empty_like(z)
+    dr, z, al = (gpu_ctx.batched_vector(B, n) for _ in range(3))   # odd n: rows padded to an even stride
+    dr.copy_(_dev(r))
     out3 = torch.empty(B, 3, dtype=torch.float64, device="cuda")
     gw = torch.empty(B, d, dtype=torch.float64, device="cuda"); gs = torch.empty(B, dtype=torch.float64, device="cuda")
     gt = torch.empty(B, S, dtype=torch.float64, device="cuda")
