@@ -380,3 +380,36 @@ def test_batched_evaluation_matches_single(gpu_ctx, n, d, S, dU, shared):
         np.testing.assert_allclose(gt[b].cpu().numpy(), t1.cpu().numpy(), rtol=1e-9, atol=1e-9 * float(t1.abs().max()))
         if dU:
             np.testing.assert_allclose(gU[b].cpu().numpy(), u1.cpu().numpy(), rtol=1e-9, atol=1e-9 * float(u1.abs().max()))
+
+
+def test_batched_mll_function_matches_single(gpu_ctx):
+    """batched.BatchedMLLFunction (values and every gradient, per batch element) against linalg.ExactMLLFunction; a
+    non-positive-definite element returns NaN with zero gradients and does not disturb the others."""
+    from gpplus_amd.batched import batched_mll
+    from gpplus_amd.linalg import KernelSpec, exact_mll
+
+    B, n, d, S, dU = 4, 301, 5, 2, 2
+    rng = np.random.default_rng(21)
+    Ub = torch.tensor(rng.standard_normal((B, n, d)), device="cuda", requires_grad=True)
+    w = torch.tensor(rng.uniform(0.05, 0.6, (B, d)), device="cuda", requires_grad=True)
+    sf2 = torch.tensor(rng.uniform(0.5, 1.5, B), device="cuda", requires_grad=True)
+    tau0 = rng.uniform(1e-3, 1e-2, (B, S)); tau0[2] = -5.0          # element 2: negative "noise" -> not p.d.
+    tau = torch.tensor(tau0, device="cuda", requires_grad=True)
+    mean = torch.tensor(rng.standard_normal((B, n)) * 0.1, device="cuda", requires_grad=True)
+    y = torch.tensor(rng.standard_normal(n), device="cuda")
+    grp = torch.tensor(rng.integers(0, S, n).astype(np.int32), device="cuda")
+    mll = batched_mll(Ub, w, sf2, tau, mean, y, grp, n_grad_dims=dU)
+    assert torch.isnan(mll[2]) and torch.isfinite(mll[[0, 1, 3]]).all()
+    coef = torch.tensor([1.0, -2.0, 3.0, 0.5], device="cuda", dtype=torch.float64)
+    torch.nansum(mll * coef).backward()
+    for b in (0, 1, 3):
+        Us = Ub[b].detach().clone().requires_grad_(True)
+        ws_, ss, ts, ms = (t[b].detach().clone().requires_grad_(True) for t in (w, sf2, tau, mean))
+        one = exact_mll(Us, KernelSpec(ws_, ss), ts, ms, y, grp=grp, n_grad_dims=dU)
+        (one * coef[b]).backward()
+        assert abs(one.item() - mll[b].item()) <= 1e-10 * abs(one.item())
+        for name, gb, g1 in (("U", Ub.grad[b], Us.grad), ("w", w.grad[b], ws_.grad), ("sf2", sf2.grad[b], ss.grad),
+                             ("tau", tau.grad[b], ts.grad), ("mean", mean.grad[b], ms.grad)):
+            np.testing.assert_allclose(gb.cpu().numpy(), g1.cpu().numpy(), rtol=1e-8, atol=1e-9 * float(g1.abs().max()), err_msg=name)
+    for g in (Ub.grad[2], w.grad[2], sf2.grad[2], tau.grad[2], mean.grad[2]):
+        assert float(g.abs().max()) == 0.0
