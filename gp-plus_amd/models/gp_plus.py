@@ -301,6 +301,11 @@ class GP_Plus(GPR):
         if optim_type == 'adam_torch':
             out = fit_model_torch(model=self, model_param_groups=None, lr_default=0.01, num_iter=100, num_restarts=64,
                                   break_steps=50)
+        elif optim_type == 'adam_torch_batched':
+            # same optimisation (64 restarts x 100 Adam steps) with all runs advancing together, one batched evaluation
+            # per iteration (optim/mll_batched.py): not in the reference, which runs its restarts one after the other
+            from ..optim import fit_model_torch_batched
+            out = fit_model_torch_batched(self, lr_default=0.01, num_iter=100, num_restarts=64, break_steps=50)
         else:
             warnings.warn('The model is built to run on CUDA (GPU), but the current optimization type is invalid for '
                           'this configuration. So, the optimizer is now using adam_torch to train the model.')

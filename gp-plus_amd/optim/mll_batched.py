@@ -1,0 +1,164 @@
+"""Restart-parallel Adam fit on ONE GPU: all ``num_restarts + 1`` runs of ``optim/mll_torch.py:99-141`` advance together,
+every iteration being one batched evaluation (``batched.BatchedMLLFunction``: B problems per kernel launch).
+
+The reference runs its restarts one after the other; for the data sizes of its examples (N = 100 ... 500) a single
+evaluation leaves an MI355X almost empty, so evaluating the 5 ... 65 parameter sets together costs about as much as
+evaluating one.  Semantics kept from ``fit_model_torch``: run 0 starts from the model's current parameters, run i >= 1
+from the i-th ``model.reset_parameters()`` sample (same RNG order); Adam(lr) per run (Adam is element-wise, so one
+optimizer over the stacked parameters IS B independent optimizers); the early stop of :126-128 per run (a stopped run
+is frozen); the winner is the run with the smallest LAST loss and its parameters are loaded into the model.
+
+Everything before and after the O(N^3) part — constraints and transforms, the latent map of categorical inputs, mean
+functions, priors — is the model's own code, vectorised over the runs with ``torch.func.functional_call`` + ``torch.vmap``
+(no second implementation of the model).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from copy import deepcopy
+from typing import Dict, List, Tuple
+
+import torch
+from torch.func import functional_call
+
+from ..batched import batched_mll
+from ..gpcore.kernels import LazyKernelMatrix
+from ..gpcore.mlls import ExactMarginalLogLikelihood
+
+__all__ = ["BatchedObjective", "fit_model_torch_batched"]
+
+
+class BatchedObjective:
+    """``loss()`` -> (B,) tensor of ``-(log p(y) + log priors) / N`` for the B stacked parameter sets ``self.theta``."""
+
+    def __init__(self, model, B: int):
+        self.model, self.B = model, B
+        model.train()
+        self.mll = ExactMarginalLogLikelihood(model.likelihood, model)
+        self.names = [n for n, p in model.named_parameters() if p.requires_grad]
+        self.fixed = {n: p.detach() for n, p in model.named_parameters() if not p.requires_grad}
+        self.buffers = {n: b for n, b in model.named_buffers()}
+        self.theta: "OrderedDict[str, torch.nn.Parameter]" = OrderedDict(
+            (n, torch.nn.Parameter(p.detach().unsqueeze(0).repeat(B, *([1] * p.dim())).clone()))
+            for n, p in model.named_parameters() if p.requires_grad)
+        self._static = None
+
+    # -- parameter plumbing ---------------------------------------------------------------------------------
+    def set_row(self, b: int, state: Dict[str, torch.Tensor]) -> None:
+        with torch.no_grad():
+            for n in self.names:
+                self.theta[n][b].copy_(state[n].to(self.theta[n]))
+
+    def row(self, b: int) -> Dict[str, torch.Tensor]:
+        return {n: self.theta[n][b].detach().clone() for n in self.names}
+
+    def sample_restarts(self) -> None:
+        """Row 0 = the model's current parameters, row b >= 1 = the b-th ``reset_parameters()`` sample (the reference
+        resets after every run, optim/mll_torch.py:138-139: same samples, same order)."""
+        model = self.model
+        start = deepcopy(model.state_dict())
+        cur = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+        self.set_row(0, cur)
+        for b in range(1, self.B):
+            model.reset_parameters()
+            self.set_row(b, {n: p.detach() for n, p in model.named_parameters() if p.requires_grad})
+        model.load_state_dict(start)
+
+    # -- evaluation -------------------------------------------------------------------------------------------
+    def _pre(self, params: Dict[str, torch.Tensor]):
+        """One parameter set -> everything the kernels need, through the model's own forward / likelihood / priors."""
+        model = self.model
+        full = dict(self.fixed)
+        full.update(params)
+        full.update(self.buffers)
+        x = model.train_inputs[0]
+
+        def run(m):
+            out = torch.nn.Module.__call__(m, x)            # GP_Plus.forward: features, mean, lazy covariance
+            cov = out.lazy_covariance_matrix
+            if not isinstance(cov, LazyKernelMatrix):
+                raise RuntimeError("the batched fit needs the model's forward to return a lazy kernel covariance")
+            noisy = m.likelihood(out).lazy_covariance_matrix
+            prior = out.mean.new_zeros(())
+            for _, module, pr, closure, _ in m.named_priors():
+                prior = prior + pr.log_prob(closure(module)).sum().to(prior)
+            static = (noisy.grp, cov.spec.kind, cov.spec.d_split)
+            return (cov.U1, cov.spec.w, cov.spec.sf2.reshape(()), noisy.tau.reshape(-1), out.mean, prior), static
+
+        class _Shim(torch.nn.Module):  # functional_call needs a module whose forward does the work
+            def __init__(s, inner):
+                super().__init__()
+                s.inner = inner
+
+            def forward(s):
+                tensors, static = run(s.inner)
+                self._static = static
+                return tensors
+
+        shim = _Shim(model)
+        return functional_call(shim, {"inner." + k: v for k, v in full.items()}, ())
+
+    def loss(self) -> torch.Tensor:
+        N = self.model.train_targets.shape[0]
+        U, w, sf2, tau, mean, prior = torch.vmap(self._pre, in_dims=(0,), randomness="error")(dict(self.theta))
+        grp, kind, d_split = self._static
+        # leading feature columns produced by the (trainable) latent map of the categorical inputs: they differ from run to
+        # run and receive gradients; without them every run sees the same features.  (Inside vmap ``requires_grad`` of
+        # the features is not visible to the model's forward, so the count is taken from the model here.)
+        dz = int(self.model._features(self.model.train_inputs[0])[1]) if hasattr(self.model, "_features") else 0
+        learn_U = U.requires_grad and dz > 0
+        if not learn_U:
+            U = U[0]  # identical features for every run: share them
+        mll = batched_mll(U, w, sf2, tau, mean, self.model.train_targets, grp, kind, d_split, dz if learn_U else 0)
+        return -(mll + prior) / N
+
+
+def fit_model_torch_batched(model, lr_default: float = 0.01, num_iter: int = 100, num_restarts: int = 0,
+                            break_steps: int = 50, verbose: bool = False) -> Tuple[float, List[List[float]]]:
+    """Drop-in for ``fit_model_torch`` (same return value) that advances all restarts together."""
+    B = num_restarts + 1
+    obj = BatchedObjective(model, B)
+    obj.sample_restarts()
+    params = list(obj.theta.values())
+    opt = torch.optim.Adam(params, lr=lr_default)
+    dev = params[0].device
+    active = torch.ones(B, dtype=torch.bool, device=dev)
+    any_frozen = False
+    H = torch.full((num_iter, B), math.nan, dtype=torch.float64, device=dev)  # loss histories stay on the GPU
+    last = torch.full((B,), math.inf, dtype=torch.float64, device=dev)
+    done_at = num_iter
+    for j in range(num_iter):
+        opt.zero_grad(set_to_none=True)
+        loss = obj.loss()
+        torch.nansum(torch.where(active, loss, torch.zeros_like(loss))).backward()
+        before = [p.detach().clone() for p in params] if any_frozen else None
+        opt.step()
+        with torch.no_grad():
+            if any_frozen:  # a stopped run keeps the parameters it stopped with
+                frozen = ~active
+                for p, old in zip(params, before):
+                    p[frozen] = old[frozen]
+            lv = loss.detach()
+            lv = torch.where(torch.isfinite(lv), lv, torch.full_like(lv, math.inf))
+            H[j] = torch.where(active, lv, torch.full_like(lv, math.nan))
+            last = torch.where(active, lv, last)
+            if j > break_steps and j % break_steps == 0:
+                # reference :126-128, per run: stop when the mean of the previous window is not above the current loss
+                stop = active & ((H[j - break_steps:j].mean(0) - H[j]) <= 0)
+                active = active & ~stop
+                any_frozen = bool((~active).any())  # (the only host sync of the loop, every break_steps iterations)
+                if verbose:
+                    print(f"iter {j}: best loss {float(last.min()):.4f}, {int(active.sum())} of {B} runs active")
+                if not bool(active.any()):
+                    done_at = j + 1
+                    break
+    Hc = H[:done_at].cpu()
+    hist = [[v for v in Hc[:, b_].tolist() if not math.isnan(v)] for b_ in range(B)]
+    best = int(torch.argmin(last).item())
+    f_inc = float(last[best].item())
+    if math.isfinite(f_inc):
+        state = deepcopy(model.state_dict())
+        state.update(obj.row(best))
+        model.load_state_dict(state)
+    return f_inc, hist
