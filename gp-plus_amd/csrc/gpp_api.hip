@@ -198,16 +198,15 @@ hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv
 }
 
 // ---- look-ahead (right-looking) driver on two streams ----------------------------------------------------------
-// The recursive factorisation spends ~40 % of its time in latency-bound launches (128-block leaves, leaf trsm, small
-// updates) during which most of the 256 CUs idle.  For large N the outer level is therefore right-looking over block
-// rows of NB with ONE step of look-ahead: the diagonal block + block-row panel of step k+1 are factored on a second,
-// high-priority stream while the main stream still runs the bulk of step k's trailing update.
-//   panel stream : wait S(k-1); U_kk = potrf(A_kk) (recursive); U_k,k+1: = U_kk^-T A_k,k+1: ; record P(k)
-//   main  stream : wait P(k);  strip (next block row) -= ...; record S(k);  rest of the trailing matrix -= ...
-// Stream priorities alone do not help: while a trailing update saturates every CU the hardware does not place the
-// (single work-group, 72 KiB LDS) leaf of the next panel until the update drains (measured: the leaf "ran" for 5.8 ms).
-// So the two internal streams get DISJOINT CU sets through CU masks: PANEL_CUS compute units run the latency-bound
-// diagonal-block factorisations, the remaining ones the wide trsm and trailing updates.
+// A factorisation made of leaf steps spends most of its time in latency-bound launches (128-block leaves, the leaf trsm,
+// rank-128 updates) during which most of the 256 CUs idle.  For N >= 4096 the outer level is therefore right-looking over
+// block rows of 1024 / 512 with ONE step of look-ahead on two internal streams:
+//   latency stream   : wait S(k-1); U_kk = potrf(A_kk) in leaf steps; invert the block completely; record D(k)
+//   throughput stream: wait D(k); U_k,k+1: = inv(U_kk)^T A_k,k+1: (one GEMM); strip (next block row) -= ...; record S(k);
+//                      rest of the trailing matrix -= ...
+// Stream priorities alone do not help: the leaf needs a CU to itself (its register allocation does not fit beside a GEMM
+// work-group), so while an update saturates every CU it is not placed until the update drains (measured: 5.8 ms).  The
+// two streams therefore get DISJOINT CU sets through CU masks (see the comment at the mask below for what that costs).
 constexpr int PANEL_CUS_DEFAULT = 32;
 hipError_t ensure_streams(gpp_handle_s* h) {
   if (h->cu_split < 0) {
