@@ -1,6 +1,6 @@
 // gpp_gemm.hip — fp64 MFMA GEMM for gfx950 (MI355X): C = beta*C + alpha*op(A)*op(B) with triangular operand
 // masks, per-tile K ranges and lower-only output.  It carries every O(N^3) flop of the exact-GP path:
-//   - TRSM / SYRK / GEMM updates of the recursive Cholesky  (replaces torch.linalg.cholesky_ex reached from
+//   - TRSM / SYRK / GEMM updates of the blocked Cholesky  (replaces torch.linalg.cholesky_ex reached from
 //     gpytorch psd_safe_cholesky, reference call site optim/mll_torch.py:116)
 //   - TRMM pair products of the bottom-up triangular inverse and the LAUUM product Linv^T Linv
 //     (replace ATen cholesky_backward, reference call site optim/mll_torch.py:117)
@@ -15,8 +15,9 @@
 // WT x WT = (WT/4) x (WT/16) such slabs (WT=64: 64 accumulator doubles per lane).  K is consumed in chunks of 16;
 // both operand chunks are staged in LDS in [k][row] order (padded strides, see ldt_*), double-buffered: the global
 // loads of chunk c+1 are issued before the MFMAs of chunk c and written to the other buffer afterwards, one barrier
-// per chunk.  WT = 32 / 16 variants (64^2 / 32^2 tiles) serve the small sub-problems of the recursions, where the
-// grid of 128^2 tiles would leave most of the 256 CUs idle.
+// per chunk.  WT = 32 / 16 variants (64^2 / 32^2 tiles) and a 128 x 32 tile serve the small sub-problems, where the
+// grid of 128^2 tiles would leave most of the 256 CUs idle; they stage K in chunks of 64 with one LDS buffer (template
+// parameters BK, NBUF below).  Work-groups are independent along two batch dimensions (grid.y, grid.z).
 #include "gpp_internal.h"
 
 typedef double v2d __attribute__((ext_vector_type(2)));

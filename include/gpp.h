@@ -80,10 +80,11 @@ int gpp_cross_kernel(gpp_handle_t h, const double* Ua, int64_t Ma, const double*
 
 /*
  * K5 (gpytorch psd_safe_cholesky -> torch.linalg.cholesky_ex reached from optim/mll_torch.py:116):
- * in-place Cholesky of A (N x N, UPPER triangle): A = U^T U.  Recursive blocked factorisation; every product runs
- * on the fp64 MFMA GEMM kernel, 128 x 128 diagonal leaves are factored AND inverted in LDS.  On return the upper
- * triangle of A holds U = L^T and the 128-aligned diagonal blocks of Linv hold inv(L_bb) (lower) mirrored with
- * inv(L_bb)^T (upper), as gpp_trtri needs them.
+ * in-place Cholesky of A (N x N, UPPER triangle): A = U^T U.  Right-looking in steps of one 128 x 128 leaf (factored
+ * AND inverted in LDS by one work-group) below 4096 rows, block rows of 1024 / 512 with look-ahead on two CU-masked
+ * streams above; every product runs on the fp64 MFMA GEMM kernel.  On return the upper triangle of A holds U = L^T and
+ * the 128-aligned diagonal blocks of Linv hold inv(L_bb) (lower) mirrored with inv(L_bb)^T (upper), as gpp_trtri needs
+ * them.
  */
 int gpp_potrf(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, int64_t ldi, int32_t* info_dev);
 /* Same, with an N x N scratch T (may be the Kinv buffer): for large N the look-ahead driver then also completes the
