@@ -144,8 +144,14 @@ def fit_model_torch_batched(model, lr_default: float = 0.01, num_iter: int = 100
             H[j] = torch.where(active, lv, torch.full_like(lv, math.nan))
             last = torch.where(active, lv, last)
             if j > break_steps and j % break_steps == 0:
-                # reference :126-128, per run: stop when the mean of the previous window is not above the current loss
-                stop = active & ((H[j - break_steps:j].mean(0) - H[j]) <= 0)
+                # reference :126-128, per run: stop when the mean of the previous window is not above the current loss.
+                # The reference forms that mean from ``torch.Tensor(loss_hist)`` on the host, i.e. in float32, which is what
+                # ends a run on a plateau (differences below ~1e-7 relative round to zero): the same expression on the
+                # same device here, so the runs stop where the sequential driver stops them.
+                Hc = H[j - break_steps:j + 1].cpu()
+                stop_l = [bool((torch.mean(torch.Tensor(Hc[:break_steps, b_].tolist())) - Hc[break_steps, b_].item()) <= 0)
+                          for b_ in range(B)]
+                stop = active & torch.tensor(stop_l, device=dev)
                 active = active & ~stop
                 any_frozen = bool((~active).any())  # (the only host sync of the loop, every break_steps iterations)
                 if verbose:

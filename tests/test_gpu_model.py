@@ -541,3 +541,26 @@ def test_fit_model_torch_batched_follows_the_sequential_driver(gpu_ctx):
     for (na, pa), (_, pb) in zip(ma.state_dict().items(), mb.state_dict().items()):
         if torch.is_tensor(pa) and pa.dtype.is_floating_point:
             np.testing.assert_allclose(pb.cpu().numpy(), pa.cpu().numpy(), rtol=1e-6, atol=1e-8, err_msg=na)
+
+
+def test_fit_model_torch_batched_stops_runs_like_the_sequential_driver(gpu_ctx):
+    """The reference's early stop (optim/mll_torch.py:126-128, a float32 window mean on the host) ends each run of the
+    batched driver at the same iteration as in the sequential driver."""
+    from gpplus_amd.models import GP_Plus
+    from gpplus_amd.optim import fit_model_torch, fit_model_torch_batched
+    from gpplus_amd.utils import set_seed
+
+    rng = np.random.default_rng(0)
+    X = rng.uniform(0, 1, (150, 3))
+    y = np.sin(3 * X[:, 0]) + X[:, 1] + 0.05 * rng.standard_normal(150)
+    out = []
+    for fit in (fit_model_torch_batched, fit_model_torch):
+        set_seed(1)
+        m = GP_Plus(torch.tensor(X), torch.tensor(y), dtype=torch.float64, device="cuda")
+        set_seed(4)
+        kw = {} if fit is fit_model_torch_batched else {"verbose": False}
+        out.append(fit(m, num_restarts=5, num_iter=260, break_steps=50, lr_default=0.3, **kw))
+    (fb, hb), (fs, hs) = out
+    assert [len(h) for h in hb] == [len(h) for h in hs]
+    assert any(len(h) < 260 for h in hs)            # the scenario does exercise the early stop
+    assert abs(fb - fs) <= 1e-8 * abs(fs)
