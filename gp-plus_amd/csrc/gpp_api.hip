@@ -88,7 +88,7 @@ hipError_t trsm_rec(const Ctx& c, int64_t c0, int64_t m, int64_t o, int64_t n) {
 // Right-looking factorisation of a block of up to BLK_MAX rows (every N below the look-ahead threshold, and the look-ahead's diagonal blocks) in steps of one leaf: leaf, ONE in-place panel solve over
 // all remaining columns, ONE rank-128 update of the remaining upper triangle (which stays in L2 at this size).  3 launches
 // per 128 rows where the recursion needs 4, and none of them narrower than the block: 0.70 -> 0.57 ms for 1024 rows, 3.4 -> 3.0 ms for 3968.
-constexpr int64_t BLK_MAX = 4096;
+constexpr int64_t BLK_MAX = 6144;
 hipError_t potrf_blk(const Ctx& c, int64_t o, int64_t n) {
   for (int64_t j0 = 0; j0 < n; j0 += NBLK) {
     const int64_t nb = std::min<int64_t>(NBLK, n - j0), oo = o + j0, rem = n - j0 - nb;
@@ -199,7 +199,7 @@ hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv
 
 // ---- look-ahead (right-looking) driver on two streams ----------------------------------------------------------
 // A factorisation made of leaf steps spends most of its time in latency-bound launches (128-block leaves, the leaf trsm,
-// rank-128 updates) during which most of the 256 CUs idle.  For N >= 4096 the outer level is therefore right-looking over
+// rank-128 updates) during which most of the 256 CUs idle.  For N >= 6144 the outer level is therefore right-looking over
 // block rows of 1024 / 512 with ONE step of look-ahead on two internal streams:
 //   latency stream   : wait S(k-1); U_kk = potrf(A_kk) in leaf steps; invert the block completely; record D(k)
 //   throughput stream: wait D(k); U_k,k+1: = inv(U_kk)^T A_k,k+1: (one GEMM); strip (next block row) -= ...; record S(k);
@@ -480,7 +480,10 @@ int gpp_potrf_ws(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv,
   Ctx c{h->stream, A, ld, Linv, ldi, info_dev};
   h->inv_N = N;
   h->inv_nblocks = 0;
-  if (N >= 4 * LOOKAHEAD_NB) GPP_TRY(potrf_lookahead(h, c, N, LOOKAHEAD_NB, T, ldt));
+  static const int64_t la_min = getenv("GPP_LOOKAHEAD_MIN") ? atol(getenv("GPP_LOOKAHEAD_MIN")) : 6 * LOOKAHEAD_NB;  // knob
+  // (measured: the leaf-step factorisation on one stream wins up to ~6000 rows — 2.99 vs 3.46 ms at 4096, 4.25 vs 4.53 at
+  //  5120, a tie at 6144; the look-ahead wins from there: 8.6 vs 10.1 ms at 8192)
+  if (N >= la_min) GPP_TRY(potrf_lookahead(h, c, N, LOOKAHEAD_NB, T, ldt));
   else GPP_TRY(potrf_rec(c, 0, N));
   return 0;
 }

@@ -81,7 +81,7 @@ int gpp_cross_kernel(gpp_handle_t h, const double* Ua, int64_t Ma, const double*
 /*
  * K5 (gpytorch psd_safe_cholesky -> torch.linalg.cholesky_ex reached from optim/mll_torch.py:116):
  * in-place Cholesky of A (N x N, UPPER triangle): A = U^T U.  Right-looking in steps of one 128 x 128 leaf (factored
- * AND inverted in LDS by one work-group) below 4096 rows, block rows of 1024 / 512 with look-ahead on two CU-masked
+ * AND inverted in LDS by one work-group) below 6144 rows, block rows of 1024 / 512 with look-ahead on two CU-masked
  * streams above; every product runs on the fp64 MFMA GEMM kernel.  On return the upper triangle of A holds U = L^T and
  * the 128-aligned diagonal blocks of Linv hold inv(L_bb) (lower) mirrored with inv(L_bb)^T (upper), as gpp_trtri needs
  * them.
@@ -173,7 +173,7 @@ int gpp_gemm_batched(gpp_handle_t h, int transA, int transB, int64_t M, int64_t 
  * fit, optim/mll_torch.py:99-141, evaluated together instead of one after the other).  Element b uses the matrices at
  * base + b*s? (strides in elements, even), parameters w + b*D, sf2 + b, tau + b*S, vectors r/z/alpha + b*sv (sv >= N,
  * even), out3 + 3*b, info_dev + b, and returns g_w + b*D, g_sf2 + b, g_tau + b*S, g_U + b*N*dU.  sU = 0 shares one
- * feature matrix.  N is at most 4096 for gpp_potrf_batched (the leaf-step
+ * feature matrix.  N is at most 6144 for gpp_potrf_batched (the leaf-step
  * factorisation); gpp_trtri_batched completes the inverse from the 128-blocks, so it follows gpp_potrf_batched
  * directly.  The workspace must hold batch * gpp_workspace_bytes(GPP_OP_MLL_EVAL, ...).
  */
