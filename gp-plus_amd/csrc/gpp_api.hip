@@ -159,7 +159,7 @@ hipError_t potrf_rec(const Ctx& c, int64_t o, int64_t n) {
 template <typename Skip>
 hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt,
                        int64_t base, int64_t n, int64_t s, Skip skip, int mbatch = 1, int64_t msU = 0, int64_t msLi = 0,
-                       int64_t msT = 0) {
+                       int64_t msT = 0, int g1_tile = 0) {
   const int64_t npairs_full = n / (2 * s);
   const int64_t rem = n - npairs_full * 2 * s;  // leftover rows after the full pairs
   auto launch = [&](int64_t o, int64_t m2, int batch) -> hipError_t {
@@ -169,7 +169,7 @@ hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv
     g1.b_mask = 2; g1.klo_mode = 2; g1.col_major = 1;  // K range depends on the column tile: keep columns together
     g1.sA = pstride_U; g1.sB = pstride_I; g1.sC = pstride_T;
     g1.batch2 = mbatch; g1.zA = msU; g1.zB = msLi; g1.zC = msT;  // independent matrices (batched evaluation)
-    hipError_t e = gpp_launch_gemm(st, 2, g1, batch);
+    hipError_t e = gpp_launch_gemm(st, 2, g1, batch, g1_tile, g1_tile);
     if (e != hipSuccess) return e;
     // Linv21 = -W22^T * T21  (TN; W22 = mirrored upper part of the (o+s) block: keep k <= m), plus its mirror
     GemmArgs g2 = mk(Linv + (o + s) * ldi + (o + s), ldi, T + (o + s) * ldt + o, ldt, Linv + (o + s) * ldi + o, ldi, m2, s,
@@ -208,6 +208,8 @@ hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv
 // work-group), so while an update saturates every CU it is not placed until the update drains (measured: 5.8 ms).  The
 // two streams therefore get DISJOINT CU sets through CU masks (see the comment at the mask below for what that costs).
 constexpr int PANEL_CUS_DEFAULT = 32;
+constexpr int64_t BORDER_MAX_N = 11264;  // largest N whose inverse is built by bordering inside the look-ahead
+constexpr int64_t BORDER_MIN_N = 4096;   // with bordering the look-ahead already wins from here (4.5 vs 4.8 ms per evaluation)
 hipError_t ensure_streams(gpp_handle_s* h) {
   if (h->cu_split < 0) {
     hipDeviceProp_t prop;
@@ -230,16 +232,19 @@ hipError_t ensure_streams(gpp_handle_s* h) {
       // does not fit beside a GEMM work-group) and starves; capped at 256 registers it is placed, but every panel launch
       // then queues behind 300-us GEMM work-groups and the update stream idles 0.55 ms per step: 62 ms vs 59.
       for (int c = 0; c < ncu; ++c) (c < PANEL_CUS ? mp : mu)[c >> 5] |= 1u << (c & 31);
-      hipStream_t sp = nullptr, su = nullptr;
+      hipStream_t sp = nullptr, su = nullptr, sf = nullptr;
       if (hipExtStreamCreateWithCUMask(&sp, words, mp) == hipSuccess &&
-          hipExtStreamCreateWithCUMask(&su, words, mu) == hipSuccess) {
+          hipExtStreamCreateWithCUMask(&su, words, mu) == hipSuccess &&
+          hipExtStreamCreateWithCUMask(&sf, words, mu) == hipSuccess) {
         h->panel_stream = sp;
         h->upd_stream = su;
+        h->fill_stream = sf;
         h->cu_split = 1;
       } else {
         (void)hipGetLastError();
         if (sp) (void)hipStreamDestroy(sp);
         if (su) (void)hipStreamDestroy(su);
+        if (sf) (void)hipStreamDestroy(sf);
       }
     }
     if (!h->cu_split) {  // fallback: priority streams sharing all CUs
@@ -249,6 +254,8 @@ hipError_t ensure_streams(gpp_handle_s* h) {
       e = hipStreamCreateWithPriority(&h->panel_stream, hipStreamNonBlocking, hi);
       if (e != hipSuccess) return e;
       e = hipStreamCreateWithFlags(&h->upd_stream, hipStreamNonBlocking);
+      if (e != hipSuccess) return e;
+      e = hipStreamCreateWithFlags(&h->fill_stream, hipStreamNonBlocking);
       if (e != hipSuccess) return e;
     }
   }
@@ -285,6 +292,18 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   const char* env_nb = getenv("GPP_LOOKAHEAD_NB");  // experiment knob: "big,small,threshold"
   long nb_big = NB, nb_small = NB / 2, nb_thresh = 6 * NB;  // measured best at N = 20000 (70.6 ms vs 71.7 for 1024 flat)
   if (env_nb) sscanf(env_nb, "%ld,%ld,%ld", &nb_big, &nb_small, &nb_thresh);
+  // bordering pays while the factorisation is bound by its chain of diagonal blocks (measured: 9.6 -> 7.8 ms per
+  // evaluation at N = 6144, 16.3 -> 14.0 at 8192, 26.5 -> 24.4 at 10000, a tie at 12288, 147 -> 156 at 20000 where the
+  // throughput CUs have no idle time to give and the long-K bordering products are slower than batched pair merges)
+  static const int64_t border_max = getenv("GPP_BORDER_MAX") ? atol(getenv("GPP_BORDER_MAX")) : BORDER_MAX_N;  // knob
+  const bool border = T != nullptr && N <= border_max;
+  static const bool split_chain = !(getenv("GPP_SPLIT_CHAIN") && atoi(getenv("GPP_SPLIT_CHAIN")) == 0);  // experiment knob
+  hipStream_t cf = h->fill_stream;
+  static const int64_t border_t128 = getenv("GPP_BORDER_T128") ? atol(getenv("GPP_BORDER_T128")) : 640;  // experiment knob
+  hipEvent_t R_prev = nullptr;  // row solves of the steps before the current one are complete
+  // with bordering the block height matters little; one height per N measured best (512 up to ~7000 rows: 7.5 vs 8.3 ms per
+  // evaluation at 6144; 1024 above: 23.3 vs 24.2 ms at 10000)
+  if (border && !env_nb) nb_thresh = (N <= 7168) ? N + 1 : 0;
   for (int64_t o = 0, nb = 0; o < N; o += nb) {
     // tall block rows while the trailing update is long enough to hide their diagonal factorisation, shorter after
     const int64_t want = (N - o >= nb_thresh) ? nb_big : nb_small;
@@ -305,46 +324,82 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
     hipEvent_t D = next_event(h);
     HIP_TRY(hipEventRecord(D, cp.s));
     HIP_TRY(hipStreamWaitEvent(cu.s, D, 0));
-    if (rem == 0) break;
-    if (T) {
-      // U12 = (inv(L_oo)^T)^T A12 = W_oo^T A12 : one TN GEMM (W_oo = mirror, keep i <= k) into the scratch, then copied
-      // over A12 (a GEMM with several row tiles cannot run in place)
-      GemmArgs gt = mk(cm.Li + o * cm.ldi + o, cm.ldi, cm.A + o * cm.ld + (o + nb), cm.ld, T + o * ldt + (o + nb), ldt, nb,
-                       rem, nb, 1.0, 0.0);
-      gt.a_mask = 1; gt.khi_mode = 1;
-      gt.row_reverse = 1;  // K grows with the row tile: longest tiles first, so the launch does not end on them
-      HIP_TRY(gpp_launch_gemm(cu.s, 2, gt, 1));
-      HIP_TRY(hipMemcpy2DAsync(cm.A + o * cm.ld + (o + nb), cm.ld * sizeof(double), T + o * ldt + (o + nb),
-                               ldt * sizeof(double), rem * sizeof(double), nb, hipMemcpyDeviceToDevice, cu.s));
-    } else {
-      HIP_TRY(trsm_rec(cu, o + nb, rem, o, nb));
+    auto border_step = [&]() -> hipError_t {
+      // bordering step of the inverse: Linv[o.., 0..o) = -W_oo^T (U[0..o, o..)^T Linv[0..o, 0..o)) — the ragged pair merge
+      // of [0, o) with [o, o+nb).  Needs block rows < o of U (row solves of the earlier steps: event R) and this block's
+      // inverse (D).  Its work grows as the trailing update shrinks, so the two together keep the throughput CUs busy.
+      HIP_TRY(hipStreamWaitEvent(cf, D, 0));
+      HIP_TRY(hipStreamWaitEvent(cf, R_prev, 0));
+      // few, long tiles (K up to o): 64-wide tiles balance better until there are several waves of 128-wide ones
+      const int64_t t128 = ((nb + 127) / 128) * ((o + 127) / 128);
+      return trtri_level(cf, cm.A, cm.ld, cm.Li, cm.ldi, T, ldt, 0, o + nb, o, [](int64_t) { return false; }, 1, 0, 0, 0,
+                         t128 < border_t128 ? 64 : 0);
+    };
+    if (rem == 0) {
+      if (border && o > 0) HIP_TRY(border_step());
+      break;
     }
     const int64_t want2 = (rem >= nb_thresh) ? nb_big : nb_small;
     const int64_t nb2 = std::min(want2, rem), rest = rem - nb2;
+    // U[o.., c0..c0+nc) = W_oo^T A[o.., c0..c0+nc) : one TN GEMM (W_oo = mirror of the block's inverse, keep i <= k) into
+    // the scratch, then copied over A (a GEMM with several row tiles cannot run in place)
+    auto row_solve = [&](int64_t c0, int64_t nc) -> hipError_t {
+      if (!T) return trsm_rec(cu, c0, nc, o, nb);
+      GemmArgs gt = mk(cm.Li + o * cm.ldi + o, cm.ldi, cm.A + o * cm.ld + c0, cm.ld, T + o * ldt + c0, ldt, nb, nc, nb, 1.0,
+                       0.0);
+      gt.a_mask = 1; gt.khi_mode = 1;
+      gt.row_reverse = 1;  // K grows with the row tile: longest tiles first, so the launch does not end on them
+      HIP_TRY(gpp_launch_gemm(cu.s, 2, gt, 1));
+      return hipMemcpy2DAsync(cm.A + o * cm.ld + c0, cm.ld * sizeof(double), T + o * ldt + c0, ldt * sizeof(double),
+                              nc * sizeof(double), nb, hipMemcpyDeviceToDevice, cu.s);
+    };
     const double* Urow = cm.A + o * cm.ld;  // block row o: U[o.., :]
-    // strip = next block row of the trailing matrix (its diagonal block, upper, then the part to its right)
+    // the chain first: the columns of the NEXT diagonal block, its update, and the panel stream may go on (event S)
+    HIP_TRY(row_solve(o + nb, split_chain ? nb2 : rem));
     GemmArgs g = mk(Urow + (o + nb), cm.ld, Urow + (o + nb), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb), cm.ld, nb2, nb2, nb,
                     -1.0, 1.0);
     g.c_lower = 2;
     HIP_TRY(gpp_launch_gemm(cu.s, 2, g, 1));
-    if (rest > 0) {
+    hipEvent_t S = next_event(h);
+    if (split_chain) {
+      HIP_TRY(hipEventRecord(S, cu.s));
+      if (rest > 0) HIP_TRY(row_solve(o + nb + nb2, rest));
+    }
+    hipEvent_t R = nullptr;
+    if (border) {
+      R = next_event(h);
+      HIP_TRY(hipEventRecord(R, cu.s));
+    }
+    if (rest > 0) {  // the part of the next block row to the right of its diagonal block
       GemmArgs g2 = mk(Urow + (o + nb), cm.ld, Urow + (o + nb + nb2), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb + nb2), cm.ld,
                        nb2, rest, nb, -1.0, 1.0);
       HIP_TRY(gpp_launch_gemm(cu.s, 2, g2, 1));
     }
-    hipEvent_t S = next_event(h);
-    HIP_TRY(hipEventRecord(S, cu.s));
+    if (!split_chain) HIP_TRY(hipEventRecord(S, cu.s));
     HIP_TRY(hipStreamWaitEvent(cp.s, S, 0));  // the next diagonal block may be factored
+    if (border && o > 0) {
+      HIP_TRY(hipStreamWaitEvent(cf, S, 0));  // behind the strip: the chain's own launches get the CUs first
+      HIP_TRY(border_step());
+    }
     if (rest > 0) {
       GemmArgs g3 = mk(Urow + (o + nb + nb2), cm.ld, Urow + (o + nb + nb2), cm.ld,
                        cm.A + (o + nb + nb2) * cm.ld + (o + nb + nb2), cm.ld, rest, rest, nb, -1.0, 1.0);
       g3.c_lower = 2;
       HIP_TRY(gpp_launch_gemm(cu.s, 2, g3, 1));
     }
+    R_prev = R;
   }
   hipEvent_t E = next_event(h);
   HIP_TRY(hipEventRecord(E, cu.s));
   HIP_TRY(hipStreamWaitEvent(cm.s, E, 0));  // (the update stream already waited for the last D)
+  if (border) {
+    hipEvent_t F = next_event(h);
+    HIP_TRY(hipEventRecord(F, cf));
+    HIP_TRY(hipStreamWaitEvent(cm.s, F, 0));
+    h->inv_nblocks = 1;  // the inverse is complete: gpp_trtri has nothing left to merge
+    h->inv_o[0] = 0;
+    h->inv_n[0] = N;
+  }
   return hipSuccess;
 }
 
@@ -376,6 +431,7 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->ws_bytes = 0;
   h->panel_stream = nullptr;
   h->upd_stream = nullptr;
+  h->fill_stream = nullptr;
   h->cu_split = -1;
   h->n_events = 0;
   h->ev_next = 0;
@@ -389,6 +445,7 @@ int gpp_destroy(gpp_handle_t h) {
   if (!h) return -1;
   if (h->panel_stream) (void)hipStreamDestroy(h->panel_stream);
   if (h->upd_stream) (void)hipStreamDestroy(h->upd_stream);
+  if (h->fill_stream) (void)hipStreamDestroy(h->fill_stream);
   for (int i = 0; i < h->n_events; ++i) (void)hipEventDestroy(h->events[i]);
   delete h;
   return 0;
@@ -483,7 +540,8 @@ int gpp_potrf_ws(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv,
   static const int64_t la_min = getenv("GPP_LOOKAHEAD_MIN") ? atol(getenv("GPP_LOOKAHEAD_MIN")) : 6 * LOOKAHEAD_NB;  // knob
   // (measured: the leaf-step factorisation on one stream wins up to ~6000 rows — 2.99 vs 3.46 ms at 4096, 4.25 vs 4.53 at
   //  5120, a tie at 6144; the look-ahead wins from there: 8.6 vs 10.1 ms at 8192)
-  if (N >= la_min) GPP_TRY(potrf_lookahead(h, c, N, LOOKAHEAD_NB, T, ldt));
+  static const int64_t la_min_b = getenv("GPP_BORDER_MIN") ? atol(getenv("GPP_BORDER_MIN")) : BORDER_MIN_N;  // knob
+  if (N >= (T ? std::min(la_min, la_min_b) : la_min)) GPP_TRY(potrf_lookahead(h, c, N, LOOKAHEAD_NB, T, ldt));
   else GPP_TRY(potrf_rec(c, 0, N));
   return 0;
 }

@@ -491,8 +491,10 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int
   };
   if (tile_m == 0) {
     // enough 128^2 tiles to give every CU a work-group -> big tile; otherwise shrink until the chip is covered
-    if (ntiles(128) >= 256) tile_m = 128;
-    else if (ntiles(64) >= 192) tile_m = 64;
+    static const int64_t t128 = getenv("GPP_TILE_T128") ? atol(getenv("GPP_TILE_T128")) : 256;  // experiment knobs
+    static const int64_t t64 = getenv("GPP_TILE_T64") ? atol(getenv("GPP_TILE_T64")) : 192;
+    if (ntiles(128) >= t128) tile_m = 128;
+    else if (ntiles(64) >= t64) tile_m = 64;
     else tile_m = 32;
     tile_n = tile_m;
   }

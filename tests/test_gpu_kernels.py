@@ -116,10 +116,14 @@ def test_kernel_build_and_cross(gpu_ctx, n, d):
 
 
 @pytest.mark.parametrize("n,use_ws", [(1, False), (5, True), (128, False), (129, True), (300, False), (777, True),
-                                      (2048, True), (4097, False), (4097, True), (6700, True)])
+                                      (2048, True), (4097, False), (4097, True), (6700, True), (6700, False),
+                                      (11500, True)])
 def test_potrf_trtri_lauum(gpu_ctx, n, use_ws):
-    """use_ws: pass the scratch to the factorisation (look-ahead path for n >= 4096 then inverts its diagonal block rows
-    itself, solves panels with one GEMM and lets trtri skip the merged levels)."""
+    """use_ws: pass the scratch to the factorisation.  The drivers behind the same entry points: leaf steps on one stream
+    (n < 4096, or < 6144 without scratch); look-ahead on internal streams above, which with the scratch inverts its diagonal
+    block rows, solves panels with one GEMM and — for 4096 <= n <= 11264 — also builds the whole inverse by bordering, so
+    trtri finds nothing left (6700, True); above that trtri skips only the merged levels (11500, True); without the scratch
+    the panels are solved recursively and trtri does all the merging (6700, False)."""
     U, w, K = _spd(n, seed=n)
     A, Li, T, Ki = _sq(n), _sq(n), _sq(n), _sq(n)
     A.copy_(_dev(np.triu(K) + np.tril(np.full((n, n), np.nan), -1)))  # the strict lower triangle must never be read
