@@ -6,6 +6,8 @@ Replaces, for the path ``optim/mll_torch.py:114-117``:
              (kernel build K1-K4, Cholesky K5, solve + logdet + quadratic form K6)
   backward = ATen ``cholesky_backward`` + the backward of every N^2 kernel op (K7): Ky^-1 by trtri + lauum, then ONE
              tiled reduction of W = (alpha alpha^T - Ky^-1)/2 against dKy/dtheta.
+Both halves are ENQUEUED together in the Function's forward when a gradient is wanted (see ExactMLLFunction), so that
+the single host sync of an evaluation — reading the factorisation status — comes after all of its device work.
 Jitter policy restates gpytorch.utils.cholesky.psd_safe_cholesky [3P]: 1e-8 * 10^i, i = 0..2 (fp64), warn, then
 ``NotPSDError``; NaN inputs raise ``NanError``.
 """
@@ -51,6 +53,8 @@ class EvalWorkspace:
         self.r = torch.empty(N, dtype=torch.float64, device=dev)
         self.out3 = torch.empty(3, dtype=torch.float64, device=dev)
         self.info = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.info_host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.info_event = torch.cuda.Event()
         self.epoch = 0
 
 
@@ -115,15 +119,24 @@ def _as_f64(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float64).contiguous()
 
 
-def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_split) -> float:
-    """Build Ky (lower) and factor it, with gpytorch's jitter-retry policy.  Returns the jitter that was needed."""
+def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_split, after=None) -> float:
+    """Build Ky (upper) and factor it, with gpytorch's jitter-retry policy.  Returns the jitter that was needed.
+    ``after()`` enqueues whatever follows the factorisation BEFORE ``info`` is read back, so the GPU keeps working while
+    the host waits (and afterwards runs the Python between forward and backward); a failed attempt just repeats it."""
     jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
     for jit in jitters:
         with _stage("kernel_build"):
             ctx.kernel_build(U, w, sf2, tau, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_UPPER)
         with _stage("potrf"):
             ctx.potrf(ws.A, ws.Li, ws.info, ws.Ki)
-        info = int(ws.info.item())  # the one host sync of an evaluation (the reference syncs on loss.item() too)
+        # the one host wait of an evaluation (the reference syncs on loss.item() too) covers the factorisation only: the
+        # status goes to pinned host memory behind an event, the rest of the evaluation is enqueued, THEN the host waits
+        ws.info_host.copy_(ws.info, non_blocking=True)
+        ws.info_event.record()
+        if after is not None:
+            after()
+        ws.info_event.synchronize()
+        info = int(ws.info_host[0])
         if info == 0:
             if jit > 0:
                 warnings.warn(f"A not p.d., added jitter of {jit:.1e} to the diagonal", RuntimeWarning)
@@ -137,7 +150,12 @@ def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_spl
 
 
 class ExactMLLFunction(torch.autograd.Function):
-    """mll = log N(y | mean, sf2*k(U,U;w) + diag(tau[grp]))  with gradients for U[:, :dU], w, sf2, tau, mean, y."""
+    """mll = log N(y | mean, sf2*k(U,U;w) + diag(tau[grp]))  with gradients for U[:, :dU], w, sf2, tau, mean, y.
+
+    The whole evaluation — value AND the parameter gradients (K7: Ky^-1 by trtri + lauum, one fused reduction) — is
+    enqueued in ``forward`` ahead of the single host sync on the factorisation status whenever an input needs a gradient:
+    the device then works through the Python that lies between the reference's ``-mll(...)`` and ``loss.backward()``
+    (optim/mll_torch.py:116-117), and ``backward`` only scales the stored gradients by the incoming one."""
 
     @staticmethod
     def forward(ctx, U, w, sf2, tau, mean, y, grp, kind, d_split, dU, slot):
@@ -151,55 +169,56 @@ class ExactMLLFunction(torch.autograd.Function):
             grp = grp.to(torch.int32)
         ws = get_workspace(gctx, N, slot)
         ws.epoch += 1
-        jit = _factor(gctx, ws, Ud, wd, sd, td, grp, kind, d_split)
-        with _stage("trtri"):
-            gctx.trtri(ws.A, ws.Li, ws.Ki)
         torch.sub(_as_f64(y.detach(), dev), _as_f64(mean.detach(), dev), out=ws.r)
-        with _stage("mll_reduce"):
-            gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
-        ctx.saved = (gctx, ws, ws.epoch, Ud, wd, sd, td, grp, S, kind, d_split, dU, jit, ws.r.clone())
+        need = ctx.needs_input_grad
+        need_grad = any(need[:6])
+        need_U = need[0] and dU > 0
+        g_w = g_s = g_t = g_Ud = None
+        if need_grad:
+            g_w = torch.empty(D, dtype=torch.float64, device=dev)
+            g_s = torch.empty(1, dtype=torch.float64, device=dev)
+            g_t = torch.empty(S, dtype=torch.float64, device=dev)
+            g_Ud = torch.empty(N, dU, dtype=torch.float64, device=dev) if need_U else None
+
+        def rest():
+            with _stage("trtri"):
+                gctx.trtri(ws.A, ws.Li, ws.Ki)
+            with _stage("mll_reduce"):
+                gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
+            if not need_grad:
+                return
+            with _stage("alpha"):
+                gctx.alpha(ws.Li, ws.z, ws.alpha)
+            with _stage("lauum"):
+                gctx.lauum(ws.Li, ws.Ki)
+            with _stage("grad_reduce"):
+                gctx.grad_reduce(Ud, wd, sd, grp, S, ws.alpha, ws.Ki, dU if need_U else 0, g_w, g_s, g_t, g_Ud, kind=kind,
+                                 d_split=d_split)
+
+        _factor(gctx, ws, Ud, wd, sd, td, grp, kind, d_split, after=rest)
+        ctx.saved = (g_w, g_s, g_t, g_Ud, ws.alpha.clone() if need_grad else None, (N, D, dU))
         ctx.in_dtypes = (U.dtype, w.dtype, sf2.dtype, tau.dtype, mean.dtype, y.dtype)
         ctx.shapes = (sf2.shape, tau.shape)
         return ws.out3[2].clone()
 
     @staticmethod
     def backward(ctx, grad_out):
-        gctx, ws, epoch, Ud, wd, sd, td, grp, S, kind, d_split, dU, jit, r_saved = ctx.saved
-        N, D = Ud.shape
-        dev = Ud.device
-        if ws.epoch != epoch:
-            # another forward reused the buffers: rebuild this evaluation's factors (correct, costs one extra potrf)
-            ws.epoch += 1
-            gctx.kernel_build(Ud, wd, sd, td, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_UPPER)
-            gctx.potrf(ws.A, ws.Li, ws.info, ws.Ki)
-            gctx.trtri(ws.A, ws.Li, ws.Ki)
-            ws.r.copy_(r_saved)
-            gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
-        with _stage("alpha"):
-            gctx.alpha(ws.Li, ws.z, ws.alpha)
-        with _stage("lauum"):
-            gctx.lauum(ws.Li, ws.Ki)
-        g_w = torch.empty(D, dtype=torch.float64, device=dev)
-        g_s = torch.empty(1, dtype=torch.float64, device=dev)
-        g_t = torch.empty(S, dtype=torch.float64, device=dev)
-        need_U = ctx.needs_input_grad[0] and dU > 0
-        g_U = torch.zeros(N, D, dtype=torch.float64, device=dev) if ctx.needs_input_grad[0] else None
-        g_Ud = torch.empty(N, dU, dtype=torch.float64, device=dev) if need_U else None
-        with _stage("grad_reduce"):
-            gctx.grad_reduce(Ud, wd, sd, grp, S, ws.alpha, ws.Ki, dU if need_U else 0, g_w, g_s, g_t, g_Ud, kind=kind,
-                             d_split=d_split)
-        if need_U:
-            g_U[:, :dU] = g_Ud
+        g_w, g_s, g_t, g_Ud, alpha, (N, D, dU) = ctx.saved
+        need = ctx.needs_input_grad
         go = grad_out.to(torch.float64)
+        g_U = None
+        if need[0]:
+            g_U = torch.zeros(N, D, dtype=torch.float64, device=alpha.device)
+            if g_Ud is not None:
+                g_U[:, :dU] = g_Ud
         dt = ctx.in_dtypes
         sf2_shape, tau_shape = ctx.shapes
-        alpha = ws.alpha
         return (None if g_U is None else (go * g_U).to(dt[0]),
-                (go * g_w).to(dt[1]) if ctx.needs_input_grad[1] else None,
-                (go * g_s).reshape(sf2_shape).to(dt[2]) if ctx.needs_input_grad[2] else None,
-                (go * g_t).reshape(tau_shape).to(dt[3]) if ctx.needs_input_grad[3] else None,
-                (go * alpha).to(dt[4]) if ctx.needs_input_grad[4] else None,
-                (-go * alpha).to(dt[5]) if ctx.needs_input_grad[5] else None,
+                (go * g_w).to(dt[1]) if need[1] else None,
+                (go * g_s).reshape(sf2_shape).to(dt[2]) if need[2] else None,
+                (go * g_t).reshape(tau_shape).to(dt[3]) if need[3] else None,
+                (go * alpha).to(dt[4]) if need[4] else None,
+                (-go * alpha).to(dt[5]) if need[5] else None,
                 None, None, None, None, None)
 
 

@@ -44,6 +44,7 @@ def main():
         ms = float(np.median(v)); total += ms
         extra = f"  {flops[k] / ms / 1e9:8.2f} TFLOP/s" if k in flops else ""
         print(f"{k:12s} {ms:10.3f} ms{extra}")
+    print("grad checksum", float(gw.sum() + gs.sum() + gt.sum()))
     print(f"{'total':12s} {total:10.3f} ms  -> {1000.0 / total:.3f} evals/s   N^3 rate {N**3 / total / 1e9:.2f} TFLOP/s   mll={out3[2].item():.6f}")
 
 if __name__ == "__main__":
