@@ -32,6 +32,8 @@ class BatchedWorkspace:
         self.r, self.z, self.alpha = (ctx.batched_vector(B, N) for _ in range(3))
         self.out3 = torch.empty(B, 3, dtype=torch.float64, device=dev)
         self.info = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.info_host = torch.zeros(B, dtype=torch.int32).pin_memory()
+        self.info_event = torch.cuda.Event()
         self.epoch = 0
 
 
@@ -55,23 +57,32 @@ def _f64(t: torch.Tensor, dev) -> torch.Tensor:
     return t.detach().to(device=dev, dtype=torch.float64).contiguous()
 
 
-def _factor_batched(gctx: GppContext, ws: BatchedWorkspace, U, w, sf2, tau, grp, kind, d_split) -> torch.Tensor:
+def _factor_batched(gctx: GppContext, ws: BatchedWorkspace, U, w, sf2, tau, grp, kind, d_split, after=None) -> torch.Tensor:
     """Build + factor all elements; failing ones are retried with gpytorch's jitter schedule added to THEIR noise.
-    Returns the boolean mask (B,) of elements that are positive definite in the end."""
+    Returns the boolean mask (B,) of elements that are positive definite in the end.  ``after()`` enqueues the rest of
+    the evaluation before the host waits for the status words (one wait per attempt, covering the factorisation only)."""
     jitters = [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
     extra = torch.zeros(ws.B, 1, dtype=torch.float64, device=U.device)
     ok = None
     for attempt in range(len(jitters) + 1):
         gctx.kernel_build_batched(U, w, sf2, tau + extra, grp, ws.A, kind=kind, d_split=d_split, uplo=UPLO_UPPER)
         gctx.potrf_batched(ws.A, ws.Li, ws.info)
-        ok = ws.info == 0  # (one host sync per attempt, like the single-problem path)
-        if bool(ok.all()) or attempt == len(jitters):
+        ok = ws.info == 0
+        ws.info_host.copy_(ws.info, non_blocking=True)
+        ws.info_event.record()
+        if after is not None:
+            after()
+        ws.info_event.synchronize()
+        if bool((ws.info_host == 0).all()) or attempt == len(jitters):
             break
         extra = torch.where(ok.unsqueeze(1), extra, torch.full_like(extra, jitters[attempt]))
     return ok
 
 
 class BatchedMLLFunction(torch.autograd.Function):
+    """B independent evaluations per launch.  As in linalg.ExactMLLFunction the gradients are produced in ``forward``
+    (when any input needs one), ahead of the host's wait for the factorisation status; ``backward`` only scales them."""
+
     @staticmethod
     def forward(ctx, U, w, sf2, tau, mean, y, grp, kind, d_split, dU):
         dev = w.device
@@ -79,15 +90,34 @@ class BatchedMLLFunction(torch.autograd.Function):
         B, D = w.shape
         N = U.shape[-2]
         Ud, wd, sd, td = _f64(U, dev), _f64(w, dev), _f64(sf2.reshape(B), dev), _f64(tau.reshape(B, -1), dev)
+        S = td.shape[1]
         if grp is not None and grp.dtype != torch.int32:
             grp = grp.to(torch.int32)
         ws = get_batched_workspace(gctx, B, N)
         ws.epoch += 1
-        ok = _factor_batched(gctx, ws, Ud, wd, sd, td, grp, kind, d_split)
-        gctx.trtri_batched(ws.A, ws.Li, ws.Ki)
         torch.sub(_f64(y, dev).expand(B, N), _f64(mean, dev).expand(B, N), out=ws.r)
-        gctx.mll_reduce_batched(ws.A, ws.Li, ws.r, ws.z, ws.out3)
-        ctx.saved = (gctx, ws, ws.epoch, Ud, wd, sd, grp, td.shape[1], kind, d_split, dU, ok)
+        need = ctx.needs_input_grad
+        need_grad = any(need[:6])
+        need_U = need[0] and dU > 0
+        g_w = g_s = g_t = g_Ud = None
+        if need_grad:
+            g_w = torch.empty(B, D, dtype=torch.float64, device=dev)
+            g_s = torch.empty(B, dtype=torch.float64, device=dev)
+            g_t = torch.empty(B, S, dtype=torch.float64, device=dev)
+            g_Ud = torch.empty(B, N, dU, dtype=torch.float64, device=dev) if need_U else None
+
+        def rest():
+            gctx.trtri_batched(ws.A, ws.Li, ws.Ki)
+            gctx.mll_reduce_batched(ws.A, ws.Li, ws.r, ws.z, ws.out3)
+            if not need_grad:
+                return
+            gctx.alpha_batched(ws.Li, ws.z, ws.alpha)
+            gctx.lauum_batched(ws.Li, ws.Ki)
+            gctx.grad_reduce_batched(Ud, wd, sd, grp, S, ws.alpha, ws.Ki, dU if need_U else 0, g_w, g_s, g_t, g_Ud,
+                                     kind=kind, d_split=d_split)
+
+        ok = _factor_batched(gctx, ws, Ud, wd, sd, td, grp, kind, d_split, after=rest)
+        ctx.saved = (g_w, g_s, g_t, g_Ud, ws.alpha.clone() if need_grad else None, ok, (B, N, Ud.shape[-1], dU))
         ctx.in_dtypes = (U.dtype, w.dtype, sf2.dtype, tau.dtype, mean.dtype, y.dtype)
         ctx.shapes = (U.shape, sf2.shape, tau.shape, mean.shape, y.shape)
         mll = ws.out3[:, 2].clone()
@@ -95,28 +125,16 @@ class BatchedMLLFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        gctx, ws, epoch, Ud, wd, sd, grp, S, kind, d_split, dU, ok = ctx.saved
-        if ws.epoch != epoch:
-            raise RuntimeError("batched evaluation: backward after another batched forward reused the buffers")
-        B, D = wd.shape
-        N = ws.N
-        dev = wd.device
-        gctx.alpha_batched(ws.Li, ws.z, ws.alpha)
-        gctx.lauum_batched(ws.Li, ws.Ki)
+        g_w, g_s, g_t, g_Ud, alpha_all, ok, (B, N, Dfull, dU) = ctx.saved
+        dev = alpha_all.device
         U_shape, sf2_shape, tau_shape, mean_shape, y_shape = ctx.shapes
-        need_U = ctx.needs_input_grad[0] and dU > 0
-        g_w = torch.empty(B, D, dtype=torch.float64, device=dev)
-        g_s = torch.empty(B, dtype=torch.float64, device=dev)
-        g_t = torch.empty(B, S, dtype=torch.float64, device=dev)
-        g_Ud = torch.empty(B, N, dU, dtype=torch.float64, device=dev) if need_U else None
-        gctx.grad_reduce_batched(Ud, wd, sd, grp, S, ws.alpha, ws.Ki, dU if need_U else 0, g_w, g_s, g_t, g_Ud, kind=kind,
-                                 d_split=d_split)
+        need_U = g_Ud is not None
         go = torch.where(ok, grad_out.to(torch.float64), torch.zeros_like(grad_out, dtype=torch.float64))  # failed: no gradient
         dt = ctx.in_dtypes
-        alpha = torch.where(ok.unsqueeze(1), ws.alpha, torch.zeros_like(ws.alpha))
+        alpha = torch.where(ok.unsqueeze(1), alpha_all, torch.zeros_like(alpha_all))
         g_U = None
         if ctx.needs_input_grad[0]:
-            full = torch.zeros(B, N, Ud.shape[-1], dtype=torch.float64, device=dev)
+            full = torch.zeros(B, N, Dfull, dtype=torch.float64, device=dev)
             if need_U:
                 full[:, :, :dU] = torch.where(ok.view(B, 1, 1), g_Ud, torch.zeros_like(g_Ud)) * go.view(B, 1, 1)
             g_U = (full if len(U_shape) == 3 else full.sum(0)).to(dt[0])
