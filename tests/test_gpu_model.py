@@ -88,9 +88,10 @@ def test_predict_matches_golden(gpu_ctx, fixture, tag, kw):
     np.testing.assert_allclose(only_mean.cpu().numpy(), mean.cpu().numpy(), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("n,d,seed", [(64, 3, 0), (777, 8, 1), (2048, 8, 2), (4097, 5, 3)])
+@pytest.mark.parametrize("n,d,seed", [(64, 3, 0), (777, 8, 1), (2048, 8, 2), (4097, 5, 3), (6200, 8, 4)])
 def test_against_oracle_on_fresh_inputs(gpu_ctx, n, d, seed):
-    """Same seeded inputs through the oracle (CPU) and the product (GPU), incl. a non-multiple-of-tile size."""
+    """Same seeded inputs through the oracle (CPU) and the product (GPU), incl. a non-multiple-of-tile size and the sizes
+    whose inverse is built by bordering inside the look-ahead factorisation (n >= 4096)."""
     from oracle.gp_oracle import OracleGP
     from gpplus_amd.models import GP_Plus
 
