@@ -304,6 +304,8 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   // the first product of a bordering step needs neither this block's factor nor its inverse: it is issued before them
   // and only the second waits for D (measured: 4.54 -> 4.44 ms per evaluation at 4096, 13.7 -> 13.4 at 8192, even above)
   static const bool border_early = !(getenv("GPP_BORDER_EARLY") && atoi(getenv("GPP_BORDER_EARLY")) == 0);  // experiment knob
+  // (measured: potrf 58.2 -> 56.4 ms at N = 20000, 28.4 -> 27.3 at 15000, 17.0 -> 16.4 at 10000)
+  static const bool merge_upd_on = !(getenv("GPP_MERGE_UPD") && atoi(getenv("GPP_MERGE_UPD")) == 0);  // experiment knob
   static const bool split_chain = !(getenv("GPP_SPLIT_CHAIN") && atoi(getenv("GPP_SPLIT_CHAIN")) == 0);  // experiment knob
   hipStream_t cf = h->fill_stream;
   static const int64_t border_t128 = getenv("GPP_BORDER_T128") ? atol(getenv("GPP_BORDER_T128")) : 640;  // experiment knob
@@ -362,6 +364,7 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
                               nc * sizeof(double), nb, hipMemcpyDeviceToDevice, cu.s);
     };
     const double* Urow = cm.A + o * cm.ld;  // block row o: U[o.., :]
+    const bool merge_upd = merge_upd_on && split_chain && nb2 % NBLK == 0;
     // the chain first: the columns of the NEXT diagonal block, its update, and the panel stream may go on (event S)
     HIP_TRY(row_solve(o + nb, split_chain ? nb2 : rem));
     GemmArgs g = mk(Urow + (o + nb), cm.ld, Urow + (o + nb), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb), cm.ld, nb2, nb2, nb,
@@ -378,7 +381,7 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
       R = next_event(h);
       HIP_TRY(hipEventRecord(R, cu.s));
     }
-    if (rest > 0) {  // the part of the next block row to the right of its diagonal block
+    if (rest > 0 && !merge_upd) {  // the part of the next block row to the right of its diagonal block
       GemmArgs g2 = mk(Urow + (o + nb), cm.ld, Urow + (o + nb + nb2), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb + nb2), cm.ld,
                        nb2, rest, nb, -1.0, 1.0);
       HIP_TRY(gpp_launch_gemm(cu.s, 2, g2, 1));
@@ -389,7 +392,15 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
       HIP_TRY(hipStreamWaitEvent(cf, S, 0));  // behind the strip: the chain's own launches get the CUs first
       HIP_TRY(border_step());
     }
-    if (rest > 0) {
+    if (rest > 0 && merge_upd) {
+      // everything but the next diagonal block (done above) in ONE launch: the next block row's part to the right of its
+      // diagonal block no longer runs as a launch of its own with a nearly empty last wave of work-groups
+      GemmArgs g3 = mk(Urow + (o + nb), cm.ld, Urow + (o + nb), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb), cm.ld, rem, rem, nb,
+                       -1.0, 1.0);
+      g3.c_lower = 2;
+      g3.skip_lead = (int)nb2;
+      HIP_TRY(gpp_launch_gemm(cu.s, 2, g3, 1, NBLK, NBLK));
+    } else if (rest > 0) {
       GemmArgs g3 = mk(Urow + (o + nb + nb2), cm.ld, Urow + (o + nb + nb2), cm.ld,
                        cm.A + (o + nb + nb2) * cm.ld + (o + nb + nb2), cm.ld, rest, rest, nb, -1.0, 1.0);
       g3.c_lower = 2;

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
         tm = tn;
         tn = q;
         if (p.own_mod > 1 && (tm / p.own_bt + p.own_off) % p.own_mod != 0) return;  // another rank's block row
+        if ((tn + 1) * TN <= p.skip_lead) return;  // (tm <= tn) inside the leading block another launch has updated
       }
     } else if (p.col_major) {
       // column-major tile order: consecutive work-groups share the column tile (hence the K range when it depends on

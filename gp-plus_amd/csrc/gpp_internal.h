@@ -48,6 +48,8 @@ struct GemmArgs {
   int swz;                 // set by the launcher: XCD-aware 8x8 super-tile mapping of blockIdx -> tile
   int own_mod, own_off, own_bt;  // c_lower == 2 only: produce the tile rows tm with (tm / own_bt + own_off) % own_mod == 0
                            // (block-cyclic block rows of own_bt tile rows; own_mod <= 1: all).  Other tiles exit at once.
+  int skip_lead;           // c_lower == 2 only: tiles lying entirely inside the leading skip_lead x skip_lead block exit at once
+                           // (that block was updated by an earlier launch; skip_lead a multiple of the tile)
   int row_mod, row_off;    // c_lower == 1 only: produce the tile rows tm with tm % row_mod == row_off (row_mod <= 1: all);
                            // the sharded LAUUM, one launch per rank over its cyclic share of the 128-row tile rows
 };
