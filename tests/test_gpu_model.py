@@ -251,6 +251,60 @@ def test_full_size_properties_n20000(gpu_ctx):
     assert abs(g_tau.item() - expect) <= 1e-6 * abs(expect)
 
 
+@pytest.mark.parametrize("cfg", ["C3", "C4"])
+def test_full_size_mixed_and_multifidelity_models(gpu_ctx, cfg):
+    """BASELINE.json's C3 (N=10000, two 5-level categorical inputs through the latent map) and C4 (N=15000, three
+    sources with their own noise and mean) at FULL size through the GP_Plus API, checked by a size-independent property:
+    the directional derivative of the loss along a random direction in parameter space, by central differences, equals
+    grad . v.  C3 runs the look-ahead factorisation with the bordered inverse, C4 the one with pair merging."""
+    from gpplus_amd.models import GP_Plus
+    from gpplus_amd.preprocessing import standard
+    from gpplus_amd.test_functions.analytical import borehole_mixed_variables
+    from gpplus_amd.test_functions.multi_fidelity import multi_fidelity_wing
+
+    torch.manual_seed(0)
+    if cfg == "C3":
+        np.random.seed(4)
+        qd = {0: 5, 5: 5}
+        U, y = borehole_mixed_variables(n=10000, qual_dict=qd, random_state=4, shuffle=False)
+        U, _, _ = standard(torch.as_tensor(U).double(), qd)
+        m = GP_Plus(U, torch.tensor(y), qual_dict=qd, dtype=torch.float64, device="cuda")
+    else:
+        X, y = multi_fidelity_wing(n={"0": 5000, "1": 5000, "2": 5000}, noise_std={"0": 0.5, "1": 1.0, "2": 1.5},
+                                   random_state=4)
+        X, _, _ = standard(torch.tensor(X), {10: 3})
+        m = GP_Plus(X, torch.tensor(y), qual_dict={10: 3}, multiple_noise=True, m_gp="multiple_constant",
+                    dtype=torch.float64, device="cuda")
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if "raw_lengthscale" in n and p.requires_grad:
+                p.fill_(-1.0)
+            elif n == "covar_module.raw_outputscale":
+                p.fill_(0.3)
+            elif "raw_noise" in n:
+                p.fill_(-6.0)
+            elif n.endswith(".constant"):
+                p.fill_(0.4 if n == "mean_module.constant" else 0.1)
+    loss0, grads = loss_and_grads(m)
+    assert np.isfinite(loss0) and all(np.isfinite(g).all() for g in grads.values())
+    params = {n: p for n, p in m.named_parameters() if n in grads}
+    gen = torch.Generator().manual_seed(1)
+    v = {n: torch.randn(p.shape, generator=gen, dtype=torch.float64).to(p) for n, p in params.items()}
+    dd = sum(float((torch.as_tensor(grads[n]).to(v[n]).cpu() * v[n].cpu()).sum()) for n in params)
+    eps = 1e-4 if all(p.dtype == torch.float64 for p in params.values()) else 2e-3
+    vals = []
+    for sgn in (+1.0, -1.0):
+        with torch.no_grad():
+            for n, p in params.items():
+                p.add_(sgn * eps * v[n])
+        vals.append(loss_and_grads(m)[0])
+        with torch.no_grad():
+            for n, p in params.items():
+                p.sub_(sgn * eps * v[n])
+    fd = (vals[0] - vals[1]) / (2 * eps)
+    assert abs(fd - dd) <= 2e-4 * max(abs(dd), 1e-3), (fd, dd)
+
+
 def test_fit_model_scipy_lbfgs(gpu_ctx):
     """the scipy multistart driver on the HIP back end; objective = -(log_prob + priors), not / N."""
     from oracle.gp_oracle import OracleGP
