@@ -392,7 +392,11 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
       const int kb = kpos(c + 1);
       load_fast<NVA>(ubaseA + (int64_t)kb * stepA, offa, ra);
       load_fast<NVB>(ubaseB + (int64_t)kb * stepB, offb, rb);
-      compute(cur);  // (s_setprio around this phase: LAUUM +4 %, the look-ahead factorisation -3 %: not adopted)
+      // raised wave priority around the MFMA phase: +2.3 % for LAUUM (TAG 1: 63.95 -> 65.4 TFLOP/s, same box), nothing
+      // for gpp_trtri's masked merges, -3 % for the look-ahead factorisation's concurrent streams (both TAG 0)
+      if constexpr (TAG == 1) __builtin_amdgcn_s_setprio(1);
+      compute(cur);
+      if constexpr (TAG == 1) __builtin_amdgcn_s_setprio(0);
       if (NBUF == 1) __syncthreads();
       store_mc<TM, BK, false>(smem + (nxt * 2 + 0) * OPSZ, tid, ra, 0);
       store_mc<TN, BK, false>(smem + (nxt * 2 + 1) * OPSZ, tid, rb, 0);
