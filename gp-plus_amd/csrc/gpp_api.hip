@@ -263,6 +263,10 @@ hipError_t ensure_streams(gpp_handle_s* h) {
       if (e != hipSuccess) return e;
     }
   }
+  if (!h->full_stream) {
+    hipError_t e = hipStreamCreateWithFlags(&h->full_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return e;
+  }
   while (h->n_events < 16) {
     hipError_t e = hipEventCreateWithFlags(&h->events[h->n_events], hipEventDisableTiming);
     if (e != hipSuccess) return e;
@@ -310,6 +314,16 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   hipStream_t cf = h->fill_stream;
   static const int64_t border_t128 = getenv("GPP_BORDER_T128") ? atol(getenv("GPP_BORDER_T128")) : 640;  // experiment knob
   hipEvent_t R_prev = nullptr;  // row solves of the steps before the current one are complete
+  // The CU mask costs the throughput stream 12.5 % (see ensure_streams) although the panel needs its CUs only while it
+  // factors the next diagonal block (~1 ms of a 6.7 ms step at N = 20000).  The trailing update is therefore split: the
+  // first rows run on the masked stream beside the panel, the bulk waits for the panel (event D) and runs on a stream
+  // WITHOUT a mask.  Measured: potrf 56.6 -> 55.5 ms at N = 20000, 173.3 -> 165 ms at 30000; the masked part is sized in
+  // entries of the upper triangle (4.5e7 .. 9e7 equal; 2e8 loses the gain, 1.5e7 half of it).
+  static const bool split_upd_on = !(getenv("GPP_SPLIT_UPD") && atoi(getenv("GPP_SPLIT_UPD")) == 0);  // experiment knob
+  static const int64_t split_elems = getenv("GPP_SPLIT_ELEMS") ? atol(getenv("GPP_SPLIT_ELEMS")) : 60000000;
+  const bool split_upd = split_upd_on && !border && h->cu_split == 1;
+  hipStream_t cx = h->full_stream;
+  struct { bool on; GemmArgs g; hipEvent_t rows_ready; } pend{false, GemmArgs{}, nullptr};
   // with bordering the block height matters little; one height per N measured best (512 up to ~7000 rows: 7.5 vs 8.3 ms per
   // evaluation at 6144; 1024 above: 23.3 vs 24.2 ms at 10000)
   if (border && !env_nb) nb_thresh = (N <= 7168) ? N + 1 : 0;
@@ -333,6 +347,17 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
     hipEvent_t D = next_event(h);
     HIP_TRY(hipEventRecord(D, cp.s));
     HIP_TRY(hipStreamWaitEvent(cu.s, D, 0));
+    if (pend.on) {
+      // the bulk of the previous step's trailing update: the diagonal block it ran beside is done (D), so no leaf is
+      // waiting for a CU and this part may take all of them (62 instead of 55 TFLOP/s)
+      HIP_TRY(hipStreamWaitEvent(cx, pend.rows_ready, 0));
+      HIP_TRY(hipStreamWaitEvent(cx, D, 0));
+      HIP_TRY(gpp_launch_gemm(cx, 2, pend.g, 1, NBLK, NBLK));
+      hipEvent_t BE = next_event(h);
+      HIP_TRY(hipEventRecord(BE, cx));
+      HIP_TRY(hipStreamWaitEvent(cu.s, BE, 0));
+      pend.on = false;
+    }
     auto border_step = [&]() -> hipError_t {
       // bordering step of the inverse: Linv[o.., 0..o) = -W_oo^T (U[0..o, o..)^T Linv[0..o, 0..o)) — the ragged pair merge
       // of [0, o) with [o, o+nb).  Needs block rows < o of U (row solves of the earlier steps: event R) and this block's
@@ -399,7 +424,26 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
                        -1.0, 1.0);
       g3.c_lower = 2;
       g3.skip_lead = (int)nb2;
-      HIP_TRY(gpp_launch_gemm(cu.s, 2, g3, 1, NBLK, NBLK));
+      // rows [0, rA) of the trailing matrix run beside the next diagonal block on the CU-masked stream; rA is sized so
+      // that this takes about as long as that block (split_elems entries of the upper triangle), the rest follows unmasked
+      int64_t rA = ((split_elems / rem + NBLK - 1) / NBLK) * NBLK;
+      rA = std::max(rA, nb2);
+      if (split_upd && rem - rA >= 2048) {
+        pend.rows_ready = next_event(h);
+        HIP_TRY(hipEventRecord(pend.rows_ready, cu.s));  // block row o is final (the unmasked part needs nothing else)
+        GemmArgs a1 = g3;  // upper triangle of the leading rA x rA block (minus the next diagonal block)
+        a1.M = a1.N = (int)rA;
+        HIP_TRY(gpp_launch_gemm(cu.s, 2, a1, 1, NBLK, NBLK));
+        GemmArgs a2 = mk(Urow + (o + nb), cm.ld, Urow + (o + nb + rA), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb + rA), cm.ld,
+                         rA, rem - rA, nb, -1.0, 1.0);  // rows [0, rA) x columns [rA, rem)
+        HIP_TRY(gpp_launch_gemm(cu.s, 2, a2, 1, NBLK, NBLK));
+        pend.g = mk(Urow + (o + nb + rA), cm.ld, Urow + (o + nb + rA), cm.ld, cm.A + (o + nb + rA) * cm.ld + (o + nb + rA),
+                    cm.ld, rem - rA, rem - rA, nb, -1.0, 1.0);
+        pend.g.c_lower = 2;
+        pend.on = true;
+      } else {
+        HIP_TRY(gpp_launch_gemm(cu.s, 2, g3, 1, NBLK, NBLK));
+      }
     } else if (rest > 0) {
       GemmArgs g3 = mk(Urow + (o + nb + nb2), cm.ld, Urow + (o + nb + nb2), cm.ld,
                        cm.A + (o + nb + nb2) * cm.ld + (o + nb + nb2), cm.ld, rest, rest, nb, -1.0, 1.0);
@@ -408,6 +452,7 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
     }
     R_prev = R;
   }
+  if (pend.on) return hipErrorUnknown;  // (cannot happen: the last step has no trailing update)
   hipEvent_t E = next_event(h);
   HIP_TRY(hipEventRecord(E, cu.s));
   HIP_TRY(hipStreamWaitEvent(cm.s, E, 0));  // (the update stream already waited for the last D)
@@ -451,6 +496,7 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->panel_stream = nullptr;
   h->upd_stream = nullptr;
   h->fill_stream = nullptr;
+  h->full_stream = nullptr;
   h->cu_split = -1;
   h->n_events = 0;
   h->ev_next = 0;
@@ -465,6 +511,7 @@ int gpp_destroy(gpp_handle_t h) {
   if (h->panel_stream) (void)hipStreamDestroy(h->panel_stream);
   if (h->upd_stream) (void)hipStreamDestroy(h->upd_stream);
   if (h->fill_stream) (void)hipStreamDestroy(h->fill_stream);
+  if (h->full_stream) (void)hipStreamDestroy(h->full_stream);
   for (int i = 0; i < h->n_events; ++i) (void)hipEventDestroy(h->events[i]);
   delete h;
   return 0;

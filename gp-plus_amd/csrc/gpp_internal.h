@@ -13,6 +13,8 @@ struct gpp_handle_s {
   size_t ws_bytes;
   hipStream_t panel_stream;  // internal stream of the look-ahead Cholesky: diagonal-block factorisations (lazy)
   hipStream_t upd_stream;    // internal stream of the look-ahead Cholesky: wide trsm / trailing updates (lazy)
+  hipStream_t full_stream;   // internal stream of the look-ahead Cholesky WITHOUT a CU mask: the part of a trailing update
+                             // that runs after the next diagonal block is done (no leaf to starve) gets all 256 CUs (lazy)
   hipStream_t fill_stream;   // internal stream of the look-ahead Cholesky: bordering steps of the inverse (lazy; CUs of upd_stream)
   int cu_split;              // 1: the two streams own disjoint CU sets (CU masks), 0: plain priority streams, -1: unknown
   hipEvent_t events[16];     // ring of timing-disabled events for the two-stream hand-offs (lazy)
