@@ -431,12 +431,12 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
       if (split_upd && rem - rA >= 2048) {
         pend.rows_ready = next_event(h);
         HIP_TRY(hipEventRecord(pend.rows_ready, cu.s));  // block row o is final (the unmasked part needs nothing else)
-        GemmArgs a1 = g3;  // upper triangle of the leading rA x rA block (minus the next diagonal block)
-        a1.M = a1.N = (int)rA;
-        HIP_TRY(gpp_launch_gemm(cu.s, 2, a1, 1, NBLK, NBLK));
         GemmArgs a2 = mk(Urow + (o + nb), cm.ld, Urow + (o + nb + rA), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb + rA), cm.ld,
                          rA, rem - rA, nb, -1.0, 1.0);  // rows [0, rA) x columns [rA, rem)
         HIP_TRY(gpp_launch_gemm(cu.s, 2, a2, 1, NBLK, NBLK));
+        GemmArgs a1 = g3;  // upper triangle of the leading rA x rA block (minus the next diagonal block): a few hundred
+        a1.M = a1.N = (int)rA;  // tiles, issued last so that they run beside the unmasked part instead of on an emptying chip
+        HIP_TRY(gpp_launch_gemm(cu.s, 2, a1, 1, NBLK, NBLK));
         pend.g = mk(Urow + (o + nb + rA), cm.ld, Urow + (o + nb + rA), cm.ld, cm.A + (o + nb + rA) * cm.ld + (o + nb + rA),
                     cm.ld, rem - rA, rem - rA, nb, -1.0, 1.0);
         pend.g.c_lower = 2;
