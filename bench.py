@@ -209,6 +209,8 @@ def main():
         stages = {}
         for name, e0, e1 in events:
             stages.setdefault(name, []).append(e0.elapsed_time(e1))
+        if os.environ.get("GPP_BENCH_DEBUG"):
+            print({k: [round(x, 2) for x in v] for k, v in stages.items()}, file=sys.stderr)
         stage_ms = {k: float(np.mean(v)) for k, v in stages.items()}
         flops = {"potrf": N ** 3 / 3, "trtri": N ** 3 / 3, "lauum": N ** 3 / 3}
         stage_rate = {k: flops[k] / (stage_ms[k] * 1e-3) / 1e12 for k in flops if k in stage_ms}

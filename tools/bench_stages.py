@@ -12,7 +12,7 @@ def main():
     ctx = get_context("cuda:0")
     g = torch.Generator(device="cuda").manual_seed(0)
     U = torch.randn(N, D, dtype=torch.float64, device="cuda", generator=g)
-    w = torch.full((D,), 0.1, dtype=torch.float64, device="cuda")
+    w = torch.full((D,), float(__import__("os").environ.get("STAGES_W", "0.1")), dtype=torch.float64, device="cuda")
     sf2 = torch.tensor([0.85], dtype=torch.float64, device="cuda")
     tau = torch.tensor([2.5e-3], dtype=torch.float64, device="cuda")
     r = torch.randn(N, dtype=torch.float64, device="cuda", generator=g)
@@ -33,10 +33,16 @@ def main():
     }
     flops = {"potrf": N**3 / 3, "trtri": N**3 / 3, "lauum": N**3 / 3}
     tot = {k: [] for k in stages}
+    nosync = __import__("os").environ.get("STAGES_NOSYNC", "0") != "0"  # enqueue the whole evaluation, then wait (as the product does)
     for rep in range(reps + 1):
+        evs = []
         for k, fn in stages.items():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            e0.record(); fn(); e1.record()
+            if not nosync: torch.cuda.synchronize()
+            evs.append((k, e0, e1))
+        torch.cuda.synchronize()
+        for k, e0, e1 in evs:
             if rep > 0: tot[k].append(e0.elapsed_time(e1))
         assert int(info.item()) == 0, info
     total = 0.0
