@@ -56,6 +56,7 @@ class EvalWorkspace:
         self.info_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.info_event = torch.cuda.Event()
         self.late_event = torch.cuda.Event()
+        self.late_pending = False
         self.epoch = 0
 
 
@@ -80,7 +81,7 @@ def eval_slot(slot: int):
 def current_slot() -> int:
     return getattr(_tls, "slot", 0)
 
-#: from this size on the host waits behind the LAUUM launch instead of the factorisation (see _factor)
+#: from this size on the host waits behind the LAUUM launch before forward returns (see _factor)
 LATE_SYNC_N = int(__import__("os").environ.get("GPP_LATE_SYNC_N", "16384"))
 
 #: optional stage timing (bench.py): when this is a list, every stage appends (name, start_event, end_event) recorded
@@ -131,22 +132,30 @@ def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_spl
     for jit in jitters:
         with _stage("kernel_build"):
             ctx.kernel_build(U, w, sf2, tau, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_UPPER)
+        if ws.late_pending:
+            # Do not park this factorisation's launches on the library's internal streams while the previous
+            # evaluation's O(N^3) stages still run: with them parked every stage of that evaluation measures slower
+            # (N = 20000: potrf 55.8 -> 59.3 ms, trtri 44.3 -> 44.9, lauum 40.3 -> 40.7; GPU_MAX_HW_QUEUES 4 / 8 / 16
+            # alike).  The Python between two evaluations has already run by now — it overlapped those stages.
+            ws.late_event.synchronize()
+            ws.late_pending = False
         with _stage("potrf"):
             ctx.potrf(ws.A, ws.Li, ws.info, ws.Ki)
         # the one host wait of an evaluation (the reference syncs on loss.item() too) covers the factorisation only: the
         # status goes to pinned host memory behind an event, the rest of the evaluation is enqueued, THEN the host waits
         ws.info_host.copy_(ws.info, non_blocking=True)
         ws.info_event.record()
-        late = after() if after is not None else None
-        # Large N (>= LATE_SYNC_N): wait further down the stream (``after`` returns the event it recorded behind its last
-        # O(N^3) launch).  Letting the host run a whole evaluation ahead costs the device there — with the next
-        # factorisation's launches already parked on the library's internal streams, every stage of the current
-        # evaluation measures slower (N = 20000: potrf 55.8 -> 59.3 ms, trtri 44.3 -> 44.9, lauum 40.3 -> 40.7; not a
-        # matter of hardware queue count: GPU_MAX_HW_QUEUES 4 / 8 / 16 alike) — while the Python it would hide (1-2 ms)
-        # fits behind the gradient reduction that still follows this event: bench.py 152.1 -> 146.3 ms per evaluation.
-        # Below that size the Python of the mixed-input models (3-4 ms) outweighs the effect (C3, C4: no gain), and
-        # waiting behind the gradient reduction as well exposes it (C4: 70.5 -> 73.4 ms).
-        (late if late is not None else ws.info_event).synchronize()
+        if after is not None:
+            after()
+        if ws.late_pending and ws.N >= LATE_SYNC_N:
+            # From this size on the wait happens HERE, before forward returns, so that the Python between two evaluations
+            # runs on an idle device (only the gradient reduction is still in flight): measured on one box, N = 20000,
+            # bench.py: 151-153 ms per evaluation with neither wait, 148.5 with the wait above, 143.9 with this one — the
+            # chip holds a higher clock after the ~1 ms pause than under unbroken load (clock under load).
+            # Below, the Python of the mixed-input models (3-4 ms) would cost more than that (C4: 70.5 -> 71.0 ms).
+            ws.late_event.synchronize()
+            ws.late_pending = False
+        ws.info_event.synchronize()
         info = int(ws.info_host[0])
         if info == 0:
             if jit > 0:
@@ -191,26 +200,22 @@ class ExactMLLFunction(torch.autograd.Function):
             g_t = torch.empty(S, dtype=torch.float64, device=dev)
             g_Ud = torch.empty(N, dU, dtype=torch.float64, device=dev) if need_U else None
 
-        late = [None]
-
         def rest():
             with _stage("trtri"):
                 gctx.trtri(ws.A, ws.Li, ws.Ki)
             with _stage("mll_reduce"):
                 gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
             if not need_grad:
-                return None
+                return
             with _stage("alpha"):
                 gctx.alpha(ws.Li, ws.z, ws.alpha)
             with _stage("lauum"):
                 gctx.lauum(ws.Li, ws.Ki)
-            if N >= LATE_SYNC_N:
-                ws.late_event.record()
-                late[0] = ws.late_event
+            ws.late_event.record()  # the next factorisation is enqueued behind this point (see _factor)
+            ws.late_pending = True
             with _stage("grad_reduce"):
                 gctx.grad_reduce(Ud, wd, sd, grp, S, ws.alpha, ws.Ki, dU if need_U else 0, g_w, g_s, g_t, g_Ud, kind=kind,
                                  d_split=d_split)
-            return late[0]
 
         _factor(gctx, ws, Ud, wd, sd, td, grp, kind, d_split, after=rest)
         ctx.saved = (g_w, g_s, g_t, g_Ud, ws.alpha.clone() if need_grad else None, (N, D, dU))
