@@ -285,9 +285,14 @@ inline hipEvent_t next_event(gpp_handle_s* h) {
     if (_e != hipSuccess) return _e; \
   } while (0)
 
-// panel stream : wait S(k-1); U_kk = potrf(A_kk) (recursive, narrow launches); record D(k)
-// update stream: wait D(k); U_k,k+1: = U_kk^-T A_k,k+1: (wide trsm); next block row of the trailing matrix -= ...;
-//                record S(k); rest of the trailing matrix -= ...
+// Step k (block row o, height nb) of the look-ahead, stream by stream (events in capitals):
+//   panel (32 CUs)    : wait S(k-1); U_oo = potrf(A_oo) in leaf steps; invert the block completely; record D(k)
+//   throughput (224)  : wait D(k); solve the columns of the NEXT diagonal block, update that block; record S(k);
+//                       solve the rest of block row o (R(k)); first rows of the trailing update
+//   unmasked (256)    : wait D(k+1); the bulk of step k's trailing update (N > 11264 only)
+//   fill (224, shared): bordering step of the inverse, Linv[o.., :o) (4096 <= N <= 11264 only): first product after
+//                       R(k-1), second after D(k)
+// The calling stream waits for all of them at the end; nothing else synchronises with the host.
 hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB, double* T, int64_t ldt) {
   HIP_TRY(ensure_streams(h));
   Ctx cp = cm, cu = cm;
