@@ -55,7 +55,11 @@ int gpp_create(gpp_handle_t* out, int device);
 int gpp_destroy(gpp_handle_t h);
 /* `stream` is a hipStream_t (passed as void* so this header needs no HIP include). */
 int gpp_set_stream(gpp_handle_t h, void* stream);
-/* The handle's two internal streams with disjoint CU sets (created on first use): which = 0 the latency stream (32 CUs,
+/* The look-ahead factorisation inside gpp_potrf(_ws) runs on internal streams of the handle, created on first use: a
+ * latency stream on 32 CUs (one per shader engine), a throughput stream and a fill stream on the other 224, and one
+ * stream without a CU mask for the bulk of each trailing update once the diagonal block it ran beside is done; the
+ * calling stream waits for all of them before the entry point's work is complete in stream order.
+ * The first two are exposed here, with their disjoint CU sets: which = 0 the latency stream (32 CUs,
  * one per shader engine) on which gpp_potrf_ws factors diagonal blocks, which = 1 the throughput stream (the other CUs)
  * of its trailing updates.  A host-side driver that overlaps its own panel factorisations with its own updates (the
  * sharded evaluation, gp-plus_amd/sharded.py) enqueues on them through gpp_set_stream.  *out receives a hipStream_t. */
