@@ -328,7 +328,10 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   static const int64_t split_elems = getenv("GPP_SPLIT_ELEMS") ? atol(getenv("GPP_SPLIT_ELEMS")) : 60000000;
   const bool split_upd = split_upd_on && !border && h->cu_split == 1;
   hipStream_t cx = h->full_stream;
-  struct { bool on; GemmArgs g; hipEvent_t rows_ready; } pend{false, GemmArgs{}, nullptr};
+  struct { bool on; GemmArgs g; hipEvent_t rows_ready; int64_t rows_masked; } pend{false, GemmArgs{}, nullptr, 0};
+  hipEvent_t be_wait = nullptr;  // end of the previous step's unmasked part, not yet waited for by the throughput stream
+  // (measured: potrf 55.3 -> 54.0 ms at N = 20000, 162.8 -> 161.1 at 30000)
+  static const bool defer_be = !(getenv("GPP_DEFER_BE") && atoi(getenv("GPP_DEFER_BE")) == 0);  // experiment knob
   // with bordering the block height matters little; one height per N measured best (512 up to ~7000 rows: 7.5 vs 8.3 ms per
   // evaluation at 6144; 1024 above: 23.3 vs 24.2 ms at 10000)
   if (border && !env_nb) nb_thresh = (N <= 7168) ? N + 1 : 0;
@@ -360,8 +363,12 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
       HIP_TRY(gpp_launch_gemm(cx, 2, pend.g, 1, NBLK, NBLK));
       hipEvent_t BE = next_event(h);
       HIP_TRY(hipEventRecord(BE, cx));
-      HIP_TRY(hipStreamWaitEvent(cu.s, BE, 0));
       pend.on = false;
+      // This step's chain (next diagonal block's columns and update) and row solve touch only rows the MASKED part of that
+      // update produced, when it was tall enough: then they run beside the bulk, and only this step's own trailing update
+      // waits for it.
+      if (defer_be && pend.rows_masked >= nb + std::min<int64_t>((rem >= nb_thresh) ? nb_big : nb_small, rem)) be_wait = BE;
+      else HIP_TRY(hipStreamWaitEvent(cu.s, BE, 0));
     }
     auto border_step = [&]() -> hipError_t {
       // bordering step of the inverse: Linv[o.., 0..o) = -W_oo^T (U[0..o, o..)^T Linv[0..o, 0..o)) — the ragged pair merge
@@ -377,6 +384,7 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
     if (border && o > 0 && border_early) HIP_TRY(border_step());
     if (rem == 0) {
       if (border && o > 0 && !border_early) HIP_TRY(border_step());
+      if (be_wait) HIP_TRY(hipStreamWaitEvent(cu.s, be_wait, 0));
       break;
     }
     const int64_t want2 = (rem >= nb_thresh) ? nb_big : nb_small;
@@ -422,6 +430,10 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
       HIP_TRY(hipStreamWaitEvent(cf, S, 0));  // behind the strip: the chain's own launches get the CUs first
       HIP_TRY(border_step());
     }
+    if (be_wait) {
+      HIP_TRY(hipStreamWaitEvent(cu.s, be_wait, 0));
+      be_wait = nullptr;
+    }
     if (rest > 0 && merge_upd) {
       // everything but the next diagonal block (done above) in ONE launch: the next block row's part to the right of its
       // diagonal block no longer runs as a launch of its own with a nearly empty last wave of work-groups
@@ -445,6 +457,7 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
         pend.g = mk(Urow + (o + nb + rA), cm.ld, Urow + (o + nb + rA), cm.ld, cm.A + (o + nb + rA) * cm.ld + (o + nb + rA),
                     cm.ld, rem - rA, rem - rA, nb, -1.0, 1.0);
         pend.g.c_lower = 2;
+        pend.rows_masked = rA;
         pend.on = true;
       } else {
         HIP_TRY(gpp_launch_gemm(cu.s, 2, g3, 1, NBLK, NBLK));
