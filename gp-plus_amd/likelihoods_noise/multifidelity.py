@@ -22,11 +22,19 @@ class Multifidelity_noise(HomoskedasticNoise):
         # group id of every point = position of its fidelity level in noise_indices; levels outside the list get a
         # zero noise in the reference (no indicator matches) -> extra group with zero variance
         fid = fidel_indices.reshape(-1)
-        grp = torch.full(fid.shape, len(noise_indices), dtype=torch.int32, device=fid.device)
-        for k, lvl in enumerate(noise_indices):
-            grp = torch.where(fid == lvl, torch.full_like(grp, k), grp)
+        # the grouping depends on the data only: computed once per index tensor (the any() below reads a device value, i.e.
+        # it synchronises the host with everything enqueued so far — once per fit instead of once per evaluation)
+        key = (id(fidel_indices), fidel_indices._version, tuple(noise_indices))
+        cached = getattr(self, "_grp_cache", None)
+        if cached is None or cached[0] != key or cached[1] is not fidel_indices:
+            grp = torch.full(fid.shape, len(noise_indices), dtype=torch.int32, device=fid.device)
+            for k, lvl in enumerate(noise_indices):
+                grp = torch.where(fid == lvl, torch.full_like(grp, k), grp)
+            cached = (key, fidel_indices, grp, bool((grp == len(noise_indices)).any()))
+            self._grp_cache = cached
+        grp, extra = cached[2], cached[3]
         noise = self.noise.reshape(-1)
-        if bool((grp == len(noise_indices)).any()):
+        if extra:
             noise = torch.cat([noise, torch.zeros(1, dtype=noise.dtype, device=noise.device)])
         return DiagNoise(noise, grp.to(noise.device), fid.shape[0])
 

@@ -82,7 +82,7 @@ def current_slot() -> int:
     return getattr(_tls, "slot", 0)
 
 #: from this size on the host waits behind the LAUUM launch before forward returns (see _factor)
-LATE_SYNC_N = int(__import__("os").environ.get("GPP_LATE_SYNC_N", "16384"))
+LATE_SYNC_N = int(__import__("os").environ.get("GPP_LATE_SYNC_N", "12000"))
 
 #: optional stage timing (bench.py): when this is a list, every stage appends (name, start_event, end_event) recorded
 #: on the stream the kernels are launched on (PyTorch's current stream).
@@ -152,7 +152,8 @@ def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_spl
             # runs on an idle device (only the gradient reduction is still in flight): measured on one box, N = 20000,
             # bench.py: 151-153 ms per evaluation with neither wait, 148.5 with the wait above, 143.9 with this one — the
             # chip holds a higher clock after the ~1 ms pause than under unbroken load (clock under load).
-            # Below, the Python of the mixed-input models (3-4 ms) would cost more than that (C4: 70.5 -> 71.0 ms).
+            # C4 (N = 15000, 2.5 ms of Python per step): 75.6-76.1 -> 69.9-71.7 ms; C3 (N = 10000): even (25.4-26.3 both) —
+            # the pause is worth 4-8 % of an evaluation and costs the Python between two of them, hence the threshold.
             ws.late_event.synchronize()
             ws.late_pending = False
         ws.info_event.synchronize()

@@ -1,0 +1,32 @@
+import os, sys, time, numpy as np, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from gpplus_amd.gpcore import ExactMarginalLogLikelihood
+from gpplus_amd.models import GP_Plus
+from gpplus_amd.preprocessing import standard
+from gpplus_amd.test_functions.analytical import borehole_mixed_variables
+from gpplus_amd.test_functions.multi_fidelity import multi_fidelity_wing
+import cProfile, pstats
+for name in ("C3-like", "C4-like"):
+    torch.manual_seed(0); np.random.seed(4)
+    if name == "C3-like":
+        qd = {0: 5, 5: 5}
+        U, y = borehole_mixed_variables(n=600, qual_dict=qd, random_state=4, shuffle=False)
+        U, _, _ = standard(torch.as_tensor(U).double(), qd)
+        m = GP_Plus(U, torch.tensor(y), qual_dict=qd, dtype=torch.float64, device="cuda")
+    else:
+        X, y = multi_fidelity_wing(n={'0': 200, '1': 200, '2': 200}, noise_std={'0': 0.5, '1': 1.0, '2': 1.5}, random_state=4)
+        X, _, _ = standard(torch.tensor(X), {10: 3})
+        m = GP_Plus(X, torch.tensor(y), qual_dict={10: 3}, multiple_noise=True, m_gp='multiple_constant', dtype=torch.float64, device="cuda")
+    m.train(); mll = ExactMarginalLogLikelihood(m.likelihood, m)
+    params = [p for p in m.parameters() if p.requires_grad]
+    def step():
+        for p in params: p.grad = None
+        loss = -mll(m(*m.train_inputs), m.train_targets); loss.backward(); return loss
+    for _ in range(10): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(100): step()
+    torch.cuda.synchronize(); print(name, "N=600: %.2f ms/step (host-bound)" % ((time.perf_counter() - t0) * 10))
+    pr = cProfile.Profile(); pr.enable()
+    for _ in range(100): step()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
