@@ -55,8 +55,6 @@ class EvalWorkspace:
         self.info = torch.zeros(1, dtype=torch.int32, device=dev)
         self.info_host = torch.zeros(1, dtype=torch.int32).pin_memory()
         self.info_event = torch.cuda.Event()
-        self.late_event = torch.cuda.Event()
-        self.late_pending = False
         self.epoch = 0
 
 
@@ -81,8 +79,8 @@ def eval_slot(slot: int):
 def current_slot() -> int:
     return getattr(_tls, "slot", 0)
 
-#: from this size on the host waits behind the LAUUM launch before forward returns (see _factor)
-LATE_SYNC_N = int(__import__("os").environ.get("GPP_LATE_SYNC_N", "12000"))
+#: smallest N for which gpp_potrf_ws (with scratch) runs its look-ahead driver on the internal streams (gpp_api.hip)
+LOOKAHEAD_MIN_N = 4096
 
 #: optional stage timing (bench.py): when this is a list, every stage appends (name, start_event, end_event) recorded
 #: on the stream the kernels are launched on (PyTorch's current stream).
@@ -132,30 +130,25 @@ def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_spl
     for jit in jitters:
         with _stage("kernel_build"):
             ctx.kernel_build(U, w, sf2, tau, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_UPPER)
-        if ws.late_pending:
-            # Do not park this factorisation's launches on the library's internal streams while the previous
-            # evaluation's O(N^3) stages still run: with them parked every stage of that evaluation measures slower
-            # (N = 20000: potrf 55.8 -> 59.3 ms, trtri 44.3 -> 44.9, lauum 40.3 -> 40.7; GPU_MAX_HW_QUEUES 4 / 8 / 16
-            # alike).  The Python between two evaluations has already run by now — it overlapped those stages.
-            ws.late_event.synchronize()
-            ws.late_pending = False
+        # The factorisation's launches (a DAG over the library's internal streams, ~1000 launches at N = 20000) run fastest
+        # when they are enqueued while the device executes them, and measurably slower when they were parked in the
+        # queues beforehand — N = 20000: potrf 55.7 ms when enqueued on an idle device, 58.0 when enqueued ~1 ms ahead
+        # (behind the previous evaluation's gradient reduction), 58.7-59.3 when enqueued a whole evaluation ahead, and
+        # the stages of the evaluation that is still running slow down as well (GPU_MAX_HW_QUEUES 4 / 8 / 16 alike; an
+        # idle pause alone changes nothing).  So the host waits HERE, for the covariance build just enqueued, which the
+        # factorisation needs anyway: the Python between two evaluations has overlapped the previous one's inverse
+        # stages by now and nothing is exposed.  bench.py at N = 20000 on one box: 151-153 ms per evaluation without
+        # this wait, 143-144 with it; C3 (N = 10000) 25.4-26.0 -> 24.3-24.8 ms.
+        if ws.N >= LOOKAHEAD_MIN_N:  # (below, the factorisation is a single-stream chain and the host is the bottleneck)
+            torch.cuda.current_stream().synchronize()
         with _stage("potrf"):
             ctx.potrf(ws.A, ws.Li, ws.info, ws.Ki)
-        # the one host wait of an evaluation (the reference syncs on loss.item() too) covers the factorisation only: the
+        # the second host wait of an evaluation (the reference syncs on loss.item() too) covers the factorisation only: the
         # status goes to pinned host memory behind an event, the rest of the evaluation is enqueued, THEN the host waits
         ws.info_host.copy_(ws.info, non_blocking=True)
         ws.info_event.record()
         if after is not None:
             after()
-        if ws.late_pending and ws.N >= LATE_SYNC_N:
-            # From this size on the wait happens HERE, before forward returns, so that the Python between two evaluations
-            # runs on an idle device (only the gradient reduction is still in flight): measured on one box, N = 20000,
-            # bench.py: 151-153 ms per evaluation with neither wait, 148.5 with the wait above, 143.9 with this one — the
-            # chip holds a higher clock after the ~1 ms pause than under unbroken load (clock under load).
-            # C4 (N = 15000, 2.5 ms of Python per step): 75.6-76.1 -> 69.9-71.7 ms; C3 (N = 10000): even (25.4-26.3 both) —
-            # the pause is worth 4-8 % of an evaluation and costs the Python between two of them, hence the threshold.
-            ws.late_event.synchronize()
-            ws.late_pending = False
         ws.info_event.synchronize()
         info = int(ws.info_host[0])
         if info == 0:
@@ -212,8 +205,6 @@ class ExactMLLFunction(torch.autograd.Function):
                 gctx.alpha(ws.Li, ws.z, ws.alpha)
             with _stage("lauum"):
                 gctx.lauum(ws.Li, ws.Ki)
-            ws.late_event.record()  # the next factorisation is enqueued behind this point (see _factor)
-            ws.late_pending = True
             with _stage("grad_reduce"):
                 gctx.grad_reduce(Ud, wd, sd, grp, S, ws.alpha, ws.Ki, dU if need_U else 0, g_w, g_s, g_t, g_Ud, kind=kind,
                                  d_split=d_split)

@@ -42,6 +42,8 @@ def main():
             if not nosync: torch.cuda.synchronize()
             evs.append((k, e0, e1))
         torch.cuda.synchronize()
+        pause = float(__import__("os").environ.get("STAGES_PAUSE_MS", "0"))
+        if pause > 0: time.sleep(pause * 1e-3)  # idle device between evaluations (clock recovery experiment)
         for k, e0, e1 in evs:
             if rep > 0: tot[k].append(e0.elapsed_time(e1))
         assert int(info.item()) == 0, info
