@@ -213,7 +213,7 @@ hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv
 // two streams therefore get DISJOINT CU sets through CU masks (see the comment at the mask below for what that costs).
 constexpr int PANEL_CUS_DEFAULT = 32;
 constexpr int64_t BORDER_MAX_N = 11264;  // largest N whose inverse is built by bordering inside the look-ahead
-constexpr int64_t BORDER_MIN_N = 4096;   // with bordering the look-ahead already wins from here (4.5 vs 4.8 ms per evaluation)
+constexpr int64_t BORDER_MIN_N = 3840;   // with bordering the look-ahead already wins from here (4.16 vs 4.32 ms per evaluation; 3712: 4.10 vs 4.03)
 hipError_t ensure_streams(gpp_handle_s* h) {
   if (h->cu_split < 0) {
     hipDeviceProp_t prop;
@@ -666,7 +666,12 @@ int gpp_lauum(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double
   if (int r = check_mat(Kinv, ldk, N, 5)) return r;
   GemmArgs g = mk(Linv, ldi, Linv, ldi, Kinv, ldk, N, N, N, 1.0, 0.0);
   g.a_mask = 2; g.b_mask = 2; g.klo_mode = 3; g.c_lower = 1; g.tag = 1;
-  GPP_TRY(gpp_launch_gemm(h->stream, 2, g, 1, NBLK, NBLK));
+  // one launch of long-K triangular tiles: small tiles balance it until there are several waves of big ones (measured:
+  // N = 1024 0.167 / 0.061 / 0.034 ms with 128 / 64 / 32-wide tiles, 2048 0.312 / 0.130 / 0.098, 3072 0.490 / 0.231 /
+  // 0.278, 4096 0.742 / 0.502 / 0.610, 6144 1.38 / 1.55 / 1.94)
+  static const int lt = getenv("GPP_LAUUM_TILE") ? atoi(getenv("GPP_LAUUM_TILE")) : 0;  // experiment knob (0: by size)
+  const int t = lt ? lt : (N <= 2560 ? 32 : N <= 5120 ? 64 : NBLK);
+  GPP_TRY(gpp_launch_gemm(h->stream, 2, g, 1, t, t));
   return 0;
 }
 

@@ -80,7 +80,7 @@ def current_slot() -> int:
     return getattr(_tls, "slot", 0)
 
 #: smallest N for which gpp_potrf_ws (with scratch) runs its look-ahead driver on the internal streams (gpp_api.hip)
-LOOKAHEAD_MIN_N = 4096
+LOOKAHEAD_MIN_N = 3840
 
 #: optional stage timing (bench.py): when this is a list, every stage appends (name, start_event, end_event) recorded
 #: on the stream the kernels are launched on (PyTorch's current stream).

@@ -94,7 +94,7 @@ int gpp_potrf(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, in
 /* Same, with an N x N scratch T (may be the Kinv buffer): for large N the look-ahead driver then also completes the
  * inverse of every diagonal block row it factors (hidden behind the trailing updates) and uses it to solve each wide
  * block-row panel with ONE GEMM; the following gpp_trtri on the same handle skips the merges that are already done.
- * For 4096 <= N <= 11264, where the factorisation is bound by its chain of diagonal blocks and most CUs would idle, it
+ * For 3840 <= N <= 11264, where the factorisation is bound by its chain of diagonal blocks and most CUs would idle, it
  * also builds the WHOLE inverse by bordering on a further internal stream while it factors (Linv is complete on return
  * and the following gpp_trtri launches nothing): 16.3 -> 14.0 ms per evaluation at N = 8192, 26.5 -> 23.6 at 10000. */
 int gpp_potrf_ws(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt,

@@ -120,8 +120,8 @@ def test_kernel_build_and_cross(gpu_ctx, n, d):
                                       (11500, True)])
 def test_potrf_trtri_lauum(gpu_ctx, n, use_ws):
     """use_ws: pass the scratch to the factorisation.  The drivers behind the same entry points: leaf steps on one stream
-    (n < 4096, or < 6144 without scratch); look-ahead on internal streams above, which with the scratch inverts its diagonal
-    block rows, solves panels with one GEMM and — for 4096 <= n <= 11264 — also builds the whole inverse by bordering, so
+    (n < 3840, or < 6144 without scratch); look-ahead on internal streams above, which with the scratch inverts its diagonal
+    block rows, solves panels with one GEMM and — for 3840 <= n <= 11264 — also builds the whole inverse by bordering, so
     trtri finds nothing left (6700, True); above that trtri skips only the merged levels (11500, True); without the scratch
     the panels are solved recursively and trtri does all the merging (6700, False)."""
     U, w, K = _spd(n, seed=n)
