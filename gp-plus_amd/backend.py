@@ -20,6 +20,13 @@ from ._lib import GppError, check
 KIND_RBF, KIND_MATERN32, KIND_MATERN52 = 0, 1, 2
 UPLO_FULL, UPLO_LOWER, UPLO_UPPER = 0, 1, 2
 OP_MLL_EVAL, OP_PREDICT = 0, 1
+#: the tile kernels stage at most this many feature columns (manifold + quantitative) per point in LDS (gpp_build.hip DMAX)
+MAX_FEATURES = 64
+
+
+def _check_features(D: int) -> None:
+    if D < 1 or D > MAX_FEATURES:
+        raise GppError(f"the covariance kernels take 1..{MAX_FEATURES} feature columns per point (got {D})")
 
 #: one context (library handle + stream binding + scratch) per (device, host thread): concurrent evaluations driven
 #: from different threads on different HIP streams never share a handle
@@ -52,6 +59,22 @@ def _ld(m: torch.Tensor) -> int:
     return m.stride(0) if m.shape[0] > 1 else max(m.shape[1], m.stride(0))
 
 
+def _on_own_device(fn):
+    """Run a GppContext operator with the context's GPU as the CURRENT device.  The library enqueues on the stream it is
+    handed; PyTorch's default stream is the null handle, which HIP resolves against the calling thread's current device —
+    so a model on cuda:1 driven while cuda:0 is current would launch on the wrong GPU with cuda:1 pointers."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        if torch.cuda.current_device() == self.index:
+            return fn(self, *args, **kwargs)
+        with torch.cuda.device(self.index):
+            return fn(self, *args, **kwargs)
+
+    return wrapper
+
+
 class GppContext:
     def __init__(self, device: torch.device):
         if device.type != "cuda":
@@ -72,6 +95,7 @@ class GppContext:
         s = torch.cuda.current_stream(self.index).cuda_stream
         check(self.lib.gpp_set_stream(self.h, ctypes.c_void_p(s)), "gpp_set_stream")
 
+    @_on_own_device
     def internal_streams(self):
         """(latency stream, throughput stream): the handle's CU-masked internal streams as torch streams."""
         if getattr(self, "_istreams", None) is None:
@@ -83,32 +107,50 @@ class GppContext:
             self._istreams = tuple(out)
         return self._istreams
 
+    @_on_own_device
     def ensure_workspace(self, op: int, N: int, M: int, D: int, S: int) -> None:
         need = int(self.lib.gpp_workspace_bytes(self.h, op, N, M, D, S))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             check(self.lib.gpp_set_workspace(self.h, self._ws.data_ptr(), self._ws.numel()), "gpp_set_workspace")
 
+    def _check_groups(self, grp: torch.Tensor, N: int, S: int) -> None:
+        """The kernels index tau[grp[i]] / g_tau[grp[i]] unchecked: the length is verified on every call, the value range
+        once per index tensor (it costs a device read, i.e. a host sync)."""
+        _need(grp, torch.int32, "grp")
+        if grp.numel() != N:
+            raise GppError(f"noise-group index has {grp.numel()} entries for {N} points (stale fidel_indices?)")
+        key = (grp.data_ptr(), grp._version, N, S)
+        if getattr(self, "_grp_ok", None) != key:
+            lo, hi = int(grp.min()), int(grp.max())
+            if lo < 0 or hi >= max(S, 1):
+                raise GppError(f"noise-group index out of range: values in [{lo}, {hi}] for {S} noise levels")
+            self._grp_ok = key
+
     # -- operators -------------------------------------------------------------------------------
+    @_on_own_device
     def kernel_build(self, U, w, sf2, tau, grp, out, *, jitter=0.0, kind=KIND_RBF, d_split=0, uplo=UPLO_FULL,
                      row0=0, nrows=None):
         N, D = U.shape
+        _check_features(D)
         for t, n in ((U, "U"), (w, "w"), (sf2, "sf2"), (out, "Ky")):
             _need(t, torch.float64, n)
         if tau is not None:
             _need(tau, torch.float64, "tau")
+        S = 0 if tau is None else tau.numel()
         if grp is not None:
-            _need(grp, torch.int32, "grp")
+            self._check_groups(grp, N, S)
         if not U.is_contiguous():
             raise GppError("U must be contiguous")
-        S = 0 if tau is None else tau.numel()
         self._stream()
         check(self.lib.gpp_kernel_build(self.h, U.data_ptr(), N, D, w.data_ptr(), sf2.data_ptr(), _ptr(tau), _ptr(grp), S,
                                         float(jitter), kind, d_split, uplo, out.data_ptr(), _ld(out), row0,
                                         N - row0 if nrows is None else nrows), "gpp_kernel_build")
         return out
 
+    @_on_own_device
     def cross_kernel(self, Ua, Ub, w, sf2, out, *, kind=KIND_RBF, d_split=0):
+        _check_features(Ua.shape[1])
         for t, n in ((Ua, "Ua"), (Ub, "Ub"), (w, "w"), (sf2, "sf2"), (out, "Kab")):
             _need(t, torch.float64, n)
         if not (Ua.is_contiguous() and Ub.is_contiguous()):
@@ -119,6 +161,7 @@ class GppContext:
               "gpp_cross_kernel")
         return out
 
+    @_on_own_device
     def potrf(self, A, Linv, info, T=None):
         _need(A, torch.float64, "A"); _need(Linv, torch.float64, "Linv"); _need(info, torch.int32, "info")
         self._stream()
@@ -129,27 +172,32 @@ class GppContext:
             check(self.lib.gpp_potrf_ws(self.h, A.data_ptr(), A.shape[0], _ld(A), Linv.data_ptr(), _ld(Linv), T.data_ptr(),
                                         _ld(T), info.data_ptr()), "gpp_potrf_ws")
 
+    @_on_own_device
     def trtri(self, U, Linv, T):
         self._stream()
         check(self.lib.gpp_trtri(self.h, U.data_ptr(), U.shape[0], _ld(U), Linv.data_ptr(), _ld(Linv), T.data_ptr(), _ld(T)),
               "gpp_trtri")
 
+    @_on_own_device
     def lauum(self, Linv, Kinv):
         self._stream()
         check(self.lib.gpp_lauum(self.h, Linv.data_ptr(), Linv.shape[0], _ld(Linv), Kinv.data_ptr(), _ld(Kinv)), "gpp_lauum")
 
+    @_on_own_device
     def syrk_rows(self, Urow, C, nb, first_block, rank, nranks):
         """C(upper) -= Urow^T Urow on the block rows (height nb) of C this rank owns (block-cyclic), one launch."""
         self._stream()
         check(self.lib.gpp_syrk_rows(self.h, Urow.data_ptr(), _ld(Urow), C.data_ptr(), _ld(C), C.shape[0], Urow.shape[0], nb,
                                      first_block, rank, nranks), "gpp_syrk_rows")
 
+    @_on_own_device
     def lauum_rows(self, Linv, Kinv, rank, nranks):
         """This rank's cyclic share (128-row tile rows) of Kinv = Linv^T Linv, one launch."""
         self._stream()
         check(self.lib.gpp_lauum_rows(self.h, Linv.data_ptr(), Linv.shape[0], _ld(Linv), Kinv.data_ptr(), _ld(Kinv), rank, nranks),
               "gpp_lauum_rows")
 
+    @_on_own_device
     def mll_reduce(self, L, Linv, r, z, out3):
         for t, n in ((r, "r"), (z, "z"), (out3, "out3")):
             _need(t, torch.float64, n)
@@ -157,23 +205,30 @@ class GppContext:
         check(self.lib.gpp_mll_reduce(self.h, L.data_ptr(), _ld(L), Linv.data_ptr(), _ld(Linv), L.shape[0], r.data_ptr(),
                                       z.data_ptr(), out3.data_ptr()), "gpp_mll_reduce")
 
+    @_on_own_device
     def alpha(self, Linv, z, alpha):
         N = Linv.shape[0]
         self._stream()
         check(self.lib.gpp_alpha(self.h, Linv.data_ptr(), _ld(Linv), N, z.data_ptr(), alpha.data_ptr()), "gpp_alpha")
 
+    @_on_own_device
     def grad_reduce(self, U, w, sf2, grp, S, alpha, Kinv, dU, g_w, g_sf2, g_tau, g_U, *, kind=KIND_RBF, d_split=0):
         N, D = U.shape
+        if grp is not None:
+            self._check_groups(grp, N, S)
         self.ensure_workspace(OP_MLL_EVAL, N, 0, D, S)
         self._stream()
         check(self.lib.gpp_grad_reduce(self.h, U.data_ptr(), N, D, w.data_ptr(), sf2.data_ptr(), _ptr(grp), S, kind,
                                        d_split, alpha.data_ptr(), Kinv.data_ptr(), _ld(Kinv), dU, g_w.data_ptr(),
                                        g_sf2.data_ptr(), g_tau.data_ptr(), _ptr(g_U)), "gpp_grad_reduce")
 
+    @_on_own_device
     def grad_reduce_rows(self, U, w, sf2, grp, S, alpha, Kinv, dU, nb, rank, nranks, g_w, g_sf2, g_tau, g_U, *,
                          kind=KIND_RBF, d_split=0):
         """Partial sums over the block rows of Kinv owned by ``rank`` (block-cyclic, block height ``nb``)."""
         N, D = U.shape
+        if grp is not None:
+            self._check_groups(grp, N, S)
         self.ensure_workspace(OP_MLL_EVAL, N, 0, D, S)
         self._stream()
         check(self.lib.gpp_grad_reduce_rows(self.h, U.data_ptr(), N, D, w.data_ptr(), sf2.data_ptr(), _ptr(grp), S, kind,
@@ -181,18 +236,21 @@ class GppContext:
                                             g_w.data_ptr(), g_sf2.data_ptr(), g_tau.data_ptr(), _ptr(g_U)),
               "gpp_grad_reduce_rows")
 
+    @_on_own_device
     def predict(self, Linv, alpha, Ksn, kss, V, mean_out, var_out):
         self._stream()
         check(self.lib.gpp_predict(self.h, Linv.data_ptr(), _ld(Linv), Linv.shape[0], alpha.data_ptr(), Ksn.data_ptr(),
                                    _ld(Ksn), Ksn.shape[0], _ptr(kss), _ptr(V), 0 if V is None else _ld(V),
                                    mean_out.data_ptr(), _ptr(var_out)), "gpp_predict")
 
+    @_on_own_device
     def gemm(self, transA, transB, M, N, K, alpha, A, B, beta, C, *, a_mask=0, b_mask=0, klo_mode=0, khi_mode=0,
              c_tri=0):
         self._stream()
         check(self.lib.gpp_gemm(self.h, transA, transB, M, N, K, float(alpha), A.data_ptr(), _ld(A), B.data_ptr(), _ld(B),
                                 float(beta), C.data_ptr(), _ld(C), a_mask, b_mask, klo_mode, khi_mode, c_tri), "gpp_gemm")
 
+    @_on_own_device
     def gemm_batched(self, transA, transB, M, N, K, alpha, A, sA, B, sB, beta, C, sC, batch, *, a_mask=0, b_mask=0,
                      klo_mode=0, khi_mode=0, c_tri=0):
         """``batch`` products of one shape; A/B/C are the first elements' views, sA/sB/sC element strides between them."""
@@ -211,12 +269,14 @@ class GppContext:
     def batched_vector(self, B: int, n: int) -> torch.Tensor:
         return torch.empty((B, n + (n & 1)), dtype=torch.float64, device=self.device)[:, :n]
 
+    @_on_own_device
     def ensure_workspace_batched(self, B, N, D, S):
         need = B * int(self.lib.gpp_workspace_bytes(self.h, OP_MLL_EVAL, N, 0, D, S))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
             check(self.lib.gpp_set_workspace(self.h, self._ws.data_ptr(), self._ws.numel()), "gpp_set_workspace")
 
+    @_on_own_device
     def kernel_build_batched(self, U, w, sf2, tau, grp, out, *, jitter=0.0, kind=KIND_RBF, d_split=0, uplo=UPLO_FULL):
         """U: (N, D) shared or (B, N, D); w: (B, D); sf2: (B,); tau: (B, S) or None; out: (B, N, ld) view."""
         B, N = out.shape[0], out.shape[1]
@@ -228,22 +288,26 @@ class GppContext:
                                                 _ptr(grp), S, float(jitter), kind, d_split, uplo, out.data_ptr(), out.stride(1),
                                                 out.stride(0), B), "gpp_kernel_build_batched")
 
+    @_on_own_device
     def potrf_batched(self, A, Linv, info):
         self._stream()
         check(self.lib.gpp_potrf_batched(self.h, A.data_ptr(), A.shape[1], A.stride(1), A.stride(0), Linv.data_ptr(),
                                          Linv.stride(1), Linv.stride(0), info.data_ptr(), A.shape[0]), "gpp_potrf_batched")
 
+    @_on_own_device
     def trtri_batched(self, U, Linv, T):
         self._stream()
         check(self.lib.gpp_trtri_batched(self.h, U.data_ptr(), U.shape[1], U.stride(1), U.stride(0), Linv.data_ptr(),
                                          Linv.stride(1), Linv.stride(0), T.data_ptr(), T.stride(1), T.stride(0), U.shape[0]),
               "gpp_trtri_batched")
 
+    @_on_own_device
     def lauum_batched(self, Linv, Kinv):
         self._stream()
         check(self.lib.gpp_lauum_batched(self.h, Linv.data_ptr(), Linv.shape[1], Linv.stride(1), Linv.stride(0), Kinv.data_ptr(),
                                          Kinv.stride(1), Kinv.stride(0), Linv.shape[0]), "gpp_lauum_batched")
 
+    @_on_own_device
     def mll_reduce_batched(self, L, Linv, r, z, out3):
         self._stream()
         check(self.lib.gpp_mll_reduce_batched(self.h, L.data_ptr(), L.stride(1), L.stride(0), Linv.data_ptr(), Linv.stride(1),
@@ -257,11 +321,13 @@ class GppContext:
             raise GppError("batched vectors must share one even row stride (use GppContext.batched_vector)")
         return sv
 
+    @_on_own_device
     def alpha_batched(self, Linv, z, alpha):
         self._stream()
         check(self.lib.gpp_alpha_batched(self.h, Linv.data_ptr(), Linv.stride(1), Linv.stride(0), Linv.shape[1], z.data_ptr(),
                                          alpha.data_ptr(), self._sv(z, alpha), Linv.shape[0]), "gpp_alpha_batched")
 
+    @_on_own_device
     def grad_reduce_batched(self, U, w, sf2, grp, S, alpha, Kinv, dU, g_w, g_sf2, g_tau, g_U, *, kind=KIND_RBF, d_split=0):
         B, N = Kinv.shape[0], Kinv.shape[1]
         D = w.shape[1]

@@ -9,6 +9,7 @@ LazyEvaluatedKernelTensor); nothing N x N exists until ``evaluate()`` or ``log_p
 """
 from __future__ import annotations
 
+import threading
 from typing import List, Optional
 
 import torch
@@ -16,6 +17,16 @@ import torch
 from ..backend import KIND_MATERN32, KIND_MATERN52, KIND_RBF
 from ..linalg import KernelSpec, cross_kernel, dense_kernel
 from .module import Interval, Module, Positive
+
+
+#: what the reference's ``forward(x1, x2, diag, **params)`` can see of its call and the weight protocol cannot: whether an
+#: input requires grad / diag was asked (kernels/Rough_RBF.py:19-26 switches formula on it).  Set by ``Kernel.__call__``
+#: around ``spec()`` for the calling host thread.
+_call = threading.local()
+
+
+def call_needs_branch1() -> bool:
+    return getattr(_call, "branch1", False)
 
 
 class LazyKernelMatrix:
@@ -167,7 +178,13 @@ class Kernel(Module):
             x1 = x1.unsqueeze(-1)
         if x2 is not None and x2.dim() == 1:
             x2 = x2.unsqueeze(-1)
-        lazy = LazyKernelMatrix(x1, x2, self.spec(x1.shape[-1], x1.device))
+        prev = getattr(_call, "branch1", False)
+        _call.branch1 = bool(x1.requires_grad or (x2 is not None and x2.requires_grad) or diag
+                             or params.get("last_dim_is_batch", False))
+        try:
+            lazy = LazyKernelMatrix(x1, x2, self.spec(x1.shape[-1], x1.device))
+        finally:
+            _call.branch1 = prev
         return lazy.diag() if diag else lazy
 
     def __mul__(self, other):

@@ -50,7 +50,18 @@ class ExactGP(GP):
                 cov = train_out.lazy_covariance_matrix
                 if not isinstance(cov, LazyKernelMatrix):
                     raise RuntimeError("exact prediction needs the model's forward to return a lazy kernel covariance")
-                noisy = self.likelihood(train_out).lazy_covariance_matrix
+                # The training covariance takes its noise groups from the TRAINING inputs' source column, whatever a
+                # previous predict()/evaluation() left in likelihood.fidel_indices (models/gpregression.py:136-139
+                # overwrites it with the test points' sources): set it around the call and put the caller's value back.
+                lik = self.likelihood
+                swap = hasattr(lik, "fidel_indices")
+                if swap:
+                    saved, lik.fidel_indices = lik.fidel_indices, self.train_inputs[0][:, -1]
+                try:
+                    noisy = lik(train_out).lazy_covariance_matrix
+                finally:
+                    if swap:
+                        lik.fidel_indices = saved
                 self.prediction_strategy = factorize(cov.U1, cov.spec, noisy.tau, noisy.grp, train_out.mean, self.train_targets)
         return self.prediction_strategy
 

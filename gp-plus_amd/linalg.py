@@ -140,13 +140,13 @@ def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_spl
         # stages by now and nothing is exposed.  bench.py at N = 20000 on one box: 151-153 ms per evaluation without
         # this wait, 143-144 with it; C3 (N = 10000) 25.4-26.0 -> 24.3-24.8 ms.
         if ws.N >= LOOKAHEAD_MIN_N:  # (below, the factorisation is a single-stream chain and the host is the bottleneck)
-            torch.cuda.current_stream().synchronize()
+            torch.cuda.current_stream(ctx.index).synchronize()
         with _stage("potrf"):
             ctx.potrf(ws.A, ws.Li, ws.info, ws.Ki)
         # the second host wait of an evaluation (the reference syncs on loss.item() too) covers the factorisation only: the
         # status goes to pinned host memory behind an event, the rest of the evaluation is enqueued, THEN the host waits
         ws.info_host.copy_(ws.info, non_blocking=True)
-        ws.info_event.record()
+        ws.info_event.record(torch.cuda.current_stream(ctx.index))
         if after is not None:
             after()
         ws.info_event.synchronize()
@@ -173,6 +173,12 @@ class ExactMLLFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, U, w, sf2, tau, mean, y, grp, kind, d_split, dU, slot):
+        get_context(U.device)  # raises GppError for anything but a GPU: there is no CPU path
+        with torch.cuda.device(U.device):  # streams, events and the library's launches all refer to the model's GPU
+            return ExactMLLFunction._forward(ctx, U, w, sf2, tau, mean, y, grp, kind, d_split, dU, slot)
+
+    @staticmethod
+    def _forward(ctx, U, w, sf2, tau, mean, y, grp, kind, d_split, dU, slot):
         dev = U.device
         gctx = get_context(dev)
         N, D = U.shape
@@ -297,6 +303,12 @@ class FactorCache:
 
 @torch.no_grad()
 def factorize(U, spec: KernelSpec, tau, grp, mean, y) -> FactorCache:
+    get_context(U.device)
+    with torch.cuda.device(U.device):
+        return _factorize(U, spec, tau, grp, mean, y)
+
+
+def _factorize(U, spec: KernelSpec, tau, grp, mean, y) -> FactorCache:
     dev = U.device
     gctx = get_context(dev)
     N = U.shape[0]

@@ -30,7 +30,7 @@ from ..priors import MollifiedUniformPrior
 from ..utils import data_type_check, set_seed  # noqa: F401
 from .gpregression import GPR
 
-_QUANT_CLASSES = ['Rough_RBF', 'RBFKernel', 'Matern32Kernel', 'Matern12Kernel', 'Matern52Kernel']
+_QUANT_CLASSES = ['Rough_RBF', 'RBFKernel', 'Matern32Kernel', 'Matern12Kernel', 'Matern52Kernel']  # gp_plus.py:150
 
 
 def _rough_transform(x):
@@ -101,6 +101,10 @@ class GP_Plus(GPR):
         if not isinstance(calibration_id, list) or not all(isinstance(i, int) for i in calibration_id):
             raise ValueError("calibration_id should be a list where each entry shows the column number in the dataset that the calibration parameters are assigned to.")
         # scope of this build
+        if quant_correlation_class == 'Matern12Kernel':
+            # passes the reference's validation (gp_plus.py:150) and then fails at gp_plus.py:236-241, because
+            # kernels/matern.py:4-8 defines Matern32Kernel and Matern52Kernel only: same error, raised before any work
+            raise RuntimeError("%s not an allowed kernel" % quant_correlation_class)
         if embedding_type == 'probabilistic' or calibration_type in ('probabilistic', 'probabelistic'):
             raise NotImplementedError("probabilistic embedding/calibration (stochastic multi-pass ensembles, "
                                       "gp_plus.py:387-392,414-461) is outside the exact-GP hot path of this build")
@@ -358,9 +362,10 @@ class GP_Plus(GPR):
         Xtest = Xtest.to(dev)
         ytest_sc = (ytest - self.y_min) / self.y_std
         with torch.no_grad():
+            f_dist = self(Xtest)  # factors the training covariance with the TRAINING noise groups if not cached yet
             if hasattr(self.likelihood, 'fidel_indices'):
-                self.likelihood.fidel_indices = Xtest[:, -1]
-            trained_pred_dist = self.likelihood(self(Xtest))
+                self.likelihood.fidel_indices = Xtest[:, -1]  # the test points' own sources, as GPR.predict does
+            trained_pred_dist = self.likelihood(f_dist)
             final_nlpd = gpmetrics.negative_log_predictive_density(trained_pred_dist, ytest_sc.to(torch.float64))
             final_mse = gpmetrics.mean_squared_error(trained_pred_dist, ytest_sc, squared=True)
             final_mae = gpmetrics.mean_absolute_error(trained_pred_dist, ytest_sc)

@@ -26,7 +26,10 @@ from ..batched import batched_mll
 from ..gpcore.kernels import LazyKernelMatrix
 from ..gpcore.mlls import ExactMarginalLogLikelihood
 
-__all__ = ["BatchedObjective", "fit_model_torch_batched"]
+__all__ = ["BatchedObjective", "fit_model_torch_batched", "BATCHED_MAX_N"]
+
+#: largest N the batched kernels take (gpp_api.hip: blocks up to GPP_BLK_MAX = 6144 rows are factored in leaf steps)
+BATCHED_MAX_N = 6144
 
 
 class BatchedObjective:
@@ -118,13 +121,18 @@ def fit_model_torch_batched(model, lr_default: float = 0.01, num_iter: int = 100
                             break_steps: int = 50, verbose: bool = False) -> Tuple[float, List[List[float]]]:
     """Drop-in for ``fit_model_torch`` (same return value) that advances all restarts together."""
     B = num_restarts + 1
+    N = int(model.train_targets.shape[0])
+    if N > BATCHED_MAX_N:
+        # gpp_potrf_batched factors each problem right-looking in leaf steps and rejects larger matrices; at these sizes
+        # one evaluation fills the GPU by itself, so the sequential driver loses nothing
+        from .mll_torch import fit_model_torch
+        return fit_model_torch(model, None, lr_default, num_iter, num_restarts, break_steps, verbose=verbose)
     obj = BatchedObjective(model, B)
     obj.sample_restarts()
     params = list(obj.theta.values())
     opt = torch.optim.Adam(params, lr=lr_default)
     dev = params[0].device
     active = torch.ones(B, dtype=torch.bool, device=dev)
-    any_frozen = False
     H = torch.full((num_iter, B), math.nan, dtype=torch.float64, device=dev)  # loss histories stay on the GPU
     last = torch.full((B,), math.inf, dtype=torch.float64, device=dev)
     done_at = num_iter
@@ -132,13 +140,14 @@ def fit_model_torch_batched(model, lr_default: float = 0.01, num_iter: int = 100
         opt.zero_grad(set_to_none=True)
         loss = obj.loss()
         torch.nansum(torch.where(active, loss, torch.zeros_like(loss))).backward()
-        before = [p.detach().clone() for p in params] if any_frozen else None
+        before = [p.detach().clone() for p in params]
         opt.step()
         with torch.no_grad():
-            if any_frozen:  # a stopped run keeps the parameters it stopped with
-                frozen = ~active
-                for p, old in zip(params, before):
-                    p[frozen] = old[frozen]
+            # a stopped run keeps the parameters it stopped with; a run whose covariance was not positive definite (NaN
+            # loss, zero gradient through nansum) does not move on Adam's momentum either
+            frozen = ~active | ~torch.isfinite(loss.detach())
+            for p, old in zip(params, before):
+                p.copy_(torch.where(frozen.reshape(-1, *([1] * (p.dim() - 1))), old, p))
             lv = loss.detach()
             lv = torch.where(torch.isfinite(lv), lv, torch.full_like(lv, math.inf))
             H[j] = torch.where(active, lv, torch.full_like(lv, math.nan))
@@ -153,7 +162,6 @@ def fit_model_torch_batched(model, lr_default: float = 0.01, num_iter: int = 100
                           for b_ in range(B)]
                 stop = active & torch.tensor(stop_l, device=dev)
                 active = active & ~stop
-                any_frozen = bool((~active).any())  # (the only host sync of the loop, every break_steps iterations)
                 if verbose:
                     print(f"iter {j}: best loss {float(last.min()):.4f}, {int(active.sum())} of {B} runs active")
                 if not bool(active.any()):

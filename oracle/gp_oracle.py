@@ -131,12 +131,19 @@ def matern_gpytorch(x1: torch.Tensor, x2: torch.Tensor, lengthscale: torch.Tenso
     return constant_component * exp_component
 
 
-def rough_rbf_standalone(x1: torch.Tensor, x2: torch.Tensor, lengthscale: torch.Tensor) -> torch.Tensor:
-    """kernels/Rough_RBF.py:6-7,27-32 (grad/ARD branch): inputs scaled by sqrt(l), squared distance, and the file's
-    OWN postprocess_rbf = div_(-1).exp_()  =>  exp(-sum_d l_d (x1_d-x2_d)^2)."""
-    s = lengthscale.sqrt()
+def rough_rbf_standalone(x1: torch.Tensor, x2: torch.Tensor, lengthscale: torch.Tensor, ard_num_dims: Optional[int] = None,
+                         diag: bool = False) -> torch.Tensor:
+    """kernels/Rough_RBF.py:18-40, both branches.
+    Branch 1 (:19-32; taken when an input requires grad, ard_num_dims > 1, or diag): inputs scaled by sqrt(l), squared
+    distance, and the file's OWN postprocess_rbf (:6-7) = div_(-1).exp_()  =>  exp(-sum_d l_d (x1_d-x2_d)^2).
+    Branch 2 (:33-40): [3P] gpytorch RBFCovariance.apply(x1, x2, l, sq_dist)  =>  exp(-0.5 ||(x1-x2)/l||^2) (the
+    ``postprocess=False`` distance, then RBFCovariance's own div_(-2).exp_())."""
     eq = x1.shape == x2.shape and torch.equal(x1, x2)
-    return sq_dist_gpytorch(x1 * s, x2 * s, eq).div(-1).exp()
+    if x1.requires_grad or x2.requires_grad or (ard_num_dims is not None and ard_num_dims > 1) or diag:
+        s = lengthscale.sqrt()
+        K = sq_dist_gpytorch(x1 * s, x2 * s, eq).div(-1).exp()
+        return torch.diagonal(K) if diag else K
+    return sq_dist_gpytorch(x1 / lengthscale, x2 / lengthscale, eq).div(-2).exp()
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -205,7 +212,7 @@ class OracleGP:
     def __init__(self, train_x, train_y, qual_dict: Optional[dict] = None, multiple_noise: bool = False,
                  lb_noise: float = 1e-8, fix_noise: bool = False, fix_noise_val: float = 1e-5,
                  quant_correlation_class: str = "Rough_RBF", embedding_dim: int = 2, m_gp: str = "single_constant",
-                 m_gp_ref: str = "zero", seed: int = 0):
+                 m_gp_ref: str = "zero", seed: int = 0, ard_num_dims="all", fixed_weights=None):
         qual_dict = dict(qual_dict or {})
         self.train_x = torch.as_tensor(train_x, dtype=DT).clone()
         train_y = torch.as_tensor(train_y, dtype=DT).reshape(-1)
@@ -234,6 +241,11 @@ class OracleGP:
             P["likelihood.noise_covar.raw_noise"] = torch.log(torch.full((S,), fix_noise_val - lb_noise, dtype=DT))
         P["covar_module.raw_outputscale"] = torch.zeros((), dtype=DT)
         dq = len(self.quant_index)
+        self.ard_num_dims = self.train_x.shape[1] if ard_num_dims == "all" else ard_num_dims
+        self.fixed_weights = torch.zeros(1, dq, dtype=DT) if fixed_weights is None else \
+            torch.as_tensor(fixed_weights, dtype=DT).reshape(1, -1)
+        if quant_correlation_class.startswith("GPR:") and self.ard_num_dims in (None, 1):
+            dq = 1  # gpytorch: raw_lengthscale has shape (1, 1) without ARD
         if dq > 0:
             key = "covar_module.base_kernel.kernels.1.raw_lengthscale" if self.qual_cols else \
                 "covar_module.base_kernel.raw_lengthscale"
@@ -295,6 +307,8 @@ class OracleGP:
     def lengthscale(self, p=None):
         p = self.params if p is None else p
         raw = p[self.ls_key]
+        if self.kclass in ("GPR:Rough_RBF", "GPR:wighted_RBF"):
+            return exp_lengthscale(raw)  # models/gpregression.py:93-95: Positive(transform=exp) for a kernel given by name
         # gp_plus.py:243-272: only 'RBFKernel' uses exp; Rough_RBF and the Matern classes share the 10^(-x/2) transform
         return exp_lengthscale(raw) if self.kclass == "RBFKernel" else rough_lengthscale(raw)
 
@@ -304,6 +318,15 @@ class OracleGP:
         K = None
         if self.qual_cols:
             K = rbf_gpytorch(U1[:, : self.dz], U2[:, : self.dz], torch.ones(1, self.dz, dtype=DT))  # gp_plus.py:223-226
+        if self.kclass == "GPR:Rough_RBF":
+            # models/gpregression.py:89-102: kernels.Rough_RBF(ard_num_dims = all input columns), no active_dims
+            K = rough_rbf_standalone(U1, U2, self.lengthscale(p), ard_num_dims=self.ard_num_dims)
+            return softplus(p["covar_module.raw_outputscale"]) * K
+        if self.kclass == "GPR:wighted_RBF":
+            # the product's kernels.wighted_RBF (documented deviation from the reference's unfinished stub,
+            # kernels/wighted_RBF.py:31-41): exp(-sum_d (fixed_d + l_d) dx_d^2), ARD branch of Rough_RBF with shifted weights
+            K = rough_rbf_standalone(U1, U2, self.lengthscale(p) + self.fixed_weights, ard_num_dims=max(2, self.ard_num_dims))
+            return softplus(p["covar_module.raw_outputscale"]) * K
         if self.ls_key is not None:
             if self.kclass in ("Matern32Kernel", "Matern52Kernel"):
                 Kq = matern_gpytorch(U1[:, self.dz:], U2[:, self.dz:], self.lengthscale(p),
@@ -342,7 +365,7 @@ class OracleGP:
         tot = log_half_horseshoe_log_prob(p["likelihood.noise_covar.raw_noise"], 0.01, self.lb_noise).sum()  # gpregression.py:84
         tot = tot + lognormal_log_prob(softplus(p["covar_module.raw_outputscale"]), 1e-6, 1.0)  # gpregression.py:113-115
         if self.ls_key is not None:
-            if self.kclass == "RBFKernel":
+            if self.kclass in ("RBFKernel", "GPR:Rough_RBF", "GPR:wighted_RBF"):  # gpregression.py:96-98 for the GPR:* classes
                 tot = tot + mollified_uniform_log_prob(p[self.ls_key], math.log(0.1), math.log(10)).sum()  # gp_plus.py:274-277
             else:
                 tot = tot + normal_log_prob(p[self.ls_key], -3.0, 3.0).sum()  # gp_plus.py:279-295 (Rough_RBF, Matern*)
@@ -377,6 +400,26 @@ class OracleGP:
         names = [k for k in self.trainable]
         grads = torch.autograd.grad(loss, [p[k] for k in names])
         return loss.detach(), {k: g for k, g in zip(names, grads)}
+
+    def fit_adam(self, num_iter: int = 100, lr: float = 0.01, break_steps: int = 50):
+        """One run of optim/mll_torch.py:99-137 (no restarts): torch.optim.Adam(lr) over the trainable raw parameters,
+        ``loss = -mll(output, y); loss.backward(); optimizer.step()``, ``loss.item()`` appended per iteration, the early
+        stop of :126-128 on the float32 mean of the previous window.  Leaves the final parameters in ``self.params``
+        and returns the loss history."""
+        p = {k: v.clone().requires_grad_(k in self.trainable) for k, v in self.params.items()}
+        opt = torch.optim.Adam([p[k] for k in self.trainable], lr=lr)
+        hist = []
+        for j in range(num_iter):
+            opt.zero_grad()
+            loss = self.loss(p)
+            loss.backward()
+            opt.step()
+            hist.append(loss.item())
+            if j > break_steps and j % break_steps == 0:
+                if (torch.mean(torch.Tensor(hist)[j - break_steps:j]) - hist[j]) <= 0:
+                    break
+        self.params = {k: v.detach().clone() for k, v in p.items()}
+        return hist
 
     # ---- prediction --------------------------------------------------------------------------------
     @torch.no_grad()
