@@ -6,21 +6,28 @@ A *step* is one evaluation of ``optim/mll_torch.py:112-117`` without ``optimizer
 on BASELINE.json's config C2: synthetic Borehole, N = 20 000, d = 8, fp64, Rough_RBF exact GP at
 theta1 = (omega = -1, raw_outputscale = 0.3, raw_noise = -6, mean constant = 0.4), inputs resident in HBM.
 
-Multi-GPU (``--gpus N``, launched by torch.distributed.run, one rank per GPU): every rank runs its own replica of the
-workload — the restart-parallel mode of the reference's multistart fit (optim/mll_scipy.py:287-293) — with no
-data-path collective; the timed region is bracketed by barrier + synchronize and the MAX over ranks is reported
-(``scaling: weak``).
+``python bench.py --gpus N``: with N > 1 and no torch.distributed environment the process starts N ranks of itself
+(``python -m torch.distributed.run --nproc-per-node N``, one rank per GPU over RCCL) BEFORE it touches a GPU, relays rank
+0's JSON line and exits with the launcher's status; started under torch.distributed.run it is a rank.  Two legs:
+  * replicas (the headline ``value``): every rank evaluates its own copy of C2 — the restart-parallel mode of the
+    reference's multistart fit (optim/mll_scipy.py:287-293), no data-path collective, ``scaling: weak``;
+  * ``sharded`` (N > 1 only, second object of the same JSON line): ALL ranks evaluate ONE C5 problem (N = 60 000, d = 16)
+    cooperatively (gp-plus_amd/sharded.py: block-cyclic rows, RCCL broadcasts of factor / inverse slabs), strong scaling.
+Every timed region is bracketed by barrier + synchronize and the MAX over ranks is reported.
 
 The JSON line also carries
-  roofline      the dominant MFMA kernel (the lower-triangular TN launch of the fp64 GEMM that forms Ky^-1 = Linv^T Linv,
-                N^3/3 flop in ONE launch) timed with HIP events on its own stream inside the timed region;
+  roofline      the O(N^3) stage furthest from the fp64 MFMA peak (the factorisation), timed with HIP events on the stream
+                the library is driven from; ``entries`` lists all three O(N^3) stages (potrf, trtri, and the single LAUUM
+                launch gpp_gemm_f64<2,64,64,1,16,2>) and the whole evaluation;
   stages        per-stage mean milliseconds and rates from the same events;
-  cpu_baseline  the CPU oracle (oracle/gp_oracle.py, plain PyTorch fp64) on this box's host cores, on a bounded sample
-                (smaller N, scaled by N^3), rank 0 and N=1 only.
+  cpu_baseline  the CPU oracle (oracle/gp_oracle.py, plain PyTorch fp64) on this box's host cores at the SAME N = 20 000
+                workload (rank 0, N = 1 only; see ``cpu_baseline``).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -38,12 +45,10 @@ THETA1 = dict(omega=-1.0, raw_os=0.3, raw_noise=-6.0, const=0.4)
 def make_c2_data(n=N_C2):
     """Sobol(d=8, seed=0) points scaled to the Borehole bounds, no shuffle (unique rows),
     z-scored with the population std, y = Borehole."""
-    from gpplus_amd.preprocessing import standard
-    from gpplus_amd.test_functions.analytical import borehole
+    from gpplus_amd.test_functions.baseline_configs import make_config
 
-    X, y = borehole(n=n, random_state=0, shuffle=False)
-    Xs, _, _ = standard(torch.tensor(X), {})
-    return Xs.double(), torch.tensor(y).double()
+    X, y, _, _ = make_config("C2", n)
+    return X, y
 
 
 def set_theta1(model):
@@ -54,17 +59,47 @@ def set_theta1(model):
         model.mean_module.constant.fill_(THETA1["const"])
 
 
-def cpu_baseline(budget_s=30.0):
-    """Oracle loss+grad (= optim/mll_torch.py:114-117 on the CPU oracle) on this box's host cores.  Bounded sample: one
-    untimed warm-up, then N = 2048, 4096, 8192 while the N^3 projection of the next size fits the budget; the largest
-    timed size is scaled to N = 20000 by N^3 (the evaluation is dominated by the O(N^3) Cholesky backward).  Thread
-    count: PyTorch CPU ops oversubscribe badly at these sizes with every hardware thread (256 threads are 10x slower
-    than 32 on a 2 x 64-core host), so the ladder runs with min(32, cores) threads and the last size is re-timed with
-    4x as many when the budget allows; the faster of the two is reported together with its thread count."""
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline
+# ---------------------------------------------------------------------------------------------------
+def _host_cpus():
+    """(physical cores, logical CPUs, model name) of this host from /proc/cpuinfo."""
+    cores, model, phys, core = set(), "", None, None
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name") and not model:
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("physical id"):
+                    phys = line.split(":", 1)[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":", 1)[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+    except OSError:
+        pass
+    logical = os.cpu_count() or 1
+    return (len(cores) or logical), logical, model
+
+
+def cpu_baseline(mode="single"):
+    """Oracle loss+grad (= optim/mll_torch.py:114-117 on the CPU oracle, plain PyTorch fp64 with the Cholesky forced) on
+    this box's host cores, on the C2 generator.
+
+    Thread count: PyTorch's CPU ops oversubscribe badly at these sizes with every hardware thread (256 threads were 10x
+    slower than 32 on the 2 x 64-core host of round 1), so a ladder N = 2048, 4096, 8192 is timed with min(32, logical
+    CPUs) threads, the last size is re-timed with 4x as many, and the faster thread count is used for what follows.
+      mode "single" (default)  ONE timed evaluation at the full N = 20 000 (after the ladder as warm-up): a measurement,
+                               not an extrapolation, inside ~1.5 min of host time;
+      mode "full"              BASELINE.md §3's protocol: 1 warm-up + median of 3 evaluations at N = 20 000 (~5 min);
+      mode "ladder"            the bounded sample only, scaled by N^3 (for hosts with < 64 GB of free memory).
+    ``cores`` is the number of threads actually used; the host's physical / logical CPU counts are given beside it."""
     from oracle.gp_oracle import OracleGP
 
-    ncpu = os.cpu_count() or 1
-    X, y = make_c2_data(8192)
+    phys, logical, model = _host_cpus()
+    X, y = make_c2_data(N_C2)
 
     def one(n, threads):
         torch.set_num_threads(threads)
@@ -77,60 +112,117 @@ def cpu_baseline(budget_s=30.0):
         o.loss_and_grad()
         return time.perf_counter() - t0
 
-    th = min(32, ncpu)
-    one(512, th)  # warm-up: thread pool, allocator
-    used, sizes = 0.0, []
-    for n in (2048, 4096, 8192):
-        if sizes and used + sizes[-1][1] * 8.0 > budget_s:
-            break
-        t = one(n, th)
-        used += t
-        sizes.append((n, t))
-    n_s, t_s = sizes[-1]
+    th = min(32, logical)
+    one(512, th)  # thread pool, allocator
+    ladder = [(n, one(n, th)) for n in (2048, 4096, 8192)]
+    n_s, t_s = ladder[-1]
     best_th = th
-    th2 = min(4 * th, ncpu)
-    if th2 > th and used + 2.0 * t_s < budget_s:
+    th2 = min(4 * th, logical)
+    if th2 > th:
         t2 = one(n_s, th2)
         if t2 < t_s:
             t_s, best_th = t2, th2
-    est = t_s * (N_C2 / n_s) ** 3
-    return {"value": 1.0 / est, "unit": "evals/s", "cores": best_th, "kind": "port",
-            "sample": f"oracle loss+grad timed at N={n_s} ({t_s:.2f} s with {best_th} threads of {ncpu}, same C2 "
-                      f"generator, 1 warm-up) and scaled by (20000/{n_s})^3 = {est:.0f} s/eval; "
-                      f"ladder at {th} threads {[(a, round(b, 2)) for a, b in sizes]}"}
+    try:
+        import psutil
+        free_gb = psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        free_gb = 0.0
+    if mode != "ladder" and free_gb < 64:
+        mode = "ladder"  # autograd through the dense N = 20 000 Cholesky holds ~45 GB of N x N fp64 temporaries
+    base = {"unit": "evals/s", "cores": best_th, "threads": best_th, "host_physical_cores": phys,
+            "host_logical_cpus": logical, "host_cpu": model, "kind": "port",
+            "ladder_s": {str(a): round(b, 3) for a, b in ladder}, "ladder_threads": th}
+    if mode == "ladder":
+        est = t_s * (N_C2 / n_s) ** 3
+        base.update(value=1.0 / est, measured_at_N=n_s, seconds_per_eval=est,
+                    sample=f"oracle loss+grad timed at N={n_s} ({t_s:.2f} s, {best_th} threads) and scaled by "
+                           f"(20000/{n_s})^3 = {est:.0f} s/eval (extrapolated: {free_gb:.0f} GB of host memory free)")
+        return base
+    times = []
+    if mode == "full":
+        one(N_C2, best_th)  # warm-up at full size
+        times = [one(N_C2, best_th) for _ in range(3)]
+        sec = float(np.median(times))
+        what = f"1 warm-up + median of 3 evaluations at N={N_C2} ({[round(t, 1) for t in times]} s)"
+    else:
+        sec = one(N_C2, best_th)
+        times = [sec]
+        what = f"ONE evaluation at N={N_C2} after the ladder as warm-up"
+    base.update(value=1.0 / sec, measured_at_N=N_C2, seconds_per_eval=sec,
+                sample=f"oracle loss+grad, {what}: {sec:.1f} s/eval with {best_th} threads on {phys} physical cores "
+                       f"({logical} logical, {model}); same C2 generator and theta1 as the GPU leg")
+    return base
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=N_C2, help="problem size (default: the C2 config)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="independent replicas evaluated concurrently on this GPU (one host thread + HIP stream + "
-                         "workspace slot each), the per-GPU form of restart parallelism")
-    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
-                    help="replicas (default): every GPU evaluates its own copy of the C2 problem (restart parallelism, weak "
-                         "scaling).  sharded: ALL GPUs evaluate ONE problem cooperatively (gp-plus_amd/sharded.py, strong "
-                         "scaling; use --n 60000 for the C5 size)")
-    ap.add_argument("--nb", type=int, default=1024, help="block height of the sharded evaluation")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------
+# self-launch
+# ---------------------------------------------------------------------------------------------------
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the exact-GP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+def spawn_ranks(args, argv):
+    """``--gpus N`` (N > 1) outside torch.distributed.run: start N fresh ranks as a child process tree (this process has
+    not initialised a GPU), relay their output and return the launcher's exit status."""
+    if not args.dry_run:
+        have = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
+        if have < args.gpus:
+            print(f"bench.py --gpus {args.gpus}: this node exposes {have} GPU(s)", file=sys.stderr)
+            return 2
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
+               MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    proc = subprocess.run(cmd, env=env)
+    return proc.returncode
 
+
+# ---------------------------------------------------------------------------------------------------
+# the legs
+# ---------------------------------------------------------------------------------------------------
+def _bracket(dist, dev, fn):
+    """barrier + synchronize, ``fn()``, synchronize + barrier; returns the MAX over ranks of the elapsed seconds."""
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = fn()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, out
+
+
+def _stage_table(events, N, share=1):
+    """Mean ms per stage and TFLOP/s of the O(N^3) stages (``share`` = ranks that split each of them)."""
+    stages = {}
+    for name, e0, e1 in events:
+        stages.setdefault(name, []).append(e0.elapsed_time(e1))
+    ms = {k: float(np.mean(v)) for k, v in stages.items()}
+    third = N ** 3 / 3
+    flops = {"potrf": third, "trtri": third, "lauum": third, "shard_factor": third, "shard_inverse": third, "shard_lauum": third}
+    rate = {k: flops[k] / share / (ms[k] * 1e-3) / 1e12 for k in flops if k in ms}
+    return ms, rate
+
+
+def _pmc_record(name):
+    p = os.path.join(ROOT, "profiles", name)
+    if os.path.exists(p):
+        with open(p) as fh:
+            return json.load(fh)
+    return None
+
+
+def run_replicas(args, dist, dev, rank, world, local_rank):
     from gpplus_amd import linalg
     from gpplus_amd.gpcore import ExactMarginalLogLikelihood
     from gpplus_amd.models import GP_Plus
@@ -145,18 +237,16 @@ def main():
         replicas.append((model, ExactMarginalLogLikelihood(model.likelihood, model),
                          [p for p in model.parameters() if p.requires_grad]))
 
-    from gpplus_amd import settings as gpp_settings
-    shard_cfg = {"group": None, "nb": args.nb} if (args.mode == "sharded" and world > 1) else None
-
     def step(k=0):
         model, mll, params = replicas[k]
         for p in params:
             p.grad = None
-        with gpp_settings.sharded_evaluation(shard_cfg):
-            output = model(*model.train_inputs)
-            loss = -mll(output, model.train_targets)
-            loss.backward()
+        output = model(*model.train_inputs)
+        loss = -mll(output, model.train_targets)
+        loss.backward()
         return loss
+
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
 
     def run_steps(nsteps):
         """``nsteps`` evaluations in total; with S > 1 they are dealt to S threads, each on its own stream and slot."""
@@ -184,69 +274,201 @@ def main():
             t.join()
         return next(r for r in results if r is not None)
 
-    streams = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
     run_steps(max(args.warmup, S if S > 1 else 0))
     torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
     linalg.STAGE_EVENTS = []  # list.append is atomic: the replica threads share it
-    t0 = time.perf_counter()
-    loss = run_steps(args.steps)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, loss = _bracket(dist, dev, lambda: run_steps(args.steps))
     events, linalg.STAGE_EVENTS = (linalg.STAGE_EVENTS or []), None
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
+    out = None
     if rank == 0:
         N = args.n
-        stages = {}
-        for name, e0, e1 in events:
-            stages.setdefault(name, []).append(e0.elapsed_time(e1))
-        if os.environ.get("GPP_BENCH_DEBUG"):
-            print({k: [round(x, 2) for x in v] for k, v in stages.items()}, file=sys.stderr)
-        stage_ms = {k: float(np.mean(v)) for k, v in stages.items()}
-        flops = {"potrf": N ** 3 / 3, "trtri": N ** 3 / 3, "lauum": N ** 3 / 3}
-        stage_rate = {k: flops[k] / (stage_ms[k] * 1e-3) / 1e12 for k in flops if k in stage_ms}
-        lauum_tflops = stage_rate.get("lauum")  # None in sharded mode (no single LAUUM launch there)
-        sharded = shard_cfg is not None
-        value = (1 if sharded else world) * args.steps / elapsed  # sharded: the ranks share every evaluation
-        # HBM-side bytes of the roofline kernel come from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-        # cannot run inside this process); they only apply to the size they were collected at
-        traffic, traffic_src = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_lauum_pmc.json")
-        if N == 20000 and os.path.exists(pmc):
-            with open(pmc) as fh:
-                rec = json.load(fh)
-            traffic, traffic_src = rec["traffic_bytes_per_launch"], "profiles/r01_lauum_pmc.json: " + rec["note"]
+        stage_ms, stage_rate = _stage_table(events, N)
+        eval_tf = N ** 3 / (elapsed / args.steps) / 1e12
+        # HBM-side bytes come from committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside this
+        # process); they only apply to the size they were collected at
+        pmc_l = _pmc_record("r01_lauum_pmc.json") if N == N_C2 else None
+        pmc_p = _pmc_record("r02_potrf_pmc.json") if N == N_C2 else None
+        third = N ** 3 / 3
+        entries = []
+        for name, kernel, pmc in (
+                ("potrf", "gpp_potrf_ws: look-ahead blocked Cholesky; ~500 launches of gpp_gemm_f64<2,64,64,0,16,2> (trailing "
+                          "updates, row solves) + gpp_leaf_potrf_inv on CU-masked streams", pmc_p),
+                ("trtri", "gpp_trtri: batched pair merges, gpp_gemm_f64<2,64,64,0,16,2>", None),
+                ("lauum", "gpp_gemm_f64<2, 64, 64, 1, 16, 2> (Kinv = Linv^T Linv, ONE lower-triangular TN launch)", pmc_l)):
+            if name in stage_rate:
+                entries.append({"stage": name, "kernel": kernel, "achieved": stage_rate[name],
+                                "frac": stage_rate[name] / PEAK_FP64_MFMA_TFLOPS, "flops": third, "ms": stage_ms[name],
+                                "traffic": None if pmc is None else pmc["traffic_bytes_per_launch"],
+                                "traffic_source": None if pmc is None else pmc.get("note")})
+        entries.append({"stage": "whole evaluation (N^3 flop, driver-timed)", "achieved": eval_tf,
+                        "frac": eval_tf / PEAK_FP64_MFMA_TFLOPS, "flops": N ** 3, "ms": 1e3 * elapsed / args.steps})
+        o3 = [e for e in entries if e["stage"] in ("potrf", "trtri", "lauum")]
+        worst = min(o3, key=lambda e: e["frac"]) if o3 else None
         out = {
             "metric": "MLL evals/sec (fwd+grad), NxN exact GP, N=20k d=8",
-            "value": value, "unit": "evals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-            "scaling": "strong" if sharded else "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "value": world * args.steps / elapsed, "unit": "evals/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"C2: synthetic Borehole (Sobol seed 0, unique rows, z-scored) N={N} d={D_C2} fp64, "
-                                   "GP_Plus Rough_RBF exact GP at theta1, " +
-                                   ("ONE evaluation sharded over all GPUs (block-cyclic rows, RCCL panel broadcasts)" if sharded
-                                    else "one replica per GPU (restart-parallel)"),
+                                   "GP_Plus Rough_RBF exact GP at theta1, one replica per GPU (restart-parallel)",
                        "N": N, "d": D_C2, "loss": float(loss.item()), "streams_per_gpu": S},
-            "roofline": {"bound": "mfma", "kernel": "gpp_gemm_f64<2, 64, 64, 1, 16, 2> (LAUUM: Kinv = Linv^T Linv, the one lower-triangular TN launch)",
-                         "achieved": lauum_tflops, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": None if lauum_tflops is None else lauum_tflops / PEAK_FP64_MFMA_TFLOPS, "traffic": traffic, "traffic_unit": "B/launch",
-                         "traffic_source": traffic_src,
-                         "flops_per_launch": N ** 3 / 3, "ms_per_launch": stage_ms.get("lauum")},
-            "stages": {"ms": stage_ms, "tflops": stage_rate,
-                       "eval_tflops_N3": N ** 3 / (elapsed / args.steps) / 1e12},
+            "roofline": {"bound": "mfma",
+                         "kernel": None if worst is None else f"{worst['stage']} stage — {worst['kernel']}",
+                         "achieved": None if worst is None else worst["achieved"], "peak": PEAK_FP64_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": None if worst is None else worst["frac"],
+                         "traffic": None if worst is None else worst["traffic"], "traffic_unit": "B/launch",
+                         "traffic_source": None if worst is None else worst["traffic_source"],
+                         "flops_per_launch": third, "ms_per_launch": None if worst is None else worst["ms"],
+                         "note": "the O(N^3) stage furthest from peak; 'entries' lists all three and the whole evaluation",
+                         "entries": entries},
+            "stages": {"ms": stage_ms, "tflops": stage_rate, "eval_tflops_N3": eval_tf},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out))
+    del replicas
+    linalg._workspaces.clear()
+    torch.cuda.empty_cache()
+    return out
+
+
+def run_sharded(args, dist, dev, rank, world, n, steps, warmup):
+    """ONE evaluation shared by all ranks (C5 generator at size ``n``; the C2 generator when ``--mode sharded --n 20000``)."""
+    from gpplus_amd import linalg
+    from gpplus_amd import settings as gpp_settings
+    from gpplus_amd.gpcore import ExactMarginalLogLikelihood
+    from gpplus_amd.models import GP_Plus
+    from gpplus_amd.test_functions.baseline_configs import apply_theta, make_config
+
+    cfg_name = "C5" if n > 30000 else "C2"
+    X, y, kw, theta = make_config(cfg_name, n)
+    model = GP_Plus(X, y, dtype=torch.float64, device=dev, **kw)
+    apply_theta(model, theta)
+    model.train()
+    mll = ExactMarginalLogLikelihood(model.likelihood, model)
+    params = [p for p in model.parameters() if p.requires_grad]
+    shard_cfg = {"group": None, "nb": args.nb}
+
+    def step():
+        for p in params:
+            p.grad = None
+        with gpp_settings.sharded_evaluation(shard_cfg):
+            loss = -mll(model(*model.train_inputs), model.train_targets)
+            loss.backward()
+        return loss
+
+    def run_steps(k):
+        out = None
+        for _ in range(k):
+            out = step()
+        return out
+
+    run_steps(warmup)
+    linalg.STAGE_EVENTS = []
+    elapsed, loss = _bracket(dist, dev, lambda: run_steps(steps))
+    events, linalg.STAGE_EVENTS = (linalg.STAGE_EVENTS or []), None
+    out = None
+    if rank == 0:
+        stage_ms, stage_rate = _stage_table(events, n, share=world)
+        per_gpu_tf = n ** 3 / (elapsed / steps) / 1e12 / world
+        D = X.shape[1]
+        out = {"metric": "MLL evals/sec (fwd+grad), ONE evaluation sharded over all GPUs", "value": steps / elapsed,
+               "unit": "evals/s", "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+               "scaling": "strong", "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"{cfg_name}: synthetic N={n} d={D} fp64 exact GP, kernel build + blocked Cholesky + "
+                                      f"inverse + gradient sharded block-cyclically (nb={args.nb}) over {world} GPU(s), "
+                                      "RCCL broadcasts of factor / inverse slabs", "N": n, "d": D, "nb": args.nb,
+                          "loss": float(loss.item()), "backend": "none" if dist is None else dist.get_backend()},
+               "roofline": {"bound": "mfma", "kernel": "whole sharded evaluation, N^3 flop / (time x GPUs)",
+                            "achieved": per_gpu_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
+                            "frac": per_gpu_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": None},
+               "stages": {"ms": stage_ms, "tflops_per_gpu": stage_rate}}
+    del model
+    from gpplus_amd import sharded as _sh
+    _sh._workspaces.clear()
+    torch.cuda.empty_cache()
+    return out
+
+
+def dry_run(args, rank, world):
+    """Launch-path check without GPUs: gloo rendezvous, barrier, MAX all-reduce, one JSON line from rank 0."""
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert int(t.item()) == world - 1
+    if rank == 0:
+        print(json.dumps({"metric": "MLL evals/sec (fwd+grad), NxN exact GP, N=20k d=8", "value": None, "unit": "evals/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=None, help="problem size (default: 20000 = C2; 60000 = C5 for --mode sharded)")
+    ap.add_argument("--cpu-baseline", choices=["single", "full", "ladder", "none"], default="single")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="independent replicas evaluated concurrently on this GPU (one host thread + HIP stream + "
+                         "workspace slot each), the per-GPU form of restart parallelism")
+    ap.add_argument("--mode", choices=["auto", "replicas", "sharded"], default="auto",
+                    help="auto (default): the replica leg, plus the sharded C5 leg when N > 1.  replicas / sharded: that "
+                         "leg only (sharded with one rank measures the algorithm without communication)")
+    ap.add_argument("--nb", type=int, default=1024, help="block height of the sharded evaluation")
+    ap.add_argument("--sharded-n", type=int, default=60000, help="size of the sharded leg (C5)")
+    ap.add_argument("--sharded-steps", type=int, default=2)
+    ap.add_argument("--sharded-warmup", type=int, default=1)
+    ap.add_argument("--dry-run", action="store_true", help="exercise the launch path only (gloo, no GPU work)")
+    args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args, sys.argv[1:]))
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.dry_run:
+        return dry_run(args, rank, world)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the exact-GP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    elif args.mode == "sharded":
+        import torch.distributed as dist  # the sharded evaluation wants a process group even when it has one rank
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        dist.init_process_group("gloo", rank=0, world_size=1)
+
+    out = None
+    if args.mode in ("auto", "replicas"):
+        if args.n is None:
+            args.n = N_C2
+        out = run_replicas(args, dist, dev, rank, world, local_rank)
+        if args.mode == "auto" and world > 1:
+            sh = run_sharded(args, dist, dev, rank, world, args.sharded_n, args.sharded_steps, args.sharded_warmup)
+            if rank == 0:
+                out["sharded"] = sh
+    else:
+        out = run_sharded(args, dist, dev, rank, world, args.n or args.sharded_n, args.steps, args.warmup)
+        if rank == 0:
+            out["higher_is_better"], out["vs_baseline"] = True, None
+    if rank == 0:
+        if world == 1 and args.mode != "sharded" and not args.no_cpu_baseline and args.cpu_baseline != "none":
+            out["cpu_baseline"] = cpu_baseline(args.cpu_baseline)
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

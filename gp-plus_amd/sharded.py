@@ -245,8 +245,10 @@ class ShardedMLLFunction(torch.autograd.Function):
         ws.epoch += 1
         jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
         used = None
+        from .linalg import _stage
         for jit in jitters:
-            info = _factor(gctx, comm, ws, Ud, wd, sd, td, grp, kind, d_split, jit)
+            with _stage("shard_factor"):
+                info = _factor(gctx, comm, ws, Ud, wd, sd, td, grp, kind, d_split, jit)
             if info == 0:
                 used = jit
                 break
@@ -259,7 +261,8 @@ class ShardedMLLFunction(torch.autograd.Function):
             raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitters[-1]:.1e}.")
         if used > 0:
             warnings.warn(f"A not p.d., added jitter of {used:.1e} to the diagonal", RuntimeWarning)
-        _inverse(gctx, comm, ws)
+        with _stage("shard_inverse"):
+            _inverse(gctx, comm, ws)
         torch.sub(f64(y), f64(mean), out=ws.r)
         gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
         ctx.saved = (gctx, comm, ws, ws.epoch, Ud, wd, sd, grp, td.numel(), kind, d_split, dU)
@@ -275,8 +278,10 @@ class ShardedMLLFunction(torch.autograd.Function):
                                "before the next evaluation")
         N, D = Ud.shape
         dev = Ud.device
+        from .linalg import _stage
         gctx.alpha(ws.Li, ws.z, ws.alpha)
-        _lauum_rows(gctx, comm, ws)
+        with _stage("shard_lauum"):
+            _lauum_rows(gctx, comm, ws)
         need_U = ctx.needs_input_grad[0] and dU > 0
         nU = N * dU if need_U else 0
         flat = torch.zeros(D + 1 + S + nU, dtype=torch.float64, device=dev)

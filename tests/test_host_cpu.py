@@ -3,6 +3,7 @@ keys), the data-prep helpers against the reference-generated fixtures, and the f
 made into the HIP library here."""
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -186,3 +187,24 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(d, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b|gp_oracle|importlib.*oracle", src, re.M), os.path.join(d, f)
+
+
+def test_bench_self_launches_its_ranks_dry_run():
+    """``python bench.py --gpus 2`` outside torch.distributed.run starts two ranks of itself before touching a GPU and
+    relays rank 0's single JSON line (launch path only: gloo rendezvous, barrier, MAX all-reduce; no GPU work)."""
+    import json
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry-run"], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["dry_run"] is True
+    # without enough GPUs the real launch refuses loudly instead of running one replica and reporting n_gpus = 1
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode != 0 and "GPU" in p.stderr
