@@ -94,8 +94,8 @@ def test_standalone_rough_rbf_through_gpr(gpu_ctx, n, d, mean):
     Xt = rng.standard_normal((64, d))
     pm, ps = o.predict(Xt, return_std=True, include_noise=True)
     gm, gs = m.predict(torch.tensor(Xt, device="cuda"), return_std=True, include_noise=True)
-    np.testing.assert_allclose(gm.cpu().numpy(), pm.numpy(), rtol=1e-4, atol=1e-8)
-    np.testing.assert_allclose(gs.cpu().numpy(), ps.numpy(), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(gm.detach().cpu().numpy(), pm.numpy(), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(gs.detach().cpu().numpy(), ps.numpy(), rtol=1e-4, atol=1e-8)  # (GPR.predict runs outside no_grad, as in the reference)
     # the dense operator: kernel(x).evaluate() against the oracle's matrix (ScaleKernel included)
     U = torch.tensor(X[:128], device="cuda")
     Kg = m.covar_module(U).evaluate().cpu()
@@ -187,7 +187,8 @@ def test_fit_model_torch_follows_the_oracle_trajectory(gpu_ctx, name, fixture, x
     np.testing.assert_allclose(np.asarray(hist[0]), ref_hist, rtol=RTOL, atol=0)
     assert abs(f_inc - ref_hist[-1]) <= RTOL * abs(ref_hist[-1])
     # the parameters after the last optimizer.step() (the driver restores the state of the best = only run)
-    final = {n: p.detach().cpu().numpy() for n, p in m.named_parameters()}
+    final = {n: p.detach().cpu().numpy() for n, p in m.named_parameters() if p.requires_grad}
+    assert len(final) == sum(1 for k in tr if k.startswith(f"{name}::final::"))
     for k, v in final.items():
         ref = tr[f"{name}::final::{k}"].reshape(v.shape)
         np.testing.assert_allclose(v, ref, rtol=1e-5, atol=1e-7, err_msg=k)
