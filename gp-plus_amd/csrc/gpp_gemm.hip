@@ -21,6 +21,7 @@
 #include "gpp_internal.h"
 
 typedef double v2d __attribute__((ext_vector_type(2)));
+typedef double v4d __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -223,6 +224,7 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
         tn = q;
         if (p.own_mod > 1 && (tm / p.own_bt + p.own_off) % p.own_mod != 0) return;  // another rank's block row
         if ((tn + 1) * TN <= p.skip_lead) return;  // (tm <= tn) inside the leading block another launch has updated
+        if (p.row_limit > 0 && tm * TM >= p.row_limit) return;  // below the trapezoid this launch produces
       }
     } else if (p.col_major) {
       // column-major tile order: consecutive work-groups share the column tile (hence the K range when it depends on
@@ -254,11 +256,14 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
   else if (p.khi_mode == 2) khi = min(p.K, col0 + TN);
   const int nch = khi > klo ? (khi - klo + BK - 1) / BK : 0;
 
-  double acc[RB][CB];
+  // accumulators: acc4[a4][b] element v is C[row0 + wm + 16 a4 + 4 v + (l>>4)][col0 + wn + 16 b + (l&15)] — the 16 x 16 result
+  // block of v_mfma_f64_16x16x4_f64 (lane l, element v: row (l>>4) + 4 v, column l&15; tools/mfma16_layout.hip)
+  static_assert(RB % 4 == 0, "wave tile rows must be a multiple of 16");
+  v4d acc4[RB / 4][CB];
 #pragma unroll
-  for (int a = 0; a < RB; ++a)
+  for (int a = 0; a < RB / 4; ++a)
 #pragma unroll
-    for (int b = 0; b < CB; ++b) acc[a][b] = 0.0;
+    for (int b = 0; b < CB; ++b) acc4[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
 
   v2d ra[NVA], rb[NVB];
   unsigned ka = 0, kb_ = 0;
@@ -320,29 +325,22 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
   __syncthreads();
 
   auto compute = [&](int cur) {
-    // A fragment: lane (i = l&3, k = l>>4), same address in the 4 column groups (l>>2)&3 -> LDS broadcast
-    const double* sa = smem + (cur * 2 + 0) * OPSZ + (A_KC ? (wm + (lane & 3)) * LDK + lk : wm + (lane & 3) + lk * LDA);
+    // v_mfma_f64_16x16x4_f64: lane (i = l&15, k = l>>4) supplies A[row i][k] and B[k][col i]; one instruction yields a
+    // 16 x 16 block of C.  Per k-step of 4 a 64 x 64 wave tile takes 4 + 4 fragment reads for 16 MFMAs.
+    const double* sa = smem + (cur * 2 + 0) * OPSZ + (A_KC ? (wm + li) * LDK + lk : wm + li + lk * LDA);
     const double* sb = smem + (cur * 2 + 1) * OPSZ + (B_KC ? (wn + li) * LDK + lk : wn + li + lk * LDB);
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
-      double bf[CB];
+      double bf[CB], af[RB / 4];
 #pragma unroll
       for (int b = 0; b < CB; ++b) bf[b] = B_KC ? sb[16 * b * LDK + kk * 4] : sb[kk * 4 * LDB + 16 * b];
-      // A fragments in groups of <= 8 row blocks: bounds the live registers (acc + staging already take ~170).
-      // (Requesting the next group's fragments before this group's MFMAs, from a second register set, was measured:
-      //  no gain — the LDS latency is already covered by the other wave of the SIMD.)
-      constexpr int AG = RB < 8 ? RB : 8;
 #pragma unroll
-      for (int a0 = 0; a0 < RB; a0 += AG) {
-        double af[AG];
+      for (int a = 0; a < RB / 4; ++a) af[a] = A_KC ? sa[16 * a * LDK + kk * 4] : sa[kk * 4 * LDA + 16 * a];
 #pragma unroll
-        for (int a = 0; a < AG; ++a) af[a] = A_KC ? sa[4 * (a0 + a) * LDK + kk * 4] : sa[kk * 4 * LDA + 4 * (a0 + a)];
+      for (int a = 0; a < RB / 4; ++a)
 #pragma unroll
-        for (int a = 0; a < AG; ++a)
-#pragma unroll
-          for (int b = 0; b < CB; ++b)
-            acc[a0 + a][b] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[a], bf[b], acc[a0 + a][b], 0, 0, 0);
-      }
+        for (int b = 0; b < CB; ++b)
+          acc4[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[a], bf[b], acc4[a][b], 0, 0, 0);
     }
   };
 
@@ -432,7 +430,7 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
       for (int b = 0; b < CB; ++b) {
         const int n = col0 + wn + 16 * b + li;
         const bool ok = (m < p.M) && (n < p.N) && (p.c_lower == 0 || (p.c_lower == 1 ? n <= m : n >= m));
-        double v = alpha * acc[a0 + a][b];
+        double v = alpha * acc4[(a0 + a) >> 2][b][(a0 + a) & 3];
         if (beta != 0.0) v = fma(beta, cold[a][b], v);
         if (ok) {
           C[(int64_t)m * p.ldc + n] = v;

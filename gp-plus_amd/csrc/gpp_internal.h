@@ -52,6 +52,9 @@ struct GemmArgs {
                            // (block-cyclic block rows of own_bt tile rows; own_mod <= 1: all).  Other tiles exit at once.
   int skip_lead;           // c_lower == 2 only: tiles lying entirely inside the leading skip_lead x skip_lead block exit at once
                            // (that block was updated by an earlier launch; skip_lead a multiple of the tile)
+  int row_limit;           // c_lower == 2 only: produce only the tiles whose rows lie below row_limit (a multiple of the tile;
+                           // 0: all): the upper TRAPEZOID rows [0, row_limit) x columns [row, N) in one launch — other tiles
+                           // of the triangular enumeration exit at once
   int row_mod, row_off;    // c_lower == 1 only: produce the tile rows tm with tm % row_mod == row_off (row_mod <= 1: all);
                            // the sharded LAUUM, one launch per rank over its cyclic share of the 128-row tile rows
 };

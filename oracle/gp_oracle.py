@@ -444,3 +444,29 @@ class OracleGP:
             var = var + self.noise_vector(xtest)
         var = var.clamp_min(1e-10)  # [3P] settings.min_variance (double)
         return out_mean, var.sqrt() * self.y_std
+
+    @torch.no_grad()
+    def evaluation(self, xtest, ytest, alpha: float = 0.05):
+        """models/gp_plus.py:889-932: ``trained_pred_dist = likelihood(self(Xtest))`` (joint predictive MVN of the test
+        points incl. their own sources' noise), then [3P] gpytorch.metrics: NLPD = -log_prob(y) / M, MSE, MAE; the interval
+        score of :907-913 on the +-2 sigma confidence region; MSE / MAE / IS scaled back (:916-919), RRMSE (:921)."""
+        xtest = torch.as_tensor(xtest, dtype=DT)
+        ytest = torch.as_tensor(ytest, dtype=DT).reshape(-1)
+        m, K = self.forward(torch.cat([self.train_x, xtest], dim=0))
+        n = self.N
+        L, _ = psd_safe_cholesky(K[:n, :n] + torch.diag(self.noise_vector(self.train_x)))
+        alpha_v = torch.cholesky_solve((self.y_sc - m[:n]).unsqueeze(-1), L).squeeze(-1)
+        mean = m[n:] + K[n:, :n] @ alpha_v
+        V = torch.linalg.solve_triangular(L, K[n:, :n].T, upper=False)
+        cov = K[n:, n:] - V.T @ V + torch.diag(self.noise_vector(xtest))
+        y_sc = (ytest - self.y_min) / self.y_std
+        M = ytest.shape[0]
+        Lp, _ = psd_safe_cholesky(cov)
+        z = torch.linalg.solve_triangular(Lp, (y_sc - mean).unsqueeze(-1), upper=False)
+        log_prob = -0.5 * ((z * z).sum() + 2 * torch.log(torch.diagonal(Lp)).sum() + M * math.log(2 * math.pi))
+        std = torch.diagonal(cov).clamp_min(1e-10).sqrt()
+        lo, up = mean - 2 * std, mean + 2 * std
+        score = (up - lo) + (y_sc > up) * 2 / alpha * (y_sc - up) + (y_sc < lo) * 2 / alpha * (lo - y_sc)
+        mse = ((y_sc - mean) ** 2).mean() * self.y_std ** 2
+        return {"NLL": -log_prob / M, "MSE": mse, "MAE": (y_sc - mean).abs().mean() * self.y_std.abs(),
+                "RRMSE": torch.sqrt(mse / torch.var(ytest)), "IS": score.mean() * self.y_std.abs()}

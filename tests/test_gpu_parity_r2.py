@@ -352,3 +352,56 @@ def test_c5_size_properties_single_gpu(gpu_ctx):
     del m2
     linalg._workspaces.clear()
     torch.cuda.empty_cache()
+
+
+# ---------------------------------------------------------------------------------------------------
+# multi-noise model: fit-like training evaluations, then evaluation() / predict() / train again
+# (models/gp_plus.py:889-932; the training covariance must keep the TRAINING points' noise groups whatever the last
+#  prediction left in likelihood.fidel_indices)
+# ---------------------------------------------------------------------------------------------------
+def test_multi_noise_evaluation_after_training_matches_oracle(gpu_ctx):
+    from oracle.gp_oracle import OracleGP
+    from gpplus_amd.models import GP_Plus
+
+    fx = dict(np.load(os.path.join(GOLD, "c4_wing_mf_n300.npz")))
+    kw = {"qual_dict": {10: 3}, "multiple_noise": True, "m_gp": "multiple_constant"}
+    X, y = fx["Xtrain"], fx["ytrain"]
+    Xt = fx["Xtest"][:47]  # M < N and M not a multiple of anything: a stale test-sized index would be out of bounds
+    yt = fx["theta1::pred_mean"][:47] + 0.3 * np.sin(np.arange(47))
+    o = OracleGP(X, y, **kw)
+    m = GP_Plus(torch.tensor(X), torch.tensor(y), dtype=torch.float64, device="cuda", **kw)
+    sd = m.state_dict()
+    for k in list(o.params):
+        o.params[k] = torch.as_tensor(fx[f"theta1::param::{k}"]).reshape(o.params[k].shape).clone()
+        sd[k] = o.params[k].reshape(sd[k].shape).to(sd[k])
+    m.load_state_dict(sd)
+    ref = {k: float(v) for k, v in o.evaluation(Xt, yt).items()}
+    loss0, grads0 = _loss_and_grads(m)                      # what fit() does: training-mode evaluations ...
+    res = m.evaluation(torch.tensor(Xt), torch.tensor(yt), verbose=False)   # ... then straight into evaluation()
+    for k, v in ref.items():
+        assert abs(float(res[k]) - v) <= 1e-4 * max(abs(v), 1e-8), (k, float(res[k]), v)
+    # predict() with a different batch leaves test-sized indices behind; training and the next evaluation are unaffected
+    pm, ps = m.predict(torch.tensor(fx["Xtest"][:13]), return_std=True, include_noise=True)
+    om, os_ = o.predict(fx["Xtest"][:13], return_std=True, include_noise=True)
+    np.testing.assert_allclose(pm.cpu().numpy(), om.numpy(), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(ps.cpu().numpy(), os_.numpy(), rtol=1e-4, atol=1e-8)
+    m.likelihood.fidel_indices = torch.tensor(fx["Xtest"][:13, -1], device="cuda")  # (what GPR.predict leaves behind)
+    m.train()
+    m.prediction_strategy = None
+    res2 = m.evaluation(torch.tensor(Xt), torch.tensor(yt), verbose=False)
+    for k, v in ref.items():
+        assert abs(float(res2[k]) - v) <= 1e-4 * max(abs(v), 1e-8), (k, float(res2[k]), v)
+    # the C ABI front refuses a group index of the wrong length instead of reading past it
+    from gpplus_amd._lib import GppError
+    from gpplus_amd.backend import square_buffer
+    U = torch.rand(64, 3, dtype=torch.float64, device="cuda")
+    w = torch.ones(3, dtype=torch.float64, device="cuda")
+    one = torch.ones(1, dtype=torch.float64, device="cuda")
+    tau = torch.full((2,), 1e-3, dtype=torch.float64, device="cuda")
+    with pytest.raises(GppError, match="noise-group index"):
+        gpu_ctx.kernel_build(U, w, one, tau, torch.zeros(10, dtype=torch.int32, device="cuda"), square_buffer(64, "cuda"))
+    with pytest.raises(GppError, match="out of range"):
+        gpu_ctx.kernel_build(U, w, one, tau, torch.full((64,), 2, dtype=torch.int32, device="cuda"), square_buffer(64, "cuda"))
+    with pytest.raises(GppError, match="feature columns"):
+        gpu_ctx.kernel_build(torch.rand(8, 65, dtype=torch.float64, device="cuda"), torch.ones(65, dtype=torch.float64, device="cuda"),
+                             one, None, None, square_buffer(8, "cuda"))

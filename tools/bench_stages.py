@@ -31,6 +31,9 @@ def main():
         "lauum": lambda: ctx.lauum(Li, Ki),
         "grad": lambda: ctx.grad_reduce(U, w, sf2, None, 1, al, Ki, 0, gw, gs, gt, None),
     }
+    only = __import__("os").environ.get("STAGES_ONLY")  # e.g. "build,potrf": profile passes whose kernels belong to one stage
+    if only:
+        stages = {k: v for k, v in stages.items() if k in only.split(",")}
     flops = {"potrf": N**3 / 3, "trtri": N**3 / 3, "lauum": N**3 / 3}
     tot = {k: [] for k in stages}
     nosync = __import__("os").environ.get("STAGES_NOSYNC", "0") != "0"  # enqueue the whole evaluation, then wait (as the product does)
@@ -52,6 +55,8 @@ def main():
         ms = float(np.median(v)); total += ms
         extra = f"  {flops[k] / ms / 1e9:8.2f} TFLOP/s" if k in flops else ""
         print(f"{k:12s} {ms:10.3f} ms{extra}")
+    if only:
+        return
     print("grad checksum", float(gw.sum() + gs.sum() + gt.sum()))
     print(f"{'total':12s} {total:10.3f} ms  -> {1000.0 / total:.3f} evals/s   N^3 rate {N**3 / total / 1e9:.2f} TFLOP/s   mll={out3[2].item():.6f}")
 
