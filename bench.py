@@ -458,7 +458,13 @@ def main():
             args.n = N_C2
         out = run_replicas(args, dist, dev, rank, world, local_rank)
         if args.mode == "auto" and world > 1:
-            sh = run_sharded(args, dist, dev, rank, world, args.sharded_n, args.sharded_steps, args.sharded_warmup)
+            # the second leg must never cost the first its JSON line: a failure is reported inside the line (all ranks reach
+            # the same branch: the sharded evaluation fails or succeeds collectively, and a hang is bounded by the
+            # process-group timeout)
+            try:
+                sh = run_sharded(args, dist, dev, rank, world, args.sharded_n, args.sharded_steps, args.sharded_warmup)
+            except Exception as exc:  # noqa: BLE001
+                sh = {"error": f"{type(exc).__name__}: {exc}"[:500]}
             if rank == 0:
                 out["sharded"] = sh
     else:

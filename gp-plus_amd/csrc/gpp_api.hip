@@ -485,176 +485,6 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   return hipSuccess;
 }
 
-// ---- hybrid right-/left-looking driver (N above the bordering range) ---------------------------------------------
-// A right-looking factorisation ends in a chain: once the trailing matrix is a few thousand rows wide its updates no longer
-// hide the next diagonal block (leaf -> panel solve -> rank-128 update, ~1 ms per 1024 rows), and the throughput stream runs
-// launches of a few hundred tiles (traced at N = 20000: the last 9760 rows take 11.5 ms for 5 ms of GEMM work).  The flops
-// that could hide that chain were spent earlier, when there was plenty to hide the panels with.  So the updates of the TAIL
-// rows [oT, N) are deferred: steps k < kL are right-looking but update only the rows below oT (an upper TRAPEZOID of the
-// trailing matrix: GemmArgs::row_limit), and from step kL on the factorisation is LEFT-looking with two block rows of
-// look-ahead: while the panel stream factors diagonal block k+1, the throughput stream gives block row k+2 ALL its updates
-// from the finished rows in one long-K product  A[k+2, k+2:] -= U[0:o_{k+1}, k+2]^T U[0:o_{k+1}, k+2:]  (K = thousands
-// instead of 512/1024: no read-modify-write passes over the trailing matrix either), after the short K = nb pieces the
-// chain needs (row solve of block row k, rank-nb update of block row k+1).  Invariant at the start of step k >= kL: block
-// row k+1 carries the updates of rows < k, every later block row of the tail those it got as "k+2" or none.
-constexpr int64_t HYB_TAIL_M = 8192, HYB_NB = 1024, HYB_NB_END = 512;
-hipError_t potrf_hybrid(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64_t ldt) {
-  HIP_TRY(ensure_streams(h));
-  Ctx cp = cm, cu = cm;
-  cp.s = h->panel_stream;
-  cu.s = h->upd_stream;
-  hipStream_t cx = h->full_stream;
-  static const int64_t nb_main = getenv("GPP_HYB_NB") ? atol(getenv("GPP_HYB_NB")) : HYB_NB;              // experiment knobs
-  static const int64_t nb_end = getenv("GPP_HYB_NB_END") ? atol(getenv("GPP_HYB_NB_END")) : HYB_NB_END;
-  static const int64_t tail_m = getenv("GPP_HYB_TAIL") ? atol(getenv("GPP_HYB_TAIL")) : HYB_TAIL_M;
-  static const int64_t split_elems = getenv("GPP_SPLIT_ELEMS") ? atol(getenv("GPP_SPLIT_ELEMS")) : 60000000;
-  static const bool split_on = !(getenv("GPP_SPLIT_UPD") && atoi(getenv("GPP_SPLIT_UPD")) == 0);
-  static const int64_t cu_t64 = getenv("GPP_HYB_T64") ? atol(getenv("GPP_HYB_T64")) : 300;  // catch-up: 64-wide tiles below this many 128-wide ones
-  // block rows: nb_main while at least two end blocks remain, then blocks of nb_end (the last two panels are exposed)
-  int64_t off[136];
-  int nblk = 0;
-  {
-    int64_t o = 0;
-    off[0] = 0;
-    while (N - o >= nb_main + 2 * nb_end && nblk < 120) { o += nb_main; off[++nblk] = o; }
-    int64_t R = N - o;
-    while (R > nb_end + nb_end / 2 && nblk < 130) { o += nb_end; R -= nb_end; off[++nblk] = o; }
-    off[++nblk] = N;
-  }
-  int kT = nblk;  // first block row whose updates are deferred
-  for (int k = 0; k < nblk; ++k)
-    if (off[k] >= N - tail_m) { kT = k; break; }
-  if (kT < 2) kT = 2;
-  const int kL = kT - 2;                                  // first left-looking step
-  const int64_t oT = kT < nblk ? off[kT] : N;
-  hipEvent_t ev = next_event(h);
-  HIP_TRY(hipEventRecord(ev, cm.s));  // inputs (kernel build) are ready
-  HIP_TRY(hipStreamWaitEvent(cp.s, ev, 0));
-  HIP_TRY(hipStreamWaitEvent(cu.s, ev, 0));
-  HIP_TRY(hipStreamWaitEvent(cx, ev, 0));
-  const bool can_split = split_on && h->cu_split == 1;
-  struct { bool on; GemmArgs g; hipEvent_t rows_ready; int64_t rows_masked; } pend{false, GemmArgs{}, nullptr, 0};
-  hipEvent_t be_wait = nullptr;
-  for (int k = 0; k < nblk; ++k) {
-    const int64_t o = off[k], nb = off[k + 1] - o, rem = N - off[k + 1];
-    // panel stream: factor and invert the diagonal block
-    HIP_TRY(potrf_rec(cp, o, nb));
-    for (int64_t s = NBLK; s < nb; s *= 2)
-      HIP_TRY(trtri_level(cp.s, cm.A, cm.ld, cm.Li, cm.ldi, T, ldt, o, nb, s, [](int64_t) { return false; }));
-    if (h->inv_nblocks < 128) {
-      h->inv_o[h->inv_nblocks] = o;
-      h->inv_n[h->inv_nblocks] = nb;
-      ++h->inv_nblocks;
-    }
-    hipEvent_t D = next_event(h);
-    HIP_TRY(hipEventRecord(D, cp.s));
-    HIP_TRY(hipStreamWaitEvent(cu.s, D, 0));
-    if (pend.on) {  // the bulk of the previous right-looking update, on all 256 CUs now that no leaf is waiting
-      HIP_TRY(hipStreamWaitEvent(cx, pend.rows_ready, 0));
-      HIP_TRY(hipStreamWaitEvent(cx, D, 0));
-      HIP_TRY(gpp_launch_gemm(cx, 2, pend.g, 1, NBLK, NBLK));
-      hipEvent_t BE = next_event(h);
-      HIP_TRY(hipEventRecord(BE, cx));
-      pend.on = false;
-      const int64_t nb_next = (k + 1 < nblk) ? off[k + 2] - off[k + 1] : 0;
-      if (pend.rows_masked >= nb + nb_next) be_wait = BE;  // this step's chain only touches rows the masked part produced
-      else HIP_TRY(hipStreamWaitEvent(cu.s, BE, 0));
-    }
-    if (rem == 0) {
-      if (be_wait) HIP_TRY(hipStreamWaitEvent(cu.s, be_wait, 0));
-      break;
-    }
-    const int64_t nb2 = off[k + 2] - off[k + 1], rest = rem - nb2;
-    auto row_solve = [&](int64_t c0, int64_t nc) -> hipError_t {
-      GemmArgs gt = mk(cm.Li + o * cm.ldi + o, cm.ldi, cm.A + o * cm.ld + c0, cm.ld, T + o * ldt + c0, ldt, nb, nc, nb, 1.0, 0.0);
-      gt.a_mask = 1; gt.khi_mode = 1; gt.row_reverse = 1;
-      HIP_TRY(gpp_launch_gemm(cu.s, 2, gt, 1));
-      return hipMemcpy2DAsync(cm.A + o * cm.ld + c0, cm.ld * sizeof(double), T + o * ldt + c0, ldt * sizeof(double),
-                              nc * sizeof(double), nb, hipMemcpyDeviceToDevice, cu.s);
-    };
-    const double* Urow = cm.A + o * cm.ld;
-    // the chain: columns of the next diagonal block, its rank-nb update, and the panel stream may go on
-    HIP_TRY(row_solve(o + nb, nb2));
-    GemmArgs g = mk(Urow + (o + nb), cm.ld, Urow + (o + nb), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb), cm.ld, nb2, nb2, nb, -1.0, 1.0);
-    g.c_lower = 2;
-    HIP_TRY(gpp_launch_gemm(cu.s, 2, g, 1));
-    hipEvent_t S = next_event(h);
-    HIP_TRY(hipEventRecord(S, cu.s));
-    HIP_TRY(hipStreamWaitEvent(cp.s, S, 0));
-    if (rest > 0) HIP_TRY(row_solve(o + nb + nb2, rest));
-    if (be_wait) {
-      HIP_TRY(hipStreamWaitEvent(cu.s, be_wait, 0));
-      be_wait = nullptr;
-    }
-    if (rest <= 0) continue;
-    if (k < kL) {
-      // right-looking, rows below oT only: upper trapezoid rows [0, r1) x columns [row, rem) of the trailing matrix, minus
-      // the next diagonal block (done by the chain)
-      const int64_t r1 = oT - off[k + 1];
-      GemmArgs g3 = mk(Urow + (o + nb), cm.ld, Urow + (o + nb), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb), cm.ld, rem, rem, nb, -1.0, 1.0);
-      g3.c_lower = 2;
-      g3.skip_lead = (nb2 % NBLK == 0) ? (int)nb2 : 0;
-      g3.row_limit = (int)r1;
-      int64_t rA = ((split_elems / rem + NBLK - 1) / NBLK) * NBLK;
-      rA = std::max(rA, nb2);
-      if (can_split && r1 - rA >= 2048 && g3.skip_lead) {
-        pend.rows_ready = next_event(h);
-        HIP_TRY(hipEventRecord(pend.rows_ready, cu.s));
-        GemmArgs a2 = mk(Urow + (o + nb), cm.ld, Urow + (o + nb + rA), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb + rA), cm.ld,
-                         rA, rem - rA, nb, -1.0, 1.0);  // rows [0, rA) x columns [rA, rem)
-        HIP_TRY(gpp_launch_gemm(cu.s, 2, a2, 1, NBLK, NBLK));
-        GemmArgs a1 = g3;  // upper triangle of the leading rA x rA block, issued last (see potrf_lookahead)
-        a1.M = a1.N = (int)rA;
-        a1.row_limit = 0;
-        HIP_TRY(gpp_launch_gemm(cu.s, 2, a1, 1, NBLK, NBLK));
-        pend.g = mk(Urow + (o + nb + rA), cm.ld, Urow + (o + nb + rA), cm.ld, cm.A + (o + nb + rA) * cm.ld + (o + nb + rA),
-                    cm.ld, rem - rA, rem - rA, nb, -1.0, 1.0);
-        pend.g.c_lower = 2;
-        pend.g.row_limit = (int)(r1 - rA);
-        pend.rows_masked = rA;
-        pend.on = true;
-      } else {
-        if (!g3.skip_lead) {  // (ragged next block: its part right of the diagonal block was not covered by the chain)
-          GemmArgs g2 = mk(Urow + (o + nb), cm.ld, Urow + (o + nb + nb2), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb + nb2), cm.ld,
-                           nb2, rest, nb, -1.0, 1.0);
-          HIP_TRY(gpp_launch_gemm(cu.s, 2, g2, 1));
-          GemmArgs g4 = mk(Urow + (o + nb + nb2), cm.ld, Urow + (o + nb + nb2), cm.ld,
-                           cm.A + (o + nb + nb2) * cm.ld + (o + nb + nb2), cm.ld, rest, rest, nb, -1.0, 1.0);
-          g4.c_lower = 2;
-          g4.row_limit = (int)std::max<int64_t>(r1 - nb2, 0);
-          if (r1 - nb2 > 0) HIP_TRY(gpp_launch_gemm(cu.s, 2, g4, 1, NBLK, NBLK));
-        } else {
-          HIP_TRY(gpp_launch_gemm(cu.s, 2, g3, 1, NBLK, NBLK));
-        }
-      }
-    } else {
-      // left-looking: the rest of block row k+1 takes row k's update (K = nb) ...
-      GemmArgs g2 = mk(Urow + (o + nb), cm.ld, Urow + (o + nb + nb2), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb + nb2), cm.ld,
-                       nb2, rest, nb, -1.0, 1.0);
-      HIP_TRY(gpp_launch_gemm(cu.s, 2, g2, 1));
-      // ... and block row k+2 everything it has missed: rows [0, o_{k+1}) of U, one long-K product over the upper trapezoid
-      // rows [0, nb3) x columns [row, w) of the matrix at (o2, o2)
-      const int64_t o2 = off[k + 2], nb3 = off[k + 3 <= nblk ? k + 3 : nblk] - o2, w = N - o2;
-      if (k + 2 < nblk && k + 2 >= kT) {
-        GemmArgs c = mk(cm.A + o2, cm.ld, cm.A + o2, cm.ld, cm.A + o2 * cm.ld + o2, cm.ld, w, w, off[k + 1], -1.0, 1.0);
-        c.c_lower = 2;
-        const int64_t t128 = ((nb3 + NBLK - 1) / NBLK) * ((w + NBLK - 1) / NBLK);
-        const int tile = (t128 >= cu_t64 || nb3 % 64 != 0) ? NBLK : 64;
-        c.row_limit = (int)(((nb3 + tile - 1) / tile) * tile);
-        HIP_TRY(gpp_launch_gemm(cu.s, 2, c, 1, tile, tile));
-      }
-    }
-  }
-  if (pend.on) return hipErrorUnknown;
-  hipEvent_t E = next_event(h);
-  HIP_TRY(hipEventRecord(E, cu.s));
-  HIP_TRY(hipStreamWaitEvent(cm.s, E, 0));
-  hipEvent_t E2 = next_event(h);
-  HIP_TRY(hipEventRecord(E2, cx));
-  HIP_TRY(hipStreamWaitEvent(cm.s, E2, 0));
-  return hipSuccess;
-}
-
 int check_mat(const void* p, int64_t ld, int64_t n, int argi) {
   if (!p) return -argi;
   if (!aligned16(p) || (ld & 1) || ld < n) return -(argi + 1);
@@ -795,12 +625,7 @@ int gpp_potrf_ws(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv,
   // (measured: the leaf-step factorisation on one stream wins up to ~6000 rows — 2.99 vs 3.46 ms at 4096, 4.25 vs 4.53 at
   //  5120, a tie at 6144; the look-ahead wins from there: 8.6 vs 10.1 ms at 8192)
   static const int64_t la_min_b = getenv("GPP_BORDER_MIN") ? atol(getenv("GPP_BORDER_MIN")) : BORDER_MIN_N;  // knob
-  // (measured at N = 20000 with the deferred tail at 4096 / 8192 rows: 63.8 / 75.6 ms against 54.7 for the plain look-ahead —
-  //  a long-K catch-up launch is ONE wave of <= 448 tiles that each run 3-5 ms, however few they are; off by default)
-  static const bool hybrid_on = getenv("GPP_HYBRID") && atoi(getenv("GPP_HYBRID")) != 0;  // experiment knob
-  static const int64_t border_max = getenv("GPP_BORDER_MAX") ? atol(getenv("GPP_BORDER_MAX")) : BORDER_MAX_N;
-  if (T && hybrid_on && N > border_max) GPP_TRY(potrf_hybrid(h, c, N, T, ldt));
-  else if (N >= (T ? std::min(la_min, la_min_b) : la_min)) GPP_TRY(potrf_lookahead(h, c, N, LOOKAHEAD_NB, T, ldt));
+  if (N >= (T ? std::min(la_min, la_min_b) : la_min)) GPP_TRY(potrf_lookahead(h, c, N, LOOKAHEAD_NB, T, ldt));
   else GPP_TRY(potrf_rec(c, 0, N));
   return 0;
 }
