@@ -302,21 +302,40 @@ class GP_Plus(GPR):
         if self.tkwargs['device'].type != 'cuda':
             raise RuntimeError("this build evaluates the marginal likelihood only on an MI355X (device='cuda'); "
                                "there is no CPU path")
-        if optim_type == 'adam_torch':
-            out = fit_model_torch(model=self, model_param_groups=None, lr_default=0.01, num_iter=100, num_restarts=64,
-                                  break_steps=50)
-        elif optim_type == 'adam_torch_batched':
-            # same optimisation (64 restarts x 100 Adam steps) with all runs advancing together, one batched evaluation
-            # per iteration (optim/mll_batched.py): not in the reference, which runs its restarts one after the other
-            from ..optim import fit_model_torch_batched
-            out = fit_model_torch_batched(self, lr_default=0.01, num_iter=100, num_restarts=64, break_steps=50)
+        if optim_type in ('adam_torch', 'adam_torch_batched'):
+            restarts = 64  # gp_plus.py:557
         else:
             warnings.warn('The model is built to run on CUDA (GPU), but the current optimization type is invalid for '
                           'this configuration. So, the optimizer is now using adam_torch to train the model.')
-            out = fit_model_torch(model=self.to(**self.tkwargs), model_param_groups=None, lr_default=0.01, num_iter=100,
-                                  num_restarts=4, break_steps=50)
+            restarts = 4   # gp_plus.py:566
+        # The reference runs the restarts one after the other.  Here they advance together (one batched evaluation per Adam
+        # iteration: same start points in the same RNG order, same per-run optimiser and early stop, same winner —
+        # optim/mll_batched.py) while the problem is small enough for that to pay and for the B x 3 N^2 workspace to fit;
+        # settings.batched_restarts(False) restores the sequential loop, 'adam_torch_batched' asks for the batched one.
+        if optim_type == 'adam_torch_batched' or self._restarts_fit_one_batch(restarts + 1):
+            from ..optim import fit_model_torch_batched
+            out = fit_model_torch_batched(self, lr_default=0.01, num_iter=100, num_restarts=restarts, break_steps=50)
+        else:
+            out = fit_model_torch(model=self, model_param_groups=None, lr_default=0.01, num_iter=100,
+                                  num_restarts=restarts, break_steps=50)
         print("## Learning the model's parameters is successfully finished ##")
         return out
+
+    def _restarts_fit_one_batch(self, B: int) -> bool:
+        """True when ``B`` restarts of this model should be evaluated together: batched restarts enabled, N within the batched
+        kernels' range, and three B x N x N fp64 buffers within a third of the device memory that is free right now."""
+        from .. import settings as gpp_settings
+        from ..optim.mll_batched import BATCHED_MAX_N
+
+        if not gpp_settings.batched_restarts.value():
+            return False
+        N = int(self.train_targets.shape[0])
+        if N > BATCHED_MAX_N:
+            return False
+        ld = max(16, (N + 15) // 16 * 16)
+        need = 3 * B * N * ld * 8
+        free, _ = torch.cuda.mem_get_info(self.tkwargs['device'])
+        return need <= free // 3
 
     def fill_nan_with_mean(self, train_x, cal_ID):
         if torch.isnan(train_x).any():

@@ -25,6 +25,13 @@ cholesky_max_tries = _Value(3)      # gpytorch.settings.cholesky_max_tries
 min_variance = _Value(1e-10)        # gpytorch.settings.min_variance (double)
 
 
+# Restart-parallel fits on ONE GPU: ``GP_Plus.fit()`` advances the reference's sequential restarts (optim/mll_torch.py:99-141)
+# together, one batched evaluation per Adam iteration (optim/mll_batched.py: same start points, same per-run Adam and early
+# stop, same winner), whenever the problem is small enough that one evaluation leaves the MI355X mostly idle.
+# ``with settings.batched_restarts(False):`` runs the restarts one after the other, exactly as the reference does.
+batched_restarts = _Value(True)
+
+
 # Sharded single evaluation (gp-plus_amd/sharded.py): ``with settings.sharded_evaluation({"group": None, "nb": 1024}):``
 # makes every exact-GP log-likelihood inside the block a cooperative evaluation by all ranks of the process group
 # (None = the default group).  Every rank must run the same model code with the same parameters.

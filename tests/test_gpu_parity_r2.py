@@ -210,8 +210,21 @@ def test_default_dtype_model_fit_and_predict(gpu_ctx, capsys):
     loss0, _ = _loss_and_grads(model)
     pre = model.predict(Xtest, return_std=False)
     rrmse0 = float(torch.sqrt(((pre.cpu() - ytest) ** 2).mean() / ytest.var()))
+    torch.manual_seed(1)
     with pytest.warns(UserWarning, match="adam_torch"):
         f_inc, hist = model.fit()  # default optim_type='scipy' on a GPU model: warning, Adam with 4 restarts (:563-567)
+    # fit() advanced the 5 runs together (settings.batched_restarts); the reference's sequential loop from the same seed
+    # visits the same start points and must produce the same histories (fp32 parameters: compared at 1e-4)
+    from gpplus_amd import settings as gpp_settings
+    torch.manual_seed(0)
+    seq = GP_Plus(Xtrain, ytrain, device="cuda")
+    torch.manual_seed(1)
+    with gpp_settings.batched_restarts(False), pytest.warns(UserWarning, match="adam_torch"):
+        f_seq, hist_seq = seq.fit()
+    assert [len(h) for h in hist_seq] == [len(h) for h in hist]
+    for a, b in zip(hist, hist_seq):
+        np.testing.assert_allclose(a, b, rtol=1e-4, atol=1e-6)
+    assert abs(f_inc - f_seq) <= 1e-4 * abs(f_seq)
     assert len(hist) == 5 and all(1 <= len(h) <= 100 for h in hist)
     assert f_inc < loss0 and abs(f_inc - min(h[-1] for h in hist)) < 1e-12
     out = capsys.readouterr().out
