@@ -198,6 +198,14 @@ class GppContext:
               "gpp_lauum_rows")
 
     @_on_own_device
+    def lauum_rows_range(self, Linv, Kinv, rank, nranks, row0, row1):
+        """The part of this rank's cyclic share of Kinv = Linv^T Linv inside rows [row0, row1) (needs the column blocks of
+        Linv up to row1 only)."""
+        self._stream()
+        check(self.lib.gpp_lauum_rows_range(self.h, Linv.data_ptr(), Linv.shape[0], _ld(Linv), Kinv.data_ptr(), _ld(Kinv), rank,
+                                            nranks, row0, row1), "gpp_lauum_rows_range")
+
+    @_on_own_device
     def mll_reduce(self, L, Linv, r, z, out3):
         for t, n in ((r, "r"), (z, "z"), (out3, "out3")):
             _need(t, torch.float64, n)

@@ -688,6 +688,28 @@ int gpp_lauum_rows(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, d
   return 0;
 }
 
+int gpp_lauum_rows_range(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double* Kinv, int64_t ldk, int rank,
+                         int nranks, int64_t row0, int64_t row1) {
+  if (!h) return -1;
+  if (N < 0) return -3;
+  if (int r = check_mat(Linv, ldi, N, 2)) return r;
+  if (int r = check_mat(Kinv, ldk, N, 5)) return r;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return -7;
+  if (row0 < 0 || row1 < row0 || row1 > N || (row0 % NBLK) != 0) return -9;
+  if (row1 == row0) return 0;
+  GemmArgs g = mk(Linv, ldi, Linv, ldi, Kinv, ldk, N, N, N, 1.0, 0.0);
+  g.a_mask = 2; g.b_mask = 2; g.klo_mode = 3; g.c_lower = 1; g.tag = 1;
+  g.row_mod = nranks; g.row_off = rank;
+  // owned tile rows are t = rank + nranks * i: those inside [row0, row1) have ceil((t0 - rank) / nranks) <= i < ceil((t1 - rank) / nranks)
+  const int64_t t0 = row0 / NBLK, t1 = (row1 + NBLK - 1) / NBLK;
+  auto first_i = [&](int64_t t) { return t <= rank ? (int64_t)0 : (t - rank + nranks - 1) / nranks; };
+  g.row_i0 = (int)first_i(t0);
+  g.row_i1 = (int)first_i(t1);
+  if (g.row_i1 <= g.row_i0) return 0;
+  GPP_TRY(gpp_launch_gemm(h->stream, 2, g, 1, NBLK, NBLK));
+  return 0;
+}
+
 int gpp_syrk_rows(gpp_handle_t h, const double* Urow, int64_t ldu, double* C, int64_t ldc, int64_t Nt, int64_t K, int64_t nb,
                   int64_t first_block, int rank, int nranks) {
   if (!h) return -1;

@@ -20,6 +20,8 @@
 // parameters BK, NBUF below).  Work-groups are independent along two batch dimensions (grid.y, grid.z).
 #include "gpp_internal.h"
 
+#include <algorithm>
+
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -203,8 +205,8 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
     if (tm >= p.tiles_m || tn >= p.tiles_n) return;
     if ((p.c_lower == 1 && tn > tm) || (p.c_lower == 2 && tn < tm)) return;
   } else {
-    const int t = blockIdx.x;
-    if (p.c_lower == 1 && p.row_mod > 1) {
+    const int t = blockIdx.x + (int)p.tile_base;
+    if (p.c_lower == 1 && p.row_mod >= 1) {
       // owned tile rows tm = row_off + row_mod * i, row i has tm + 1 tiles: S(i) = i (row_off + 1) + row_mod i (i-1) / 2
       const float a = 0.5f * (float)p.row_mod, b = (float)p.row_off + 1.f - a;
       int i = (int)((-b + sqrtf(b * b + 4.f * a * (float)t)) / (2.f * a));
@@ -505,11 +507,19 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int
   a.tiles_m = (a.M + tile_m - 1) / tile_m;
   a.tiles_n = (a.N + tile_n - 1) / tile_n;
   int64_t nt = a.c_lower ? (int64_t)a.tiles_m * (a.tiles_m + 1) / 2 : (int64_t)a.tiles_m * a.tiles_n;
-  if (a.c_lower == 1 && a.row_mod > 1) {
+  a.tile_base = 0;
+  if (a.c_lower == 1 && (a.row_mod > 1 || a.row_i1 > 0)) {
+    if (a.row_mod < 1) { a.row_mod = 1; a.row_off = 0; }
     if (a.row_off < 0 || a.row_off >= a.row_mod) return hipErrorInvalidValue;
     const int64_t rows = a.tiles_m > a.row_off ? (a.tiles_m - a.row_off + a.row_mod - 1) / a.row_mod : 0;
-    nt = rows * (a.row_off + 1) + (int64_t)a.row_mod * (rows * (rows - 1) / 2);
-    if (nt == 0) return hipSuccess;
+    // tiles before owned row i: S(i) = i (row_off + 1) + row_mod i (i - 1) / 2
+    auto S = [&](int64_t i) { return i * (a.row_off + 1) + (int64_t)a.row_mod * (i * (i - 1) / 2); };
+    const int64_t i0 = std::min<int64_t>(std::max(a.row_i0, 0), rows), i1 = a.row_i1 > 0 ? std::min<int64_t>(a.row_i1, rows) : rows;
+    if (i1 <= i0) return hipSuccess;
+    a.tile_base = S(i0);
+    nt = S(i1) - S(i0);
+  } else {
+    a.row_mod = 0;  // plain enumeration
   }
   a.swz = 0;
   // Measured on MI355X (N = 20000): the super-tile mapping LOSES 10-20 % against plain row-major order (row-major

@@ -55,6 +55,10 @@ struct GemmArgs {
   int row_limit;           // c_lower == 2 only: produce only the tiles whose rows lie below row_limit (a multiple of the tile;
                            // 0: all): the upper TRAPEZOID rows [0, row_limit) x columns [row, N) in one launch — other tiles
                            // of the triangular enumeration exit at once
+  int row_i0, row_i1;      // c_lower == 1 only: of the owned tile rows (index i = 0, 1, ... in increasing order) produce those
+                           // with row_i0 <= i < row_i1 (row_i1 == 0: all): the sharded LAUUM, block row by block row as the
+                           // column blocks of the inverse arrive
+  int64_t tile_base;       // set by the launcher: first tile index of this launch in the owned-row enumeration
   int row_mod, row_off;    // c_lower == 1 only: produce the tile rows tm with tm % row_mod == row_off (row_mod <= 1: all);
                            // the sharded LAUUM, one launch per rank over its cyclic share of the 128-row tile rows
 };

@@ -15,7 +15,9 @@ O(N^3) stages split by 1-D block-cyclic BLOCK ROWS of the upper-stored matrices 
   inverse  column blocks of L^-1 are independent forward substitutions against the (now replicated) factor: the owner of
            column block c sweeps Y_k = -L_kk^-1 sum_{j<k} L_kj Y_j right-looking (one wide TN GEMM per step); the column
            blocks are then broadcast so that every rank holds L^-1 (lower) and its mirror (upper).
-  lauum    every rank forms its tile-cyclic share (128-row tile rows) of Ky^-1 = L^-T L^-1 in one launch (no communication)
+  lauum    every rank forms its tile-cyclic share (128-row tile rows) of Ky^-1 = L^-T L^-1, block row c as soon as column
+           block c of the inverse has arrived (Ky^-1[i, j <= i] needs columns i and j only): the product runs on the main
+           stream while the side stream broadcasts the next column block
   grad     ``gpp_grad_reduce_rows`` over the same tile rows, then ONE all-reduce of D + 1 + S (+ N dU) doubles.
 
 Communication per evaluation: the packed factor slabs (4 N^2 B), the column blocks of the inverse (4 N^2 B) and the
@@ -84,7 +86,7 @@ class ShardedWorkspace:
         self.Li = square_buffer(N, dev)     # L^-1 (lower) + mirror (upper)
         self.Ki = square_buffer(N, dev)     # scratch, then the owned block rows of Ky^-1 (lower)
         self.ld = self.A.stride(0)
-        self.pack = torch.empty(N * nb, dtype=torch.float64, device=dev)
+        self.pack = torch.empty(2 * N * nb, dtype=torch.float64, device=dev)  # two slabs (factor rows / inverse column blocks)
         self.dbuf = torch.empty(nb * nb, dtype=torch.float64, device=dev)
         self.z = torch.empty(N, dtype=torch.float64, device=dev)
         self.alpha = torch.empty(N, dtype=torch.float64, device=dev)
@@ -208,24 +210,53 @@ def _inverse(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
             # diagonal, masked out: keep k >= n)
             ctx.gemm(1, 0, N - oj1, nbj, nbj, 1.0, A[oj:oj1, oj1:N], Li[oj:oj1, oj:oj1], 1.0, Li[oj1:N, oj:oj1], b_mask=2,
                      klo_mode=2)
+
+
+def _exchange_inverse(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, with_lauum: bool) -> None:
+    """Broadcast the column blocks of L^-1 (packed: the rows below each diagonal block) so that every rank holds L^-1 (lower)
+    and its mirror (upper) — and, when the gradient is wanted, PIPELINE this rank's share of Ky^-1 = L^-T L^-1 with the
+    broadcasts: Ky^-1[i, j <= i] needs the column blocks i and j of L^-1 only, so the tile rows of block row c are formed
+    (``gpp_lauum_rows_range``, on the calling stream) as soon as column block c has arrived, while the side stream moves
+    column block c+1.  4 N^2 bytes per GPU travel here against N^3 / (3 P) flops of product per GPU: at C5 on 8 GPUs 14 GB
+    beside 9e12 flop, i.e. comparable times — serialised they would add up."""
+    N, offs, P, me = ws.N, ws.offs, comm.world, comm.rank
+    nblk = len(offs) - 1
+    Li = ws.Li
+    main = torch.cuda.current_stream(ctx.index)
+    side, _ = ctx.internal_streams()
+    side.wait_stream(main)  # the sweeps that produced the owned column blocks
+    # two packing buffers so that the unpack of block c and the broadcast of block c+1 never share memory
+    half = ws.pack.numel() // 2
+    bounds, b = [], 0  # exclusive ends of the groups of block rows: halves of what is left, at most 6 groups
+    while b < nblk:
+        b = nblk if len(bounds) == 5 else b + max(1, (nblk - b + 1) // 2)
+        bounds.append(b)
+    group_start = 0
     for c in range(nblk):
         oc, oc1 = offs[c], offs[c + 1]
-        if oc1 >= N:
-            break  # the last column block is its diagonal block, which every rank already has
-        wc = oc1 - oc
-        buf = ws.pack[:(N - oc1) * wc].view(N - oc1, wc)
-        if c % P == me:
-            buf.copy_(Li[oc1:N, oc:oc1])
-        comm.bcast(buf, c % P)
-        if c % P != me:
-            Li[oc1:N, oc:oc1].copy_(buf)
-        Li[oc:oc1, oc1:N].copy_(buf.t())  # mirror
-
-
-def _lauum_rows(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
-    """This rank's share of Ky^-1 = L^-T L^-1 (lower triangle) into ws.Ki: the 128-row tile rows t with t % P == rank, in
-    ONE launch of the LAUUM kernel (tile-cyclic: balanced, and as efficient as the single-GPU launch)."""
-    ctx.lauum_rows(ws.Li, ws.Ki, comm.rank, comm.world)
+        if oc1 < N:
+            wc = oc1 - oc
+            with torch.cuda.stream(side):
+                base = (c & 1) * half
+                buf = ws.pack[base:base + (N - oc1) * wc].view(N - oc1, wc)
+                if c % P == me:
+                    buf.copy_(Li[oc1:N, oc:oc1])
+                comm.bcast(buf, c % P)
+                if c % P != me:
+                    Li[oc1:N, oc:oc1].copy_(buf)
+                Li[oc:oc1, oc1:N].copy_(buf.t())  # mirror
+        # (the last column block is its diagonal block, which every rank already has)
+        if with_lauum and c + 1 == bounds[0]:
+            # a GROUP of block rows per launch: one launch per block row leaves the early rows (a handful of tiles with the
+            # longest K ranges, several ms each) alone on the chip — measured with one rank at N = 20000: 70 ms for 20
+            # launches against 41 ms for the single launch.  Groups halve what is left ([0, 1/2), [1/2, 3/4), ...): every
+            # launch has hundreds of tiles, and the heavy early broadcasts still overlap the previous group's product.
+            arrived = torch.cuda.Event()
+            arrived.record(side)
+            main.wait_event(arrived)
+            ctx.lauum_rows_range(ws.Li, ws.Ki, me, P, offs[group_start], oc1)
+            group_start = bounds.pop(0)
+    main.wait_stream(side)
 
 
 class ShardedMLLFunction(torch.autograd.Function):
@@ -261,10 +292,15 @@ class ShardedMLLFunction(torch.autograd.Function):
             raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitters[-1]:.1e}.")
         if used > 0:
             warnings.warn(f"A not p.d., added jitter of {used:.1e} to the diagonal", RuntimeWarning)
+        need_grad = any(ctx.needs_input_grad[:6])
         with _stage("shard_inverse"):
             _inverse(gctx, comm, ws)
+            # (with a gradient: this rank's share of Ky^-1 is formed here too, block row by block row behind the broadcasts)
+            _exchange_inverse(gctx, comm, ws, with_lauum=need_grad)
         torch.sub(f64(y), f64(mean), out=ws.r)
         gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
+        if need_grad:
+            gctx.alpha(ws.Li, ws.z, ws.alpha)
         ctx.saved = (gctx, comm, ws, ws.epoch, Ud, wd, sd, grp, td.numel(), kind, d_split, dU)
         ctx.in_dtypes = (U.dtype, w.dtype, sf2.dtype, tau.dtype, mean.dtype, y.dtype)
         ctx.shapes = (sf2.shape, tau.shape)
@@ -278,10 +314,6 @@ class ShardedMLLFunction(torch.autograd.Function):
                                "before the next evaluation")
         N, D = Ud.shape
         dev = Ud.device
-        from .linalg import _stage
-        gctx.alpha(ws.Li, ws.z, ws.alpha)
-        with _stage("shard_lauum"):
-            _lauum_rows(gctx, comm, ws)
         need_U = ctx.needs_input_grad[0] and dU > 0
         nU = N * dU if need_U else 0
         flat = torch.zeros(D + 1 + S + nU, dtype=torch.float64, device=dev)

@@ -119,6 +119,13 @@ int gpp_syrk_rows(gpp_handle_t h, const double* Urow, int64_t ldu, double* C, in
  * Linv must be complete on this rank; the other tile rows of Kinv are not touched. */
 int gpp_lauum_rows(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double* Kinv, int64_t ldk, int rank, int nranks);
 
+/* The part of that share inside the rows [row0, row1) of Kinv (row0 a multiple of 128): what one rank can form as soon as
+ * the column blocks 0 .. row1 of the inverse have arrived — Kinv[i, j <= i] needs the columns i and j of Linv only — so the
+ * product is pipelined with the broadcasts of the inverse's column blocks (gp-plus_amd/sharded.py).  The reference has no
+ * counterpart (single-process ATen cholesky_backward, optim/mll_torch.py:117). */
+int gpp_lauum_rows_range(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double* Kinv, int64_t ldk, int rank,
+                         int nranks, int64_t row0, int64_t row1);
+
 /*
  * K6 (gpytorch MultivariateNormal.log_prob -> inv_quad_logdet, optim/mll_torch.py:116):
  *   z = Linv r;  out3 = { quad = z'z, logdet = 2 sum log U_ii, mll = -0.5*(quad + logdet + N log 2pi) }

@@ -32,6 +32,20 @@ def test_sharded_matches_single_gpu(N, D, nb, kind, S, dU):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,N,D,nb,kind,S,dU", [
+    (3, 8200, 6, 1024, 0, 1, 0),   # 9 block rows (8 x 1024 + 8) on 3 ranks: the look-ahead / batched inverse sweep at C5-like block counts
+    (4, 4500, 5, 512, 0, 2, 2),    # 9 block rows on 4 ranks: P does not divide the block count; per-group noise; manifold gradients
+    (3, 300, 4, 256, 0, 1, 0),     # 2 block rows on 3 ranks: a rank that owns nothing (P > number of block rows)
+    (4, 128, 3, 128, 0, 1, 0),     # one block: three idle ranks
+    (2, 2176, 7, 128, 1, 1, 0),    # 17 leaf-sized block rows (nb = 128): owners alternate every 128 rows; Matern 3/2
+])
+def test_sharded_more_ranks_and_block_counts(world, N, D, nb, kind, S, dU):
+    out = _run([N, D, nb, kind, S, dU], world=world, port=29560 + (N * 7 + world * 13 + nb) % 400)  # distinct rendezvous ports
+    for name, e in out["err"].items():
+        assert e < 1e-9, (name, e, out)
+
+
+@pytest.mark.gpu
 def test_sharded_through_gp_plus_api():
     """settings.sharded_evaluation routes GP_Plus's own loss through the cooperative evaluation (mixed-input model)."""
     out = _run([700, 8, 256, 0, 1, 2, "model"], port=29547)
