@@ -128,19 +128,22 @@ def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_spl
     the host waits (and afterwards runs the Python between forward and backward); a failed attempt just repeats it."""
     jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
     for jit in jitters:
-        with _stage("kernel_build"):
-            ctx.kernel_build(U, w, sf2, tau, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_UPPER)
         # The factorisation's launches (a DAG over the library's internal streams, ~1000 launches at N = 20000) run fastest
         # when they are enqueued while the device executes them, and measurably slower when they were parked in the
         # queues beforehand — N = 20000: potrf 55.7 ms when enqueued on an idle device, 58.0 when enqueued ~1 ms ahead
         # (behind the previous evaluation's gradient reduction), 58.7-59.3 when enqueued a whole evaluation ahead, and
         # the stages of the evaluation that is still running slow down as well (GPU_MAX_HW_QUEUES 4 / 8 / 16 alike; an
-        # idle pause alone changes nothing).  So the host waits HERE, for the covariance build just enqueued, which the
-        # factorisation needs anyway: the Python between two evaluations has overlapped the previous one's inverse
-        # stages by now and nothing is exposed.  bench.py at N = 20000 on one box: 151-153 ms per evaluation without
-        # this wait, 143-144 with it; C3 (N = 10000) 25.4-26.0 -> 24.3-24.8 ms.
+        # idle pause alone changes nothing).  So the host waits HERE for whatever is still running on this stream: the
+        # Python between two evaluations has overlapped the previous one's inverse stages by now and nothing is exposed.
+        # bench.py at N = 20000 on one box: 151-153 ms per evaluation without this wait, 143-144 with it; C3 (N = 10000)
+        # 25.4-26.0 -> 24.3-24.8 ms.
         if ws.N >= LOOKAHEAD_MIN_N:  # (below, the factorisation is a single-stream chain and the host is the bottleneck)
             torch.cuda.current_stream(ctx.index).synchronize()
+        # (Measured and NOT adopted: building the first diagonal block's columns first and handing them to the panel stream
+        #  while the rest of Ky is written — the build is an unmasked launch that floods every CU, the panel's 32 included,
+        #  so the first leaf waits for it anyway: 53.6 ms against 0.64 + 52.4.)
+        with _stage("kernel_build"):
+            ctx.kernel_build(U, w, sf2, tau, grp, ws.A, jitter=jit, kind=kind, d_split=d_split, uplo=UPLO_UPPER)
         with _stage("potrf"):
             ctx.potrf(ws.A, ws.Li, ws.info, ws.Ki)
         # the second host wait of an evaluation (the reference syncs on loss.item() too) covers the factorisation only: the
@@ -207,6 +210,9 @@ class ExactMLLFunction(torch.autograd.Function):
                 gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
             if not need_grad:
                 return
+            # (Measured and NOT adopted: z, the MLL scalars and alpha on a side stream beside the LAUUM launch — the extra
+            #  stream perturbs the hardware-queue mapping of the NEXT evaluation's factorisation DAG: potrf 53.3 -> 58-60 ms,
+            #  137 -> 142-144 ms per evaluation at N = 20000, tools/side_ab.py.)
             with _stage("alpha"):
                 gctx.alpha(ws.Li, ws.z, ws.alpha)
             with _stage("lauum"):

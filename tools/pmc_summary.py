@@ -5,8 +5,9 @@ import collections, csv, glob, os, re, sys
 
 def short(name):
     name = re.sub(r"^void ", "", name)
-    if name.startswith("at::native") or "at::native" in name[:60]:
-        m = re.search(r"at::native::(?:\(anonymous namespace\)::)?([A-Za-z_0-9]+)", name)
+    name = name.replace("(anonymous namespace)::", "")
+    if "at::native" in name[:60]:
+        m = re.search(r"at::native::([A-Za-z_0-9]+)", name)
         return "torch:" + (m.group(1) if m else "op")
     return re.sub(r"\(.*$", "", name)[:70]
 
