@@ -39,8 +39,11 @@ __global__ __launch_bounds__(256) void gpp_cov_tile(const double* __restrict__ U
                                                     int lower, int add_diag, double* __restrict__ K, int64_t ld,
                                                     int64_t row0, int tiles_n, int64_t tile_row0, int64_t sU, int64_t sK,
                                                     int S) {
-  __shared__ double sa[DMAX * TB];
-  __shared__ double sb[DMAX * TB];
+  // the two feature slabs, D x 64 doubles each, sized by the launch (dynamic LDS): with the static DMAX-sized arrays (64 KiB)
+  // only two work-groups fitted a CU and the exp chains had two waves per SIMD to hide behind
+  extern __shared__ __attribute__((aligned(16))) double cov_smem[];
+  double* sa = cov_smem;
+  double* sb = cov_smem + (size_t)D * TB;
   {  // batch element blockIdx.y: its own features (sU = 0: shared), weights, scale, noise levels and output matrix
     const int64_t b = blockIdx.y;
     Ua += b * sU;
@@ -90,11 +93,11 @@ __global__ __launch_bounds__(256) void gpp_cov_tile(const double* __restrict__ U
     for (int b = 0; b < 4; ++b) r2a[a][b] = r2b[a][b] = 0.0;
   const int dsp = (kind == 0) ? D : d_split;
   for (int d = 0; d < D; ++d) {
-    double ua[4], ub[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) ua[a] = sa[d * TB + 4 * ty + a];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) ub[b] = sb[d * TB + 4 * tx + b];
+    // the thread's 4 rows / 4 columns of feature d: one 32-byte LDS read each (two ds_read_b128, conflict-free)
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const v2d a01 = reinterpret_cast<const v2d*>(sa + d * TB + 4 * ty)[0], a23 = reinterpret_cast<const v2d*>(sa + d * TB + 4 * ty)[1];
+    const v2d b01 = reinterpret_cast<const v2d*>(sb + d * TB + 4 * tx)[0], b23 = reinterpret_cast<const v2d*>(sb + d * TB + 4 * tx)[1];
+    const double ua[4] = {a01.x, a01.y, a23.x, a23.y}, ub[4] = {b01.x, b01.y, b23.x, b23.y};
     if (d < dsp) {
 #pragma unroll
       for (int a = 0; a < 4; ++a)
@@ -143,12 +146,27 @@ __global__ __launch_bounds__(256) void gpp_cov_tile(const double* __restrict__ U
 
 }  // namespace
 
+// more than 48 KiB of dynamic LDS (D > 48 features) needs the opt-in, once per device
+static hipError_t cov_lds_optin(int D) {
+  if ((size_t)2 * D * TB * sizeof(double) <= 48 * 1024) return hipSuccess;
+  static bool done[64] = {false};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev >= 0 && dev < 64 && done[dev]) return hipSuccess;
+  e = hipFuncSetAttribute(reinterpret_cast<const void*>(gpp_cov_tile), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          2 * DMAX * TB * (int)sizeof(double));
+  if (e == hipSuccess && dev >= 0 && dev < 64) done[dev] = true;
+  return e;
+}
+
 hipError_t gpp_launch_kernel_build(hipStream_t s, const double* U, int64_t N, int D, const double* w, const double* sf2,
                                    const double* tau, const int32_t* grp, int S, double jitter, int kind, int d_split,
                                    int uplo, double* Ky, int64_t ld, int64_t row0, int64_t nrows, int batch, int64_t sU,
                                    int64_t sK) {
   if (N <= 0 || nrows <= 0 || batch <= 0) return hipSuccess;
   if (D > DMAX) return hipErrorInvalidValue;
+  if (hipError_t e = cov_lds_optin(D); e != hipSuccess) return e;
   const int64_t tr0 = row0 / TB;
   const int64_t tr1 = (row0 + nrows + TB - 1) / TB;  // exclusive
   const int tiles_n = (int)((N + TB - 1) / TB);
@@ -156,7 +174,7 @@ hipError_t gpp_launch_kernel_build(hipStream_t s, const double* U, int64_t N, in
   if (uplo) nt = tr1 * (tr1 + 1) / 2 - tr0 * (tr0 + 1) / 2;
   else nt = (tr1 - tr0) * tiles_n;
   // rows of the last tile row beyond row0+nrows are cut by passing Ma = row0+nrows
-  hipLaunchKernelGGL(gpp_cov_tile, dim3((unsigned)nt, (unsigned)batch), dim3(256), 0, s, U, row0 + nrows, U, N, D, w, sf2, tau,
+  hipLaunchKernelGGL(gpp_cov_tile, dim3((unsigned)nt, (unsigned)batch), dim3(256), (size_t)2 * D * TB * sizeof(double), s, U, row0 + nrows, U, N, D, w, sf2, tau,
                      grp, jitter, kind, d_split, uplo, 1, Ky, ld, row0, tiles_n, tr0, sU, sK, S);
   return hipGetLastError();
 }
@@ -165,9 +183,10 @@ hipError_t gpp_launch_cross_kernel(hipStream_t s, const double* Ua, int64_t Ma, 
                                    const double* w, const double* sf2, int kind, int d_split, double* Kab, int64_t ld) {
   if (Ma <= 0 || Nb <= 0) return hipSuccess;
   if (D > DMAX) return hipErrorInvalidValue;
+  if (hipError_t e = cov_lds_optin(D); e != hipSuccess) return e;
   const int tiles_n = (int)((Nb + TB - 1) / TB);
   const int64_t tiles_m = (Ma + TB - 1) / TB;
-  hipLaunchKernelGGL(gpp_cov_tile, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, s, Ua, Ma, Ub, Nb, D, w, sf2,
+  hipLaunchKernelGGL(gpp_cov_tile, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), (size_t)2 * D * TB * sizeof(double), s, Ua, Ma, Ub, Nb, D, w, sf2,
                      (const double*)nullptr, (const int32_t*)nullptr, 0.0, kind, d_split, 0, 0, Kab, ld, (int64_t)0,
                      tiles_n, (int64_t)0, (int64_t)0, (int64_t)0, 0);
   return hipGetLastError();

@@ -128,7 +128,9 @@ __device__ __forceinline__ void tile_from_index(int64_t t, int64_t& ti, int64_t&
   tj = t - r * (r + 1) / 2;
 }
 
-template <int DT>
+// MAT = false: pure RBF product (kind 0): no Matern distance / derivative registers, two waves per SIMD
+// HASU = false: no gradient w.r.t. feature columns (dU = 0): the 4 x 4 blocks of G are never materialised
+template <int DT, bool MAT, bool HASU>
 __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__ U, int64_t N, int D,
                                                       const double* __restrict__ w, const double* __restrict__ sf2p,
                                                       int kind, int d_split, const double* __restrict__ alpha, const double* __restrict__ Kinv,
@@ -148,8 +150,8 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
     wdiag += b * ws_stride;
     gUpart += b * ws_stride;
   }
-  __shared__ double sa[DT * GT];  // raw U rows of tile-row ti, [d][r]
-  __shared__ double sb[DT * GT];
+  __shared__ __attribute__((aligned(16))) double sa[DT * GT];  // raw U rows of tile-row ti, [d][r]
+  __shared__ __attribute__((aligned(16))) double sb[DT * GT];
   __shared__ double sal_a[GT], sal_b[GT];
   __shared__ double sw[DT];
   __shared__ double red[256];
@@ -187,60 +189,110 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
     // GM = mult * W_ij * dK_ij/d(-r2_mat)  for the Matern dims (d >= d_split), with K = sf2 e^{-r2_rbf} m(a):
     //      nu = 3/2: a = sqrt(6 r2_mat), m = (1+a)e^{-a},          dm/d(-r2_mat) = 3 e^{-a}
     //      nu = 5/2: a = sqrt(10 r2_mat), m = (1+a+a^2/3)e^{-a},   dm/d(-r2_mat) = (5/3)(1+a) e^{-a}
-    const int dsp = (kind == 0) ? DT : d_split;
-    double G[4][4], GM[4][4];
+    const int dsp = MAT ? d_split : DT;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    double G[4][4], GM[4][4];  // (GM only lives in the Matern instantiation; G / GM feed the g_U part below)
+    // Two half-tiles of 2 rows x 4 columns per thread, each with its own two passes over the features: the live set stays
+    // at 8 distances + 8 Kinv entries + 8 G values (two waves per SIMD), and every LDS access is a 16-byte read of
+    // consecutive rows / columns of one feature (conflict-free; 16 scalar reads at a 32-byte lane stride were 2-way conflicts).
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      const int ra = 4 * ty + 2 * h;  // first of this half's two rows inside the tile
+      double kin[2][4];
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      const int64_t i = i0 + 4 * ty + a;
+      for (int a = 0; a < 2; ++a) {
+        const int64_t i = i0 + ra + a, jb = j0 + 4 * tx;
+        const double* src = Kinv + (i < N ? i : N - 1) * ldk + jb;
+        if (jb + 4 <= ldk) {  // two 16-byte loads, issued before the arithmetic (entries above the diagonal are never used)
+          const v2d p0 = reinterpret_cast<const v2d*>(src)[0], p1 = reinterpret_cast<const v2d*>(src)[1];
+          kin[a][0] = p0.x; kin[a][1] = p0.y; kin[a][2] = p1.x; kin[a][3] = p1.y;
+        } else {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) {
-        const int64_t j = j0 + 4 * tx + b;
-        double g = 0.0, gm = 0.0;
-        if (i < N && j <= i) {
-          double r2 = 0.0, r2m = 0.0;
-#pragma unroll
-          for (int d = 0; d < DT; ++d) {
-            const double df = sa[d * GT + 4 * ty + a] - sb[d * GT + 4 * tx + b];
-            if (d < dsp) r2 = fma(sw[d] * df, df, r2);
-            else r2m = fma(sw[d] * df, df, r2m);
-          }
-          const double er = exp(-r2);
-          double kv = er, kd = 0.0;
-          if (kind == 1) {
-            const double aa = sqrt(6.0 * r2m), ea = exp(-aa);
-            kv = er * (1.0 + aa) * ea;
-            kd = er * 3.0 * ea;
-          } else if (kind == 2) {
-            const double aa = sqrt(10.0 * r2m), ea = exp(-aa);
-            kv = er * (1.0 + aa + aa * aa * (1.0 / 3.0)) * ea;
-            kd = er * (5.0 / 3.0) * (1.0 + aa) * ea;
-          }
-          const double Wij = 0.5 * (sal_a[4 * ty + a] * sal_b[4 * tx + b] - Kinv[i * ldk + j]);
-          const double mult = (i == j) ? 1.0 : 2.0;
-          my_sf2 = fma(mult * Wij, kv, my_sf2);
-          g = mult * Wij * sf2 * kv;
-          gm = mult * Wij * sf2 * kd;
-          if (i == j) wdiag[i] = Wij;
+          for (int b = 0; b < 4; ++b) kin[a][b] = (jb + b < N) ? src[b] : 0.0;
         }
-        G[a][b] = g;
-        GM[a][b] = gm;
       }
-    }
+      double r2[2][4], r2m[2][4];
 #pragma unroll
-    for (int d = 0; d < DT; ++d) {
-      double s = 0.0;
+      for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) r2[a][b] = r2m[a][b] = 0.0;
+#pragma unroll 4
+      for (int d = 0; d < DT; ++d) {
+        const v2d ua = *reinterpret_cast<const v2d*>(sa + d * GT + ra);
+        const v2d b01 = reinterpret_cast<const v2d*>(sb + d * GT + 4 * tx)[0], b23 = reinterpret_cast<const v2d*>(sb + d * GT + 4 * tx)[1];
+        const double ub[4] = {b01.x, b01.y, b23.x, b23.y};
+        const double wd = sw[d];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const double df = (a ? ua.y : ua.x) - ub[b];
+            if (!MAT || d < dsp) r2[a][b] = fma(wd * df, df, r2[a][b]);
+            else r2m[a][b] = fma(wd * df, df, r2m[a][b]);
+          }
+      }
+      // compiler barrier: without it the second pass below re-uses the first pass's LDS reads (same addresses), i.e. keeps
+      // 12 registers per feature alive across the exp section (DT = 16: 398 VGPRs, DT >= 32: spills)
+      __asm__ volatile("" ::: "memory");
+      double g2[2][4], gm2[2][4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int64_t i = i0 + ra + a;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const double df = sa[d * GT + 4 * ty + a] - sb[d * GT + 4 * tx + b];
-          s = fma(-((d < dsp) ? G[a][b] : GM[a][b]) * df, df, s);
+          const int64_t j = j0 + 4 * tx + b;
+          double g = 0.0, gm = 0.0;
+          if (i < N && j <= i) {
+            const double er = exp(-r2[a][b]);
+            double kv = er, kd = 0.0;
+            if (MAT && kind == 1) {
+              const double aa = sqrt(6.0 * r2m[a][b]), ea = exp(-aa);
+              kv = er * (1.0 + aa) * ea;
+              kd = er * 3.0 * ea;
+            } else if (MAT && kind == 2) {
+              const double aa = sqrt(10.0 * r2m[a][b]), ea = exp(-aa);
+              kv = er * (1.0 + aa + aa * aa * (1.0 / 3.0)) * ea;
+              kd = er * (5.0 / 3.0) * (1.0 + aa) * ea;
+            }
+            const double Wij = 0.5 * (sal_a[ra + a] * sal_b[4 * tx + b] - kin[a][b]);
+            const double mult = (i == j) ? 1.0 : 2.0;
+            my_sf2 = fma(mult * Wij, kv, my_sf2);
+            g = mult * Wij * sf2 * kv;
+            gm = mult * Wij * sf2 * kd;
+            if (i == j) wdiag[i] = Wij;
+          }
+          g2[a][b] = g;
+          gm2[a][b] = gm;
         }
-      my_w[d] += s;
+      }
+#pragma unroll
+      for (int d = 0; d < DT; ++d) {
+        const v2d ua = *reinterpret_cast<const v2d*>(sa + d * GT + ra);
+        const v2d b01 = reinterpret_cast<const v2d*>(sb + d * GT + 4 * tx)[0], b23 = reinterpret_cast<const v2d*>(sb + d * GT + 4 * tx)[1];
+        const double ub[4] = {b01.x, b01.y, b23.x, b23.y};
+        double s = 0.0;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            const double df = (a ? ua.y : ua.x) - ub[b];
+            s = fma(-((!MAT || d < dsp) ? g2[a][b] : gm2[a][b]) * df, df, s);
+          }
+        my_w[d] += s;
+      }
+      if constexpr (HASU) {  // the manifold-gradient part below wants the whole 4 x 4 block
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            if (h == 0) { G[a][b] = g2[a][b]; GM[a][b] = gm2[a][b]; }
+            else { G[2 + a][b] = g2[a][b]; GM[2 + a][b] = gm2[a][b]; }
+          }
+      }
     }
-    for (int d = 0; d < dU; ++d) {
+    for (int d = 0; HASU && d < dU; ++d) {
       const double m2w = -2.0 * sw[d];
-      const bool rbf_dim = d < dsp;
+      const bool rbf_dim = !MAT || d < dsp;
       double rs[4], cs[4];
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -420,14 +472,19 @@ hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int
     hipError_t e = hipMemsetAsync(ws, 0, (size_t)batch * ws_stride * sizeof(double), s);
     if (e != hipSuccess) return e;
   }
-#define GPP_GRAD_LAUNCH(DT)                                                                                              \
-  hipLaunchKernelGGL(gpp_grad_tiles<DT>, dim3(nwg, batch), dim3(256), 0, s, U, N, D, w, sf2, kind, d_split, alpha, Kinv, ldk, dU, \
-                     ntiles, shard_nb, shard_rank, shard_nranks, sU, sK, sv, ws_stride, rec, wdiag, gUpart)
-  if (D <= 8) GPP_GRAD_LAUNCH(8);
-  else if (D <= 16) GPP_GRAD_LAUNCH(16);
-  else if (D <= 32) GPP_GRAD_LAUNCH(32);
-  else GPP_GRAD_LAUNCH(64);
-#undef GPP_GRAD_LAUNCH
+  auto launch = [&](auto kern) {
+    hipLaunchKernelGGL(kern, dim3(nwg, batch), dim3(256), 0, s, U, N, D, w, sf2, kind, d_split, alpha, Kinv, ldk, dU, ntiles,
+                       shard_nb, shard_rank, shard_nranks, sU, sK, sv, ws_stride, rec, wdiag, gUpart);
+  };
+  const bool mat = kind != 0, hasu = dU > 0;
+#define GPP_GT(DT)                                                                                                   \
+  (mat ? (hasu ? launch(gpp_grad_tiles<DT, true, true>) : launch(gpp_grad_tiles<DT, true, false>))                   \
+       : (hasu ? launch(gpp_grad_tiles<DT, false, true>) : launch(gpp_grad_tiles<DT, false, false>)))
+  if (D <= 8) GPP_GT(8);
+  else if (D <= 16) GPP_GT(16);
+  else if (D <= 32) GPP_GT(32);
+  else GPP_GT(64);
+#undef GPP_GT
   hipLaunchKernelGGL(gpp_grad_finish, dim3(D + 1 + S, batch), dim3(256), 0, s, rec, nwg, D, S, wdiag, grp, N, g_w, g_sf2, g_tau,
                      ws_stride);
   if (dU > 0)
