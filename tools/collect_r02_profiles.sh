@@ -15,11 +15,14 @@ rocprofv3 --kernel-trace --output-format csv --pmc TCC_HIT_sum TCC_MISS_sum SQ_L
 # 3) HBM-side traffic of the factorisation alone (build + potrf stages only), FETCH_SIZE and WRITE_SIZE in separate passes
 STAGES_ONLY=build,potrf rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmcF -o a -- python3 tools/bench_stages.py 20000 8 1 > $OUT/pmcF.log 2>&1
 STAGES_ONLY=build,potrf rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmcW -o a -- python3 tools/bench_stages.py 20000 8 1 > $OUT/pmcW.log 2>&1
+# 3b) the same two passes over the whole evaluation (the LAUUM launch, TAG 1, and the N^2 kernels)
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $OUT/pmcF2 -o a -- python3 tools/bench_stages.py 20000 8 1 > $OUT/pmcF2.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $OUT/pmcW2 -o a -- python3 tools/bench_stages.py 20000 8 1 > $OUT/pmcW2.log 2>&1
 # 4) timeline of the factorisation (kernel trace only): per-queue busy time, update-queue gaps, tail windows
 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace -o t -- python3 tools/bench_stages.py 20000 8 2 > $OUT/trace.log 2>&1
 python3 tools/trace_lookahead.py $OUT/trace 30 > $OUT/trace_lookahead.txt 2>&1
 python3 tools/trace_tail.py $OUT/trace 2 > $OUT/trace_tail.txt 2>&1
-for d in pmcA pmcB pmcF pmcW; do python3 tools/pmc_summary.py $OUT/$d > $OUT/${d}_summary.txt 2>&1; done
+for d in pmcA pmcB pmcF pmcW pmcF2 pmcW2; do python3 tools/pmc_summary.py $OUT/$d > $OUT/${d}_summary.txt 2>&1; done
 find $OUT -name "*kernel_stats.csv" | head -3
 # keep the merge under the 64 MiB limit: drop the raw per-dispatch CSVs, keep the summaries and the stats
 find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
