@@ -423,6 +423,7 @@ def main():
     ap.add_argument("--sharded-n", type=int, default=60000, help="size of the sharded leg (C5)")
     ap.add_argument("--sharded-steps", type=int, default=2)
     ap.add_argument("--sharded-warmup", type=int, default=1)
+    ap.add_argument("--sharded-timeout", type=float, default=600.0, help="seconds before rank 0 gives up on the sharded leg")
     ap.add_argument("--dry-run", action="store_true", help="exercise the launch path only (gloo, no GPU work)")
     args = ap.parse_args()
 
@@ -461,10 +462,26 @@ def main():
             # the second leg must never cost the first its JSON line: a failure is reported inside the line (all ranks reach
             # the same branch: the sharded evaluation fails or succeeds collectively, and a hang is bounded by the
             # process-group timeout)
+            # ... and neither can a hang (the RCCL branch of the sharded evaluation has never run on real links): after
+            # ``--sharded-timeout`` seconds rank 0 prints the replica line with the failure recorded and leaves
+            watchdog = None
+            if rank == 0 and args.sharded_timeout > 0:
+                import threading
+
+                def give_up():
+                    out["sharded"] = {"error": f"no result within {args.sharded_timeout} s (hang in the sharded leg)"}
+                    print(json.dumps(out), flush=True)
+                    os._exit(0)
+
+                watchdog = threading.Timer(args.sharded_timeout, give_up)
+                watchdog.daemon = True
+                watchdog.start()
             try:
                 sh = run_sharded(args, dist, dev, rank, world, args.sharded_n, args.sharded_steps, args.sharded_warmup)
             except Exception as exc:  # noqa: BLE001
                 sh = {"error": f"{type(exc).__name__}: {exc}"[:500]}
+            if watchdog is not None:
+                watchdog.cancel()
             if rank == 0:
                 out["sharded"] = sh
     else:

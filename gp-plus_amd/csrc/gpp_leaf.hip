@@ -17,8 +17,7 @@
 //       LDS with its diagonal replaced by the reciprocals 1/L_cc;
 //   (3) panel rows are solved by forward substitution, one lane per row, against broadcast LDS reads of that tile
 //       (no 16 x 16 inverse on the critical path);
-//   (4) trailing tiles acc(i,j) -= L(i,s) L(j,s)^T on the MFMA (four v_mfma_f64_4x4x4_4b per 16x16x4 step: they issue
-//       every 16 cycles on gfx950, v_mfma_f64_16x16x4 only every ~138, tools/mfma_probe.hip).
+//   (4) trailing tiles acc(i,j) -= L(i,s) L(j,s)^T on the MFMA (one v_mfma_f64_16x16x4_f64 per 16x16x4 step).
 // Then the 8 diagonal tiles are inverted in parallel (2 per wave, lane per column) and the inverse is assembled by
 // pair merging at tile level (sizes 16, 32, 64): X21 = -X22 (L21 X11), MFMA again.
 #include "gpp_internal.h"
@@ -92,7 +91,7 @@ __device__ __forceinline__ LaneOff lane_offsets(int lane) {
 // requested together, and the callers request the NEXT product's fragments before issuing this one's 16 MFMAs, so the
 // LDS latency hides behind the matrix pipe instead of preceding every instruction.
 struct Frag {
-  double a[4][4];  // [kk][rb]: rows 4rb + (l&3), k = 4kk + (l>>4) of At
+  double a[4];     // [kk]: At[row = l&15][k = 4kk + (l>>4)]  (v_mfma_f64_16x16x4_f64 A operand; the "tile^T" read pattern)
   double b[4];     // [kk]: B[k = 4kk + (l>>4)][n = l&15]
 };
 // KN: B is stored [k][n] (merge products);  !KN: B is stored [n][k], i.e. the product is At * Bt^T (trailing update)
@@ -104,15 +103,13 @@ __device__ __forceinline__ void load_frag(Frag& f, const double* At, const doubl
     f.b[kk] = NEG ? -v : v;
   }
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) f.a[kk][rb] = At[o.a[rb & 1] + 64 * rb + ((4 * kk) ^ (4 * (rb >> 1)))];
+  for (int kk = 0; kk < 4; ++kk) f.a[kk] = At[o.rk[kk & 1] + 8 * (kk >> 1)];
 }
+// one v_mfma_f64_16x16x4_f64 per k-step of 4 (round 1 issued four 4x4x4 forms with broadcast A fragments: 16 + 4 LDS reads and
+// 16 MFMAs per tile product where 4 + 4 and 4 do; the accumulator layout — row (l>>4) + 4v, col l&15 — is the same)
 __device__ __forceinline__ void mma_frag(v4d& acc, const Frag& f) {
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-    for (int rb = 0; rb < 4; ++rb) acc[rb] = __builtin_amdgcn_mfma_f64_4x4x4f64(f.a[kk][rb], f.b[kk], acc[rb], 0, 0, 0);
+  for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(f.a[kk], f.b[kk], acc, 0, 0, 0);
 }
 // t += sgn * sum_{k=k0}^{k1} tile(i,k) * tile(k,j)   (k1 >= k0), double-buffered over k
 template <bool NEG>
