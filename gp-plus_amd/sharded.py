@@ -228,6 +228,8 @@ def _exchange_inverse(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, with_l
     # two packing buffers so that the unpack of block c and the broadcast of block c+1 never share memory
     half = ws.pack.numel() // 2
     bounds, b = [], 0  # exclusive ends of the groups of block rows: halves of what is left, at most 6 groups
+    if P == 1:
+        bounds, b = [nblk], nblk  # nothing travels: one launch, as on the single-GPU path
     while b < nblk:
         b = nblk if len(bounds) == 5 else b + max(1, (nblk - b + 1) // 2)
         bounds.append(b)

@@ -12,11 +12,13 @@ def _run(args, world=2, port=29531):
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "workers", "sharded_worker.py")] + [str(a) for a in args]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    res = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")]
-    same = [l for l in p.stdout.splitlines() if "same_as_rank0=" in l]
+    import re
+    # (robust against ranks sharing a line of the launcher's pipe: parse from the marker, not by lines)
+    res = [json.JSONDecoder().raw_decode(p.stdout, m.end())[0] for m in re.finditer(r"RESULT (?=\{)", p.stdout)]
+    same = re.findall(r"same_as_rank0=(True|False)", p.stdout)
     assert len(res) == 1 and len(same) == world, p.stdout[-3000:]
-    assert all(l.endswith("True") for l in same), same
-    return json.loads(res[0][7:])
+    assert all(v == "True" for v in same), same
+    return res[0]
 
 
 @pytest.mark.gpu

@@ -3,6 +3,14 @@ ranks (the 1-GPU test box) the ranks share cuda:0 and talk over gloo (host-stage
 the backend is nccl (= RCCL).  Every rank evaluates the sharded MLL + gradients and rank 0 compares them with the
 single-GPU path on the same inputs."""
 import os, sys, json
+
+
+def emit(line: str) -> None:
+    """One write() per line: the ranks share the launcher's stdout pipe, and print() may split a line into two writes that
+    interleave with another rank's."""
+    sys.stdout.flush()
+    os.write(1, (line + "\n").encode())
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -37,8 +45,8 @@ def model_case(rank, world, dev, N, nb):
         out[mode] = torch.cat([loss.detach().reshape(1)] + [p.grad.reshape(-1) for p in m.parameters() if p.requires_grad]).cpu()
     if rank == 0:
         e = float((out["sharded"] - out["single"]).abs().max() / out["single"].abs().max())
-        print("RESULT " + json.dumps({"err": {"loss_and_grads": e}, "mll": float(out["single"][0]), "backend": dist.get_backend()}), flush=True)
-    print(f"RANK{rank} same_as_rank0=True", flush=True)
+        emit("RESULT " + json.dumps({"err": {"loss_and_grads": e}, "mll": float(out["single"][0]), "backend": dist.get_backend()}))
+    emit(f"RANK{rank} same_as_rank0=True")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -87,8 +95,8 @@ def main():
         err = {}
         for n, a, b in zip(names, res["sharded"], res["single"]):
             err[n] = float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
-        print("RESULT " + json.dumps({"err": err, "mll": float(res["single"][0]), "backend": dist.get_backend()}), flush=True)
-    print(f"RANK{rank} same_as_rank0={same}", flush=True)
+        emit("RESULT " + json.dumps({"err": err, "mll": float(res["single"][0]), "backend": dist.get_backend()}))
+    emit(f"RANK{rank} same_as_rank0={same}")
     dist.barrier()
     dist.destroy_process_group()
 
