@@ -6,13 +6,12 @@
 //     (replace ATen cholesky_backward, reference call site optim/mll_torch.py:117)
 //   - V = K_*N Linv^T of the prediction path (models/gpregression.py:122-149).
 //
-// Design (CDNA4, measured on MI355X — tools/mfma_probe.hip): v_mfma_f64_16x16x4_f64 issues only every ~105-140
-// cycles per SIMD (<= 48 TFLOP/s chip-wide), while v_mfma_f64_4x4x4_4b_f64 issues every 16 cycles (512 flop:
-// 32 flop/clk/SIMD, the 78.6 TFLOP/s fp64 peak).  Its cbsz/abid broadcast is ignored for f64, so the kernel
-// broadcasts in the LDS read instead: the A fragment of a 4-row block is loaded with the same address in the four
-// 4-lane column groups, the B fragment is a plain 16-column x 4-k fragment, and one MFMA yields a 4 x 16 slab of C
-// (lane l: row l>>4, col l&15).  A (2*WT)^2 output tile per 256-thread work-group, 2x2 waves; each wave owns
-// WT x WT = (WT/4) x (WT/16) such slabs (WT=64: 64 accumulator doubles per lane).  K is consumed in chunks of 16;
+// Design (CDNA4, measured on MI355X): v_mfma_f64_16x16x4_f64 — lane l supplies A[row l%16][k l/16] and B[k l/16][col l%16] and
+// holds D[row (l/16) + 4v][col l%16] in element v of its 4-double accumulator (tools/mfma16_layout.hip).  A bare loop of the
+// instruction sustains 69.6 TFLOP/s chip-wide, the rate rocBLAS's MI16x16x4 DGEMM kernels reach too (72.9); the round-1 kernel
+// used the 4x4x4_4b form on the strength of a probe that had measured hipcc's AGPR copies (profiles/r02_mfma_f64_16x16x4.txt).
+// A (2*WT)^2 output tile per 256-thread work-group, 2x2 waves; each wave owns WT x WT = (WT/16)^2 blocks of 16 x 16
+// (WT=64: 64 accumulator doubles per lane, in VGPRs: __launch_bounds__(256, 2)).  K is consumed in chunks of 16;
 // both operand chunks are staged in LDS in [k][row] order (padded strides, see ldt_*), double-buffered: the global
 // loads of chunk c+1 are issued before the MFMAs of chunk c and written to the other buffer afterwards, one barrier
 // per chunk.  WT = 32 / 16 variants (64^2 / 32^2 tiles) and a 128 x 32 tile serve the small sub-problems, where the

@@ -67,8 +67,8 @@ __device__ __forceinline__ void fnma_bcast16(double& acc, double l, double m) {
 
 // Per-lane element offsets inside a tile for the three MFMA fragment shapes, swizzle folded in so that every LDS read
 // is "tile base + lane offset + immediate".  With lr = lane>>4, lc = lane&15, i = lane&3:
-//  A operand of v_mfma_f64_4x4x4_4b (rows 4rb+i, k = 4kk+lr; same 4x4 block in all four lane groups = LDS broadcast):
-//      tix = a[rb&1] + 64 rb + (4kk ^ 4(rb>>1))
+//  (a[]: offsets of the round-1 4x4x4 A fragments, rows 4rb+i, k = 4kk+lr: tix = a[rb&1] + 64 rb + (4kk ^ 4(rb>>1)); kept for
+//   the probes, the tile products read A through the "tile^T" pattern below now)
 //  B operand "tile^T" (n = lc, k = 4kk+lr reads tile[n][k]):      tix = rk[kk&1] + 8 (kk>>1)
 //  B operand "tile"   (k = 4kk+lr, n = lc reads tile[k][n]) and the C/D layout (row lr+4r, col lc): tix = kn[kk]
 struct LaneOff {
