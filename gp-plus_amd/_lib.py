@@ -40,6 +40,7 @@ _SIGNATURES = {
     "gpp_syrk_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int]),
     "gpp_lauum_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int]),
     "gpp_lauum_rows_range": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_int64]),
+    "gpp_transpose": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64]),
     "gpp_mll_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_void_p]),
     "gpp_alpha": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "gpp_grad_reduce": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

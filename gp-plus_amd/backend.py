@@ -206,6 +206,15 @@ class GppContext:
                                             nranks, row0, row1), "gpp_lauum_rows_range")
 
     @_on_own_device
+    def transpose(self, src, dst):
+        """dst = src^T, out of place (2-D views with unit column stride)."""
+        if src.shape[0] != dst.shape[1] or src.shape[1] != dst.shape[0]:
+            raise GppError("transpose: shapes do not match")
+        self._stream()
+        check(self.lib.gpp_transpose(self.h, src.data_ptr(), src.stride(0), src.shape[0], src.shape[1], dst.data_ptr(), dst.stride(0)),
+              "gpp_transpose")
+
+    @_on_own_device
     def mll_reduce(self, L, Linv, r, z, out3):
         for t, n in ((r, "r"), (z, "z"), (out3, "out3")):
             _need(t, torch.float64, n)

@@ -718,6 +718,15 @@ int gpp_lauum_rows_range(gpp_handle_t h, const double* Linv, int64_t N, int64_t 
   return 0;
 }
 
+int gpp_transpose(gpp_handle_t h, const double* src, int64_t lds, int64_t rows, int64_t cols, double* dst, int64_t ldd) {
+  if (!h) return -1;
+  if (!src || lds < cols) return -2;
+  if (rows < 0 || cols < 0) return -4;
+  if (!dst || ldd < rows) return -6;
+  GPP_TRY(gpp_launch_transpose(h->stream, src, lds, rows, cols, dst, ldd));
+  return 0;
+}
+
 int gpp_syrk_rows(gpp_handle_t h, const double* Urow, int64_t ldu, double* C, int64_t ldc, int64_t Nt, int64_t K, int64_t nb,
                   int64_t first_block, int rank, int nranks) {
   if (!h) return -1;

@@ -98,6 +98,8 @@ hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int
                                   int shard_nranks = 1, int batch = 1, int64_t sU = 0, int64_t sK = 0, int64_t sv = 0);
 // (batch > 1: U + b*sU, w + b*D, sf2 + b, alpha + b*sv, Kinv + b*sK; outputs g_w + b*D, g_sf2 + b, g_tau + b*S,
 //  g_U + b*N*dU; the workspace holds batch * gpp_grad_ws_bytes)
+// dst[c][r] = src[r][c] for r < rows, c < cols (64 x 64 tiles through LDS)
+hipError_t gpp_launch_transpose(hipStream_t s, const double* src, int64_t lds, int64_t rows, int64_t cols, double* dst, int64_t ldd);
 hipError_t gpp_launch_predict_reduce(hipStream_t s, const double* Ksn, int64_t lds, const double* V, int64_t ldv,
                                      int64_t M, int64_t N, const double* alpha, const double* kss, double* mean_out,
                                      double* var_out);

@@ -501,3 +501,31 @@ hipError_t gpp_launch_predict_reduce(hipStream_t s, const double* Ksn, int64_t l
                      mean_out, var_out);
   return hipGetLastError();
 }
+
+// ---- out-of-place transpose (the mirror L^-T of the sharded evaluation's column blocks) --------------------------------
+namespace {
+__global__ __launch_bounds__(256) void gpp_transpose_tile(const double* __restrict__ src, int64_t lds, int64_t rows, int64_t cols,
+                                                          double* __restrict__ dst, int64_t ldd) {
+  __shared__ double tile[64][65];  // padded: the transposed read walks a column
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4 threads, 16 passes
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[r * lds + c] : 0.0;
+  }
+  __syncthreads();
+#pragma unroll 4
+  for (int i = ty; i < 64; i += 4) {
+    const int64_t c = c0 + i, r = r0 + tx;  // dst row = source column
+    if (c < cols && r < rows) dst[c * ldd + r] = tile[tx][i];
+  }
+}
+}  // namespace
+
+hipError_t gpp_launch_transpose(hipStream_t s, const double* src, int64_t lds, int64_t rows, int64_t cols, double* dst, int64_t ldd) {
+  if (rows <= 0 || cols <= 0) return hipSuccess;
+  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+  hipLaunchKernelGGL(gpp_transpose_tile, grid, dim3(256), 0, s, src, lds, rows, cols, dst, ldd);
+  return hipGetLastError();
+}

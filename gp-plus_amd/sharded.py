@@ -239,14 +239,15 @@ def _exchange_inverse(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, with_l
         if oc1 < N:
             wc = oc1 - oc
             with torch.cuda.stream(side):
-                base = (c & 1) * half
-                buf = ws.pack[base:base + (N - oc1) * wc].view(N - oc1, wc)
-                if c % P == me:
-                    buf.copy_(Li[oc1:N, oc:oc1])
-                comm.bcast(buf, c % P)
-                if c % P != me:
-                    Li[oc1:N, oc:oc1].copy_(buf)
-                Li[oc:oc1, oc1:N].copy_(buf.t())  # mirror
+                if P > 1:
+                    base = (c & 1) * half
+                    buf = ws.pack[base:base + (N - oc1) * wc].view(N - oc1, wc)
+                    if c % P == me:
+                        buf.copy_(Li[oc1:N, oc:oc1])
+                    comm.bcast(buf, c % P)
+                    if c % P != me:
+                        Li[oc1:N, oc:oc1].copy_(buf)
+                ctx.transpose(Li[oc1:N, oc:oc1], Li[oc:oc1, oc1:N])  # mirror (tiled through LDS: gpp_transpose)
         # (the last column block is its diagonal block, which every rank already has)
         if with_lauum and c + 1 == bounds[0]:
             # a GROUP of block rows per launch: one launch per block row leaves the early rows (a handful of tiles with the

@@ -126,6 +126,10 @@ int gpp_lauum_rows(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, d
 int gpp_lauum_rows_range(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double* Kinv, int64_t ldk, int rank,
                          int nranks, int64_t row0, int64_t row1);
 
+/* dst[c][r] = src[r][c] (rows x cols, out of place, 64 x 64 tiles through LDS): the mirror L^-T of a column block of the inverse
+ * that arrived from another rank (gp-plus_amd/sharded.py); on the single-GPU path the mirror is written by the GEMM epilogue. */
+int gpp_transpose(gpp_handle_t h, const double* src, int64_t lds, int64_t rows, int64_t cols, double* dst, int64_t ldd);
+
 /*
  * K6 (gpytorch MultivariateNormal.log_prob -> inv_quad_logdet, optim/mll_torch.py:116):
  *   z = Linv r;  out3 = { quad = z'z, logdet = 2 sum log U_ii, mll = -0.5*(quad + logdet + N log 2pi) }
