@@ -169,6 +169,8 @@ hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv
     g1.b_mask = 2; g1.klo_mode = 2; g1.col_major = 1;  // K range depends on the column tile: keep columns together
     g1.sA = pstride_U; g1.sB = pstride_I; g1.sC = pstride_T;
     g1.batch2 = mbatch; g1.zA = msU; g1.zB = msLi; g1.zC = msT;  // independent matrices (batched evaluation)
+    static const bool bf = !(getenv("GPP_BATCH_FAST") && atoi(getenv("GPP_BATCH_FAST")) == 0);  // experiment knob
+    g1.batch_fast = bf;  // the pairs' tiles of equal K run together: the launch ends on every pair's short tiles
     hipError_t e = gpp_launch_gemm(st, 2, g1, batch, g1_tile, g1_tile);
     if (e != hipSuccess) return e;
     if (before_g2) {  // W22 comes from another stream (the look-ahead's bordering: the first product does not need it)
@@ -182,6 +184,7 @@ hipError_t trtri_level(hipStream_t st, const double* U, int64_t ld, double* Linv
     g2.sA = pstride_I; g2.sB = pstride_T; g2.sC = pstride_I;
     g2.C2 = Linv + o * ldi + (o + s); g2.ldc2 = ldi; g2.sC2 = pstride_I;
     g2.batch2 = mbatch; g2.zA = msLi; g2.zB = msT; g2.zC = msLi; g2.zC2 = msLi;
+    g2.batch_fast = bf;
     return gpp_launch_gemm(st, 2, g2, batch);
   };
   // full pairs: batched over maximal runs of pairs that still need merging

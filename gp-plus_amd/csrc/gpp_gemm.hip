@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
     if (tm >= p.tiles_m || tn >= p.tiles_n) return;
     if ((p.c_lower == 1 && tn > tm) || (p.c_lower == 2 && tn < tm)) return;
   } else {
-    const int t = blockIdx.x + (int)p.tile_base;
+    const int t = (p.batch_fast ? (int)(blockIdx.x / (unsigned)p.nbatch) : (int)blockIdx.x) + (int)p.tile_base;
     if (p.c_lower == 1 && p.row_mod >= 1) {
       // owned tile rows tm = row_off + row_mod * i, row i has tm + 1 tiles: S(i) = i (row_off + 1) + row_mod i (i-1) / 2
       const float a = 0.5f * (float)p.row_mod, b = (float)p.row_off + 1.f - a;
@@ -238,9 +238,10 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
       if (p.row_reverse) tm = p.tiles_m - 1 - tm;  // longest K ranges (khi grows with the row) first: short tail
     }
   }
-  const double* __restrict__ A = p.A + (int64_t)blockIdx.y * p.sA + (int64_t)blockIdx.z * p.zA;
-  const double* __restrict__ B = p.B + (int64_t)blockIdx.y * p.sB + (int64_t)blockIdx.z * p.zB;
-  double* __restrict__ C = p.C + (int64_t)blockIdx.y * p.sC + (int64_t)blockIdx.z * p.zC;
+  const int64_t bi = p.batch_fast ? (int64_t)(blockIdx.x % (unsigned)p.nbatch) : (int64_t)blockIdx.y;  // batch element
+  const double* __restrict__ A = p.A + bi * p.sA + (int64_t)blockIdx.z * p.zA;
+  const double* __restrict__ B = p.B + bi * p.sB + (int64_t)blockIdx.z * p.zB;
+  double* __restrict__ C = p.C + bi * p.sC + (int64_t)blockIdx.z * p.zC;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -436,7 +437,7 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
         if (ok) {
           C[(int64_t)m * p.ldc + n] = v;
           if (p.C2)  // mirrored (transposed) copy
-            p.C2[(int64_t)blockIdx.y * p.sC2 + (int64_t)blockIdx.z * p.zC2 + (int64_t)n * p.ldc2 + m] = v;
+            p.C2[bi * p.sC2 + (int64_t)blockIdx.z * p.zC2 + (int64_t)n * p.ldc2 + m] = v;
         }
       }
     }
@@ -531,6 +532,12 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int
   }
   const int batch2 = a.batch2 > 1 ? a.batch2 : 1;
   dim3 grid((unsigned)nt, (unsigned)batch, (unsigned)batch2);
+  if (a.batch_fast && batch > 1 && !a.swz && nt * batch < (int64_t)1 << 31) {
+    a.nbatch = batch;
+    grid = dim3((unsigned)(nt * batch), 1u, (unsigned)batch2);
+  } else {
+    a.batch_fast = 0;
+  }
   switch (variant) {
     case 0: return launch_var<0>(s, tile_m, tile_n, grid, a);
     case 1: return launch_var<1>(s, tile_m, tile_n, grid, a);

@@ -55,6 +55,9 @@ struct GemmArgs {
   int row_limit;           // c_lower == 2 only: produce only the tiles whose rows lie below row_limit (a multiple of the tile;
                            // 0: all): the upper TRAPEZOID rows [0, row_limit) x columns [row, N) in one launch — other tiles
                            // of the triangular enumeration exit at once
+  int batch_fast, nbatch;  // batch_fast: one grid dimension, tile-major with the batch element as the FAST index (nbatch of them),
+                           // so that tiles of equal K length of all batch elements run together and the launch ends on the
+                           // shortest tiles of every element (pair merges of gpp_trtri) instead of on the last element's longest
   int row_i0, row_i1;      // c_lower == 1 only: of the owned tile rows (index i = 0, 1, ... in increasing order) produce those
                            // with row_i0 <= i < row_i1 (row_i1 == 0: all): the sharded LAUUM, block row by block row as the
                            // column blocks of the inverse arrive
