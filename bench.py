@@ -408,8 +408,8 @@ def dry_run(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=None, help="problem size (default: 20000 = C2; 60000 = C5 for --mode sharded)")
     ap.add_argument("--cpu-baseline", choices=["single", "full", "ladder", "none"], default="single")
     ap.add_argument("--no-cpu-baseline", action="store_true")
