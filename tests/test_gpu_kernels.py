@@ -443,3 +443,27 @@ def test_lookahead_driver_is_bitwise_repeatable(gpu_ctx, n):
         else:
             for a, b in zip(ref, cur):
                 assert torch.equal(a, b), f"repetition {rep} differs by {float((a - b).abs().max()):.3e}"
+
+
+@pytest.mark.gpu
+def test_transpose_and_lauum_row_ranges(gpu_ctx):
+    """``gpp_transpose`` (the sharded inverse's mirror) on ragged shapes and padded views, and ``gpp_lauum_rows_range``: the
+    ranges of block rows of every rank's cyclic share add up to the full lower triangle of Linv^T Linv."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for rows, cols in ((1, 1), (63, 65), (130, 70), (1000, 257)):
+        src = torch.randn(rows + 3, cols + 5, dtype=torch.float64, device="cuda", generator=g)[2:2 + rows, 1:1 + cols]
+        dst = torch.full((cols + 2, rows + 4), -7.0, dtype=torch.float64, device="cuda")
+        gpu_ctx.transpose(src, dst[1:1 + cols, 3:3 + rows])
+        assert torch.equal(dst[1:1 + cols, 3:3 + rows], src.t())
+        assert float(dst[0].abs().min()) == 7.0 and float(dst[:, :3].abs().min()) == 7.0  # nothing outside the view
+    n = 1100
+    Li = _sq(n)
+    Li.copy_(torch.tril(torch.randn(n, n, dtype=torch.float64, device="cuda", generator=g)))
+    ref = torch.tril(Li.T @ Li)
+    for nranks in (1, 3):
+        Ki = _sq(n, fill=0.0)
+        bounds = [0, 256, 640, 1024, n]
+        for rank in range(nranks):
+            for r0, r1 in zip(bounds[:-1], bounds[1:]):
+                gpu_ctx.lauum_rows_range(Li, Ki, rank, nranks, r0, r1)
+        np.testing.assert_allclose(torch.tril(Ki).cpu().numpy(), ref.cpu().numpy(), rtol=1e-11, atol=1e-9)
