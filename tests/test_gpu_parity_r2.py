@@ -418,3 +418,36 @@ def test_multi_noise_evaluation_after_training_matches_oracle(gpu_ctx):
     with pytest.raises(GppError, match="feature columns"):
         gpu_ctx.kernel_build(torch.rand(8, 65, dtype=torch.float64, device="cuda"), torch.ones(65, dtype=torch.float64, device="cuda"),
                              one, None, None, square_buffer(8, "cuda"))
+
+
+# ---------------------------------------------------------------------------------------------------
+# bench.py contract (one JSON line, the fields the driver reads), on a small problem
+# ---------------------------------------------------------------------------------------------------
+def test_bench_line_contract(gpu_ctx):
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--n", "4096",
+                        "--cpu-baseline", "none"], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "stages"):
+        assert key in rec, key
+    assert rec["n_gpus"] == 1 and rec["steps"] == 3 and rec["warmup"] == 1 and rec["unit"] == "evals/s"
+    assert rec["dtype"] == "f64" and rec["data"] == "synthetic" and rec["scaling"] == "weak" and rec["vs_baseline"] is None
+    assert "workload" in rec["config"] and rec["config"]["N"] == 4096
+    assert abs(rec["value"] - 1e3 / rec["ms_per_step"]) <= 1e-6 * rec["value"]
+    rf = rec["roofline"]
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "entries"):
+        assert key in rf, key
+    assert rf["bound"] == "mfma" and rf["peak"] == 78.6 and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    stages = {e["stage"] for e in rf["entries"]}
+    assert {"potrf", "trtri", "lauum"} <= stages
+    # the stage events cover the step (no work outside the timed stages): their sum is within 25 % of ms_per_step at this size
+    assert sum(rec["stages"]["ms"].values()) <= 1.05 * rec["ms_per_step"]
