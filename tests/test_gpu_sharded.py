@@ -10,7 +10,7 @@ def _run(args, world=2, port=29531):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "workers", "sharded_worker.py")] + [str(a) for a in args]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     import re
     # (robust against ranks sharing a line of the launcher's pipe: parse from the marker, not by lines)
@@ -40,6 +40,7 @@ def test_sharded_matches_single_gpu(N, D, nb, kind, S, dU):
     (3, 300, 4, 256, 0, 1, 0),     # 2 block rows on 3 ranks: a rank that owns nothing (P > number of block rows)
     (4, 128, 3, 128, 0, 1, 0),     # one block: three idle ranks
     (2, 2176, 7, 128, 1, 1, 0),    # 17 leaf-sized block rows (nb = 128): owners alternate every 128 rows; Matern 3/2
+    (2, 20000, 8, 1024, 0, 1, 0),  # the C2 size on two ranks: 20 block rows of 1024, the grouped LAUUM pipeline with real groups
 ])
 def test_sharded_more_ranks_and_block_counts(world, N, D, nb, kind, S, dU):
     out = _run([N, D, nb, kind, S, dU], world=world, port=29560 + (N * 7 + world * 13 + nb) % 400)  # distinct rendezvous ports
