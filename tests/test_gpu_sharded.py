@@ -53,3 +53,32 @@ def test_sharded_through_gp_plus_api():
     """settings.sharded_evaluation routes GP_Plus's own loss through the cooperative evaluation (mixed-input model)."""
     out = _run([700, 8, 256, 0, 1, 2, "model"], port=29547)
     assert out["err"]["loss_and_grads"] < 1e-8, out
+
+
+@pytest.mark.gpu
+def test_sharded_c5_size_two_ranks():
+    """BASELINE config C5 at FULL size (N = 60 000, d = 16: 59 block rows of 1024) through GP_Plus, sharded over two ranks
+    (one GPU, gloo: 2 x 87 GB) against the single-GPU path run on its own beforehand (86 GB): loss and every gradient."""
+    import re
+    import torch
+
+    if torch.cuda.get_device_properties(0).total_memory < 200 * 2 ** 30:
+        pytest.skip("needs ~175 GiB of device memory")
+    worker = os.path.join(ROOT, "tests", "workers", "sharded_worker.py")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+
+    def values(cmd):
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+        assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+        res = [json.JSONDecoder().raw_decode(p.stdout, m.end())[0] for m in re.finditer(r"RESULT (?=\{)", p.stdout)]
+        assert len(res) == 1, p.stdout[-3000:]
+        return res[0]["values"]
+
+    single = values([sys.executable, worker, "config", "C5", "single", "1024"])
+    shard = values([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                    "--master-port", "29977", worker, "config", "C5", "sharded", "1024"])
+    assert set(single) == set(shard)
+    for k, ref in single.items():
+        a, b = (shard[k], ref) if isinstance(ref, list) else ([shard[k]], [ref])
+        scale = max(max(abs(v) for v in b), 1e-300)
+        assert max(abs(x - y) for x, y in zip(a, b)) <= 1e-8 * scale, (k, a, b)

@@ -51,7 +51,41 @@ def model_case(rank, world, dev, N, nb):
     dist.destroy_process_group()
 
 
+def config_case(name, sharded, nb):
+    """A BASELINE config at FULL size through GP_Plus (baseline_configs.make_config), sharded over the ranks or — one process,
+    no process group — on the single-GPU path; rank 0 prints loss and gradients."""
+    from gpplus_amd.models import GP_Plus
+    from gpplus_amd.gpcore import ExactMarginalLogLikelihood
+    from gpplus_amd.test_functions.baseline_configs import apply_theta, make_config
+    rank = int(os.environ.get("RANK", "0"))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    if sharded:
+        dist.init_process_group("nccl" if torch.cuda.device_count() >= int(os.environ["WORLD_SIZE"]) else "gloo")
+    X, y, kw, theta = make_config(name)
+    torch.manual_seed(0)
+    m = GP_Plus(X, y, dtype=torch.float64, device=str(dev), **kw)
+    apply_theta(m, theta)
+    m.train()
+    mll = ExactMarginalLogLikelihood(m.likelihood, m)
+    with settings.sharded_evaluation({"group": None, "nb": nb} if sharded else None):
+        loss = -mll(m(*m.train_inputs), m.train_targets)
+        loss.backward()
+    if rank == 0:
+        vals = {"loss": float(loss)}
+        for n, p in m.named_parameters():
+            if p.grad is not None:
+                vals[n] = p.grad.detach().cpu().reshape(-1).tolist()
+        emit("RESULT " + json.dumps({"values": vals}))
+    if sharded:
+        emit(f"RANK{rank} same_as_rank0=True")
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[1] == "config":
+        return config_case(sys.argv[2], sys.argv[3] == "sharded", int(sys.argv[4]))
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     ngpu = torch.cuda.device_count()
     one_each = ngpu >= world
