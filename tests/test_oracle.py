@@ -222,3 +222,17 @@ def test_matern_kernels_against_direct_formula():
         flat[i] = old - h; fm = o.loss().item()
         flat[i] = old
         assert abs((fp - fm) / (2 * h) - grads[o.ls_key].reshape(-1)[i].item()) < 1e-7
+
+
+def test_transforms_against_the_reference_module():
+    """softplus / inv_softplus of the oracle AND of the product's ``utils.transforms`` against values produced by the reference's own
+    ``utils/transforms.py`` (tests/golden/make_ref_transforms.py imports it from /root/reference): fp64 and fp32 arguments."""
+    from gpplus_amd.utils.transforms import inv_softplus, softplus
+
+    fx = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_transforms.npz")))
+    x, pos = torch.tensor(fx["x"]), torch.tensor(fx["pos"])
+    for sp, isp in ((G.softplus, G.inv_softplus), (softplus, inv_softplus)):
+        np.testing.assert_allclose(sp(x).numpy(), fx["softplus_x"], rtol=1e-15, atol=0)
+        np.testing.assert_allclose(isp(pos).numpy(), fx["inv_softplus_pos"], rtol=1e-15, atol=1e-300)
+        np.testing.assert_allclose(sp(x.float()).numpy(), fx["softplus_x32"], rtol=1e-7, atol=0)
+        np.testing.assert_allclose(isp(pos.float()).numpy(), fx["inv_softplus_pos32"], rtol=1e-6, atol=1e-30)
