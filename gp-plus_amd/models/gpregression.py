@@ -15,56 +15,63 @@ from ..priors import LogHalfHorseshoePrior, MollifiedUniformPrior
 from ..utils.transforms import inv_softplus, softplus
 
 
+def _require(cond: bool, message: str) -> None:
+    if not cond:
+        raise RuntimeError(message)
+
+
+def _named_correlation(name: str, n_features: int) -> Kernel:
+    """A kernel of ``kernels`` chosen by name: ARD over every input column, ``l = exp(raw)``, mollified-uniform prior on
+    ``raw`` over [log 0.1, log 10] (models/gpregression.py:89-102; any failure is reported as the reference reports it)."""
+    try:
+        k = getattr(kernels, name)(ard_num_dims=n_features,
+                                   lengthscale_constraint=Positive(transform=torch.exp, inv_transform=torch.log))
+        k.register_prior('lengthscale_prior', MollifiedUniformPrior(math.log(0.1), math.log(10)), 'raw_lengthscale')
+    except Exception:
+        raise RuntimeError("%s not an allowed kernel" % name)
+    return k
+
+
 class GPR(ExactGP):
+    #: registered on the model in this order (state_dict keys of the reference, models/gpregression.py:73-76)
+    _TARGET_BUFFERS = ('y_min', 'y_std', 'y_scaled')
+
     def __init__(self, train_x: torch.Tensor, train_y: torch.Tensor, correlation_kernel, noise_indices: List[int],
                  fix_noise: bool = False, fix_noise_val: float = 1e-5, lb_noise: float = 1e-12) -> None:
-        # input checks: models/gpregression.py:50-56
-        if not torch.is_tensor(train_x):
-            raise RuntimeError("'train_x' must be a tensor")
-        if not torch.is_tensor(train_y):
-            raise RuntimeError("'train_y' must be a tensor")
-        if train_x.shape[0] != train_y.shape[0]:
-            raise RuntimeError("Inputs and output have different number of observations")
+        # models/gpregression.py:50-56
+        _require(torch.is_tensor(train_x), "'train_x' must be a tensor")
+        _require(torch.is_tensor(train_y), "'train_y' must be a tensor")
+        _require(train_x.shape[0] == train_y.shape[0], "Inputs and output have different number of observations")
 
-        noise_constraint = GreaterThan(lb_noise, transform=torch.exp, inv_transform=torch.log)
-        if len(noise_indices) == 0:
-            likelihood = GaussianLikelihood(noise_constraint=noise_constraint)
+        # tau = exp(raw) + lb_noise; one level, or one per data source named in the last input column (:59-66)
+        noise_args = dict(noise_constraint=GreaterThan(lb_noise, transform=torch.exp, inv_transform=torch.log))
+        if noise_indices:
+            likelihood = Multifidelity_likelihood(noise_indices=noise_indices, fidel_indices=train_x[:, -1], **noise_args)
         else:
-            likelihood = Multifidelity_likelihood(noise_constraint=noise_constraint, noise_indices=noise_indices,
-                                                  fidel_indices=train_x[:, -1])
-        y_min = train_y.min()
-        y_std = train_y.max() - train_y.min()
-        train_y_sc = (train_y - y_min) / y_std
+            likelihood = GaussianLikelihood(**noise_args)
 
-        ExactGP.__init__(self, train_x, train_y_sc, likelihood)
-        self.register_buffer('y_min', y_min)
-        self.register_buffer('y_std', y_std)
-        self.register_buffer('y_scaled', train_y_sc)
+        # targets scaled to [0, 1] by their range (:67-69); the three quantities travel with the state_dict
+        lo = train_y.min()
+        span = train_y.max() - lo
+        scaled = (train_y - lo) / span
+        ExactGP.__init__(self, train_x, scaled, likelihood)
+        for key, value in zip(self._TARGET_BUFFERS, (lo, span, scaled)):
+            self.register_buffer(key, value)
         self._num_outputs = 1
 
+        # priors in the reference's registration order: noise, lengthscale (named kernels only), outputscale — this is the
+        # order reset_parameters() consumes random numbers in (:84, :97-99, :113-115)
         self.likelihood.register_prior('noise_prior', LogHalfHorseshoePrior(0.01, lb_noise), 'raw_noise')
         if fix_noise:
             self.likelihood.raw_noise.requires_grad_(False)
             self.likelihood.noise_covar.noise = torch.tensor(fix_noise_val)
 
         if isinstance(correlation_kernel, str):
-            try:
-                correlation_kernel_class = getattr(kernels, correlation_kernel)
-                correlation_kernel = correlation_kernel_class(
-                    ard_num_dims=self.train_inputs[0].size(1),
-                    lengthscale_constraint=Positive(transform=torch.exp, inv_transform=torch.log),
-                )
-                correlation_kernel.register_prior(
-                    'lengthscale_prior', MollifiedUniformPrior(math.log(0.1), math.log(10)), 'raw_lengthscale')
-            except Exception:
-                raise RuntimeError("%s not an allowed kernel" % correlation_kernel)
-        elif not isinstance(correlation_kernel, Kernel):
-            raise RuntimeError("specified correlation kernel is not a `gpytorch.kernels.Kernel` instance")
-
+            correlation_kernel = _named_correlation(correlation_kernel, self.train_inputs[0].size(1))
+        _require(isinstance(correlation_kernel, Kernel),
+                 "specified correlation kernel is not a `gpytorch.kernels.Kernel` instance")
         self.covar_module = kernels.ScaleKernel(
-            base_kernel=correlation_kernel,
-            outputscale_constraint=Positive(transform=softplus, inv_transform=inv_softplus),
-        )
+            base_kernel=correlation_kernel, outputscale_constraint=Positive(transform=softplus, inv_transform=inv_softplus))
         self.covar_module.register_prior('outputscale_prior', LogNormalPrior(1e-6, 1.), 'outputscale')
 
     # a plain GPR has no mean module in the reference either (forward uses self.mean_module set by subclasses)

@@ -11,44 +11,52 @@ from tqdm import tqdm
 from ..gpcore.mlls import ExactMarginalLogLikelihood
 
 
+def _plateaued(history: List[float], j: int, window: int) -> bool:
+    """The reference's early stop (optim/mll_torch.py:126-128): at every ``window``-th iteration after the first
+    ``window`` ones, stop when the mean of the last ``window`` losses is not above the current one (float32 mean, as
+    there).  First reachable at j = 2 * window."""
+    if j <= window or j % window != 0:
+        return False
+    recent = torch.Tensor(history)[j - window:j]
+    return bool((torch.mean(recent) - history[j]) <= 0)
+
+
+def _adam_run(model, mll, params, lr: float, num_iter: int, break_steps: int, verbose: bool) -> List[float]:
+    """One start point: up to ``num_iter`` Adam steps on ``-mll`` (optim/mll_torch.py:99-128).  Returns the losses seen
+    BEFORE each step; the last entry is what the restart is judged by."""
+    optimizer = torch.optim.Adam(params, lr=lr)
+    history: List[float] = []
+    bar = tqdm(range(num_iter), desc='Epoch', position=0, leave=True, disable=not verbose)
+    for j in bar:
+        optimizer.zero_grad()
+        loss = -mll(model(*model.train_inputs), model.train_targets)
+        loss.backward()
+        optimizer.step()
+        history.append(loss.item())
+        if verbose:
+            bar.set_description(f'Epoch {j} - loss {history[-1]:.4f}')
+        if _plateaued(history, j, break_steps):
+            break
+    return history
+
+
 def fit_model_torch(model, model_param_groups: Optional[List] = None, lr_default: float = 0.01, num_iter: int = 100,
                     num_restarts: int = 0, break_steps: int = 50, verbose: bool = True) -> float:
-    """Optimize the log-posterior of a GP+ model with ``torch.optim.Adam``.
+    """Optimize the log-posterior of a GP+ model with ``torch.optim.Adam`` (optim/mll_torch.py:56-141).
 
     :returns: ``(f_inc, loss_hist_total)`` — best (negative, per-datum) log-posterior found and the loss histories.
     """
     model.train()
     mll = ExactMarginalLogLikelihood(model.likelihood, model)
-    f_inc = math.inf
-    current_state_dict = model.state_dict()
-    loss_hist_total = []
-
-    for i in range(num_restarts + 1):
-        optimizer = torch.optim.Adam(model.parameters() if model_param_groups is None else model_param_groups, lr=lr_default)
-        loss_hist = []
-        epochs_iter = tqdm(range(num_iter), desc='Epoch', position=0, leave=True, disable=not verbose)
-        for j in epochs_iter:
-            optimizer.zero_grad()
-            output = model(*model.train_inputs)
-            loss = -mll(output, model.train_targets)
-            loss.backward()
-            optimizer.step()
-
-            acc_loss = loss.item()
-            if verbose:
-                epochs_iter.set_description(f'Epoch {j} - loss {acc_loss:.4f}')
-            loss_hist.append(acc_loss)
-            # reference early stop (optim/mll_torch.py:126-128): first reachable at j = 2*break_steps
-            if j > break_steps and j % break_steps == 0:
-                if (torch.mean(torch.Tensor(loss_hist)[j - break_steps:j]) - loss_hist[j]) <= 0:
-                    break
-        loss_hist_total.append(loss_hist)
-
-        if loss.item() < f_inc:
-            current_state_dict = deepcopy(model.state_dict())
-            f_inc = loss.item()
-        if i < num_restarts:
-            model.reset_parameters()
-
-    model.load_state_dict(current_state_dict)
-    return f_inc, loss_hist_total
+    best_loss, best_state = math.inf, model.state_dict()
+    histories = []
+    for restart in range(num_restarts + 1):
+        params = model.parameters() if model_param_groups is None else model_param_groups
+        history = _adam_run(model, mll, params, lr_default, num_iter, break_steps, verbose)
+        histories.append(history)
+        if history and history[-1] < best_loss:  # strict, as in the reference: ties keep the earlier start
+            best_loss, best_state = history[-1], deepcopy(model.state_dict())
+        if restart < num_restarts:
+            model.reset_parameters()  # next start point: a draw from the priors (models/gpregression.py:168-174)
+    model.load_state_dict(best_state)
+    return best_loss, histories
