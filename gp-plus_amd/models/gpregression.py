@@ -106,7 +106,14 @@ class GPR(ExactGP):
 
     def reset_parameters(self) -> None:
         """Reset parameters by sampling from their priors (models/gpregression.py:168-174)."""
+        # The reference builds its priors from Python numbers (torch's default dtype, float32) and never casts them on its
+        # CPU path, so every draw is made in that dtype and converted afterwards — whatever ``dtype`` the model was given.
+        # Here a model is created in its dtype, buffers of the priors included; the expanded copy is put back first so
+        # that one seed gives the start points the reference would draw (tests/test_restart_sampling.py).
+        draw_dtype = torch.get_default_dtype()
         for _, module, prior, closure, setting_closure in self.named_priors():
-            if not closure(module).requires_grad:
-                continue
-            setting_closure(module, prior.expand(closure(module).shape).sample().to(**self.tkwargs))
+            current = closure(module)
+            if not current.requires_grad:
+                continue  # (consumes no random numbers)
+            sampler = prior.expand(current.shape).to(dtype=draw_dtype)
+            setting_closure(module, sampler.sample().to(**self.tkwargs))

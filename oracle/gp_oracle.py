@@ -421,6 +421,71 @@ class OracleGP:
         self.params = {k: v.detach().clone() for k, v in p.items()}
         return hist
 
+    # ---- restart start points ------------------------------------------------------------------------
+    def reset_parameters(self, generator: Optional[torch.Generator] = None) -> Dict[str, torch.Tensor]:
+        """models/gpregression.py:168-174: every trainable parameter with a prior is re-drawn,
+        ``setting_closure(module, prior.expand(closure(module).shape).sample().to(**tkwargs))``, in the order of [3P] gpytorch
+        ``Module.named_priors()`` — a module's own priors in registration order, then its children in registration order:
+          GP_Plus itself      latent map          NormalPrior(0, 1)              models/gp_plus.py:1245-1247
+          .likelihood         raw_noise           LogHalfHorseshoePrior(0.01, lb) models/gpregression.py:84
+          .covar_module       outputscale         LogNormalPrior(1e-6, 1)        models/gpregression.py:113-115
+            .base_kernel[...] raw_lengthscale     NormalPrior(-3, 3) / MollifiedUniformPrior(log .1, log 10)
+                                                                                  models/gp_plus.py:274-295, gpregression.py:96-98
+          .mean_module[_s]    constant            NormalPrior(0, 1)              models/gp_plus.py:495
+        (likelihood and covar_module are set in GPR.__init__, the latent map and the means after it: gp_plus.py:305-382).
+        The reference builds its priors from Python numbers, i.e. in torch's DEFAULT dtype (float32), and never casts them
+        on the CPU: every draw is made in float32 from the global generator and converted afterwards.  Draws, written out:
+          NormalPrior     [3P] torch.distributions.Normal.sample:  torch.normal(loc.expand(shape), scale.expand(shape))
+          LogNormalPrior  [3P] TransformedDistribution.sample:     exp(torch.normal(loc, scale))
+          MollifiedUniformPrior.rsample  priors/mollified_uniform.py:84-85:  Uniform(a, b).rsample() = a + rand * (b - a)
+          LogHalfHorseshoePrior          priors/horseshoe.py:68-79, see ``_horseshoe_draw``.
+        A parameter that does not require grad is skipped WITHOUT consuming random numbers (gpregression.py:172-173)."""
+        f32 = torch.get_default_dtype()
+        g = generator
+
+        def normal(loc: float, scale: float, shape) -> torch.Tensor:
+            return torch.normal(torch.full(tuple(shape), loc, dtype=f32), torch.full(tuple(shape), scale, dtype=f32), generator=g)
+
+        P = self.params
+        if self.qual_cols:
+            P[self.latent_key] = normal(0.0, 1.0, P[self.latent_key].shape).to(DT)
+        nk = "likelihood.noise_covar.raw_noise"
+        if not self.fix_noise:
+            P[nk] = self._horseshoe_draw(0.01, P[nk].shape, g).to(DT)
+        # 'outputscale' names the CONSTRAINED value: the setter stores raw = inv_softplus(value) ([3P] ScaleKernel._set_outputscale),
+        # evaluated after the conversion to the model's dtype
+        v = torch.exp(normal(1e-6, 1.0, ()))
+        P["covar_module.raw_outputscale"] = inv_softplus(v.to(DT))
+        if self.ls_key is not None:
+            shape = P[self.ls_key].shape
+            if self.kclass in ("RBFKernel", "GPR:Rough_RBF", "GPR:wighted_RBF"):
+                a, b = torch.tensor(math.log(0.1), dtype=f32), torch.tensor(math.log(10), dtype=f32)
+                P[self.ls_key] = (a + torch.rand(tuple(shape), dtype=f32, generator=g) * (b - a)).to(DT)
+            else:
+                P[self.ls_key] = normal(-3.0, 3.0, shape).to(DT)
+        for k in [k for k in P if k.startswith("mean_module") and k.endswith(".constant")]:  # insertion order = registration order
+            P[k] = normal(0.0, 1.0, P[k].shape).to(DT)
+        return P
+
+    @staticmethod
+    def _horseshoe_draw(scale: float, shape, generator=None) -> torch.Tensor:
+        """priors/horseshoe.py:68-79.  ``expand`` (:77-79) rebuilds the prior from the expanded ``scale`` ALONE, so the draw
+        is clamped at the constructor's default lb = 1e-6, not at the model's ``lb_noise`` (SURVEY B-7); ``lb`` then has the
+        shape of ``scale`` and the clamp reads ``lb[0]`` when there are several noise levels (:71-74).
+          local_shrinkage = HalfCauchy(1).rsample(scale.shape)        = | Cauchy(0, 1) draw |    ([3P] loc.new(shape).cauchy_())
+          param_sample    = HalfNormal(local_shrinkage * scale).rsample() = | N(0, 1) draw * (local_shrinkage * scale) |
+          param_sample[param_sample < lb] = lb ;  return log(param_sample)         (the prior is on log noise = raw_noise)."""
+        f32 = torch.get_default_dtype()
+        shape = tuple(shape)
+        sc = torch.full(shape, scale, dtype=f32)
+        lb = torch.full(shape, 1e-6, dtype=f32)
+        local_shrinkage = torch.empty(shape, dtype=f32).cauchy_(generator=generator).abs()
+        eps = torch.normal(torch.zeros(shape, dtype=f32), torch.ones(shape, dtype=f32), generator=generator)
+        param_sample = (eps * (local_shrinkage * sc)).abs()
+        floor = lb[0] if lb.numel() > 1 else lb
+        param_sample = torch.where(param_sample < floor, floor.expand_as(param_sample), param_sample)
+        return param_sample.log()
+
     # ---- prediction --------------------------------------------------------------------------------
     @torch.no_grad()
     def predict(self, xtest, return_std: bool = True, include_noise: bool = True):
