@@ -209,7 +209,7 @@ def _stage_table(events, N, share=1):
         stages.setdefault(name, []).append(e0.elapsed_time(e1))
     ms = {k: float(np.mean(v)) for k, v in stages.items()}
     third = N ** 3 / 3
-    flops = {"potrf": third, "trtri": third, "lauum": third, "shard_factor": third, "shard_inverse": third, "shard_lauum": third}
+    flops = {"potrf": third, "trtri": third, "lauum": third, "shard_factor": third, "shard_inverse": third, "shard_backsolve": third}
     rate = {k: flops[k] / share / (ms[k] * 1e-3) / 1e12 for k in flops if k in ms}
     return ms, rate
 

@@ -10,6 +10,7 @@ from __future__ import annotations
 import atexit
 import ctypes
 import threading
+import weakref
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -97,10 +98,11 @@ class GppContext:
 
     @_on_own_device
     def internal_streams(self):
-        """(latency stream, throughput stream): the handle's CU-masked internal streams as torch streams."""
+        """(latency stream, throughput stream, unmasked stream): the handle's internal streams as torch streams — 32 CUs,
+        the other 224, and one without a CU mask."""
         if getattr(self, "_istreams", None) is None:
             out = []
-            for which in (0, 1):
+            for which in (0, 1, 2):
                 p = ctypes.c_void_p()
                 check(self.lib.gpp_internal_stream(self.h, which, ctypes.byref(p)), "gpp_internal_stream")
                 out.append(torch.cuda.ExternalStream(p.value, device=self.device))
@@ -120,12 +122,14 @@ class GppContext:
         _need(grp, torch.int32, "grp")
         if grp.numel() != N:
             raise GppError(f"noise-group index has {grp.numel()} entries for {N} points (stale fidel_indices?)")
-        key = (grp.data_ptr(), grp._version, N, S)
-        if getattr(self, "_grp_ok", None) != key:
+        # keyed on the tensor OBJECT (weak reference) and its version counter, not on its address: the caching allocator
+        # hands a new index tensor of the same size the address of a freed one
+        seen = getattr(self, "_grp_ok", None)
+        if seen is None or seen[0]() is not grp or seen[1:] != (grp._version, N, S):
             lo, hi = int(grp.min()), int(grp.max())
             if lo < 0 or hi >= max(S, 1):
                 raise GppError(f"noise-group index out of range: values in [{lo}, {hi}] for {S} noise levels")
-            self._grp_ok = key
+            self._grp_ok = (weakref.ref(grp), grp._version, N, S)
 
     # -- operators -------------------------------------------------------------------------------
     @_on_own_device
@@ -191,6 +195,34 @@ class GppContext:
                                      first_block, rank, nranks), "gpp_syrk_rows")
 
     @_on_own_device
+    def gemm_lower_cols(self, A, B, C, alpha, beta, nb, first_block, rank, nranks, row0=0, row1=None):
+        """C(lower, owned column blocks of width nb) = beta C + alpha A^T B;  A, B: K x M row-contiguous, C: M x M; rows
+        [row0, row1) of C only."""
+        if A.shape != B.shape or C.shape[0] != C.shape[1] or C.shape[0] != A.shape[1]:
+            raise GppError("gemm_lower_cols: shapes do not match")
+        self._stream()
+        check(self.lib.gpp_gemm_lower_cols(self.h, A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), C.data_ptr(), _ld(C), C.shape[0],
+                                           A.shape[0], float(alpha), float(beta), nb, first_block, rank, nranks, row0,
+                                           C.shape[0] if row1 is None else row1),
+              "gpp_gemm_lower_cols")
+
+    @_on_own_device
+    def trmv_lower_cols(self, T, x, y, nb, rank, nranks, trans=False):
+        """y = (owned column blocks of lower T) x, or their transpose times x on the owned entries (0 elsewhere)."""
+        for t, n in ((x, "x"), (y, "y")):
+            _need(t, torch.float64, n)
+        if trans:
+            self.ensure_workspace(OP_MLL_EVAL, T.shape[0], 0, 1, 1)
+        self._stream()
+        check(self.lib.gpp_trmv_lower_cols(self.h, T.data_ptr(), _ld(T), T.shape[0], x.data_ptr(), y.data_ptr(), nb, rank, nranks,
+                                           1 if trans else 0), "gpp_trmv_lower_cols")
+
+    @_on_own_device
+    def mll_scalars(self, U, z, out3):
+        self._stream()
+        check(self.lib.gpp_mll_scalars(self.h, U.data_ptr(), _ld(U), U.shape[0], z.data_ptr(), out3.data_ptr()), "gpp_mll_scalars")
+
+    @_on_own_device
     def lauum_rows(self, Linv, Kinv, rank, nranks):
         """This rank's cyclic share (128-row tile rows) of Kinv = Linv^T Linv, one launch."""
         self._stream()
@@ -252,6 +284,20 @@ class GppContext:
                                             d_split, alpha.data_ptr(), Kinv.data_ptr(), _ld(Kinv), dU, nb, rank, nranks,
                                             g_w.data_ptr(), g_sf2.data_ptr(), g_tau.data_ptr(), _ptr(g_U)),
               "gpp_grad_reduce_rows")
+
+    @_on_own_device
+    def grad_reduce_cols(self, U, w, sf2, grp, S, alpha, Kinv, dU, nb, rank, nranks, g_w, g_sf2, g_tau, g_U, *,
+                         kind=KIND_RBF, d_split=0):
+        """Partial sums over the COLUMN blocks of Kinv's lower triangle owned by ``rank`` (block-cyclic, width ``nb``)."""
+        N, D = U.shape
+        if grp is not None:
+            self._check_groups(grp, N, S)
+        self.ensure_workspace(OP_MLL_EVAL, N, 0, D, S)
+        self._stream()
+        check(self.lib.gpp_grad_reduce_cols(self.h, U.data_ptr(), N, D, w.data_ptr(), sf2.data_ptr(), _ptr(grp), S, kind,
+                                            d_split, alpha.data_ptr(), Kinv.data_ptr(), _ld(Kinv), dU, nb, rank, nranks,
+                                            g_w.data_ptr(), g_sf2.data_ptr(), g_tau.data_ptr(), _ptr(g_U)),
+              "gpp_grad_reduce_cols")
 
     @_on_own_device
     def predict(self, Linv, alpha, Ksn, kss, V, mean_out, var_out):

@@ -247,6 +247,7 @@ hipError_t ensure_streams(gpp_handle_s* h) {
         h->upd_stream = su;
         h->fill_stream = sf;
         h->cu_split = 1;
+        h->panel_cus = PANEL_CUS;
       } else {
         (void)hipGetLastError();
         if (sp) (void)hipStreamDestroy(sp);
@@ -527,6 +528,7 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->fill_stream = nullptr;
   h->full_stream = nullptr;
   h->cu_split = -1;
+  h->panel_cus = 0;
   h->n_events = 0;
   h->ev_next = 0;
   h->inv_N = 0;
@@ -554,10 +556,10 @@ int gpp_set_stream(gpp_handle_t h, void* stream) {
 
 int gpp_internal_stream(gpp_handle_t h, int which, void** out) {
   if (!h) return -1;
-  if (which != 0 && which != 1) return -2;
+  if (which < 0 || which > 2) return -2;
   if (!out) return -3;
   GPP_TRY(ensure_streams(h));
-  *out = reinterpret_cast<void*>(which == 0 ? h->panel_stream : h->upd_stream);
+  *out = reinterpret_cast<void*>(which == 0 ? h->panel_stream : which == 1 ? h->upd_stream : h->full_stream);
   return 0;
 }
 
@@ -565,7 +567,7 @@ size_t gpp_workspace_bytes(gpp_handle_t h, int op, int64_t N, int64_t M, int D, 
   (void)h;
   (void)M;
   if (op == GPP_OP_MLL_EVAL) {
-    return gpp_grad_ws_bytes(N, D, S, D) + 256;
+    return std::max(gpp_grad_ws_bytes(N, D, S, D), gpp_trmv_t_ws_bytes(N)) + 256;
   }
   if (op == GPP_OP_PREDICT) return 256;
   return 0;
@@ -749,6 +751,55 @@ int gpp_syrk_rows(gpp_handle_t h, const double* Urow, int64_t ldu, double* C, in
   return 0;
 }
 
+int gpp_gemm_lower_cols(gpp_handle_t h, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                        int64_t M, int64_t K, double alpha, double beta, int64_t nb, int64_t first_block, int rank, int nranks,
+                        int64_t row0, int64_t row1) {
+  if (!h) return -1;
+  if (!A || !aligned16(A) || (lda & 1)) return -2;
+  if (!B || !aligned16(B) || (ldb & 1)) return -4;
+  if (!C || !aligned16(C) || (ldc & 1)) return -6;
+  if (M < 0 || K < 0) return -8;
+  if (nb < NBLK || nb % NBLK != 0) return -12;
+  if (first_block < 0) return -13;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return -14;
+  if (row0 < 0 || row1 < row0 || row1 > M || row0 % NBLK != 0) return -16;
+  if (M == 0 || K == 0 || row1 == row0) return 0;
+  GemmArgs g = mk(A, lda, B, ldb, C, ldc, M, M, K, alpha, beta);
+  g.c_lower = 1;
+  g.row_t0 = (int)(row0 / NBLK);
+  g.row_t1 = (int)((row1 + NBLK - 1) / NBLK);
+  g.own_mod = nranks;
+  g.own_bt = (int)(nb / NBLK);
+  g.own_off = (int)(((first_block - rank) % nranks + nranks) % nranks);
+  GPP_TRY(gpp_launch_gemm(h->stream, 2, g, 1, NBLK, NBLK));
+  return 0;
+}
+
+int gpp_trmv_lower_cols(gpp_handle_t h, const double* T, int64_t ldt, int64_t N, const double* x, double* y, int64_t nb, int rank,
+                        int nranks, int trans) {
+  if (!h) return -1;
+  if (N < 0) return -4;
+  if (int q = check_mat(T, ldt, N, 2)) return q;
+  if (!x || !aligned16(x)) return -5;
+  if (!y) return -6;
+  if (nb < 64 || nb % 64 != 0) return -7;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return -8;
+  if (trans != 0 && trans != 1) return -10;
+  if (trans && (!h->ws || h->ws_bytes < gpp_trmv_t_ws_bytes(N))) return -1;  // workspace of GPP_OP_MLL_EVAL (gpp_set_workspace)
+  GPP_TRY(gpp_launch_trmv_lower_cols(h->stream, T, ldt, N, x, y, nb, rank, nranks, trans, h->ws, h->ws_bytes));
+  return 0;
+}
+
+int gpp_mll_scalars(gpp_handle_t h, const double* U, int64_t ld, int64_t N, const double* z, double* out3) {
+  if (!h) return -1;
+  if (N < 0) return -4;
+  if (int q = check_mat(U, ld, N, 2)) return q;
+  if (!z) return -5;
+  if (!out3) return -6;
+  GPP_TRY(gpp_launch_mll_scalars(h->stream, U, ld, N, z, out3));
+  return 0;
+}
+
 int gpp_mll_reduce(gpp_handle_t h, const double* U, int64_t ld, const double* Linv, int64_t ldi, int64_t N,
                    const double* r, double* z, double* out3) {
   if (!h) return -1;
@@ -827,6 +878,34 @@ int gpp_grad_reduce_rows(gpp_handle_t h, const double* U, int64_t N, int D, cons
   return 0;
 }
 
+int gpp_grad_reduce_cols(gpp_handle_t h, const double* U, int64_t N, int D, const double* w, const double* sf2,
+                         const int32_t* grp, int S, int kind, int d_split, const double* alpha, const double* Kinv,
+                         int64_t ldk, int dU, int64_t nb, int rank, int nranks, double* g_w, double* g_sf2, double* g_tau,
+                         double* g_U) {
+  if (!h) return -1;
+  if (!U) return -2;
+  if (N < 0) return -3;
+  if (D < 1 || D > 64) return -4;
+  if (!w) return -5;
+  if (!sf2) return -6;
+  if (S < 1 || S > 64) return -8;
+  if (kind < 0 || kind > 2) return -9;
+  if (d_split < 0 || d_split > D) return -10;
+  if (!alpha) return -11;
+  if (int q = check_mat(Kinv, ldk, N, 12)) return q;
+  if (dU < 0 || dU > D) return -14;
+  if (nb < 64 || nb % 64 != 0 || nb > (1 << 30)) return -15;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return -16;
+  if (!g_w) return -18;
+  if (!g_sf2) return -19;
+  if (!g_tau) return -20;
+  if (dU > 0 && !g_U) return -21;
+  if (!h->ws || h->ws_bytes < gpp_grad_ws_bytes(N, D, S, dU)) return -1;
+  GPP_TRY(gpp_launch_grad_reduce(h->stream, U, N, D, w, sf2, grp, S, kind, d_split, alpha, Kinv, ldk, dU, g_w, g_sf2, g_tau,
+                                 g_U, h->ws, h->ws_bytes, (int)nb, rank, nranks, 1, 0, 0, 0, /*shard_cols=*/1));
+  return 0;
+}
+
 int gpp_predict(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, const double* alpha, const double* Ksn,
                 int64_t lds, int64_t M, const double* kss, double* V, int64_t ldv, double* mean_out, double* var_out) {
   if (!h) return -1;
@@ -879,6 +958,7 @@ int gpp_gemm(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64
     GPP_TRY(hipStreamWaitEvent(h->stream, b, 0));
     return 0;
   }
+  if (h->cu_split == 1 && h->stream == h->panel_stream) g.cu_hint = h->panel_cus;
   GPP_TRY(gpp_launch_gemm(h->stream, variant, g, 1, ftm, ftn));
   return 0;
 }
@@ -904,6 +984,7 @@ int gpp_gemm_batched(gpp_handle_t h, int transA, int transB, int64_t M, int64_t 
   GemmArgs g = mk(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta);
   g.a_mask = a_mask; g.b_mask = b_mask; g.klo_mode = klo_mode; g.khi_mode = khi_mode; g.c_lower = c_tri;
   g.sA = sA; g.sB = sB; g.sC = sC;
+  if (h->cu_split == 1 && h->stream == h->panel_stream) g.cu_hint = h->panel_cus;
   GPP_TRY(gpp_launch_gemm(h->stream, variant, g, batch));
   return 0;
 }

@@ -219,6 +219,8 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
       while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
       while (tm * (tm + 1) / 2 > t) --tm;
       tn = t - tm * (tm + 1) / 2;
+      // lower triangle, column blocks owned block-cyclically (the sharded back-substitution): another rank's column block
+      if (p.c_lower == 1 && p.own_mod > 1 && (tn / p.own_bt + p.own_off) % p.own_mod != 0) return;
       if (p.c_lower == 2) {  // upper triangle: same enumeration, mirrored tile
         const int q = tm;
         tm = tn;
@@ -498,8 +500,10 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int
     // enough 128^2 tiles to give every CU a work-group -> big tile; otherwise shrink until the chip is covered
     static const int64_t t128 = getenv("GPP_TILE_T128") ? atol(getenv("GPP_TILE_T128")) : 256;  // experiment knobs
     static const int64_t t64 = getenv("GPP_TILE_T64") ? atol(getenv("GPP_TILE_T64")) : 192;
-    if (ntiles(128) >= t128) tile_m = 128;
-    else if (ntiles(64) >= t64) tile_m = 64;
+    // (a launch on the panel stream has 32 CUs to fill, not 256: the thresholds scale with the stream's CU count)
+    const int64_t cus = a.cu_hint > 0 ? a.cu_hint : 256;
+    if (ntiles(128) * 256 >= t128 * cus) tile_m = 128;
+    else if (ntiles(64) * 256 >= t64 * cus) tile_m = 64;
     else tile_m = 32;
     tile_n = tile_m;
   }
@@ -520,6 +524,13 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int
     nt = S(i1) - S(i0);
   } else {
     a.row_mod = 0;  // plain enumeration
+    if (a.c_lower == 1 && a.row_t1 > 0) {
+      // a band of tile rows [row_t0, row_t1): the row-by-row enumeration of the lower triangle makes it a contiguous range
+      const int64_t t0 = std::min<int64_t>(std::max(a.row_t0, 0), a.tiles_m), t1 = std::min<int64_t>(a.row_t1, a.tiles_m);
+      if (t1 <= t0) return hipSuccess;
+      a.tile_base = t0 * (t0 + 1) / 2;
+      nt = t1 * (t1 + 1) / 2 - a.tile_base;
+    }
   }
   a.swz = 0;
   // Measured on MI355X (N = 20000): the super-tile mapping LOSES 10-20 % against plain row-major order (row-major

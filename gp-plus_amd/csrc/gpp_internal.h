@@ -16,6 +16,7 @@ struct gpp_handle_s {
   hipStream_t full_stream;   // internal stream of the look-ahead Cholesky WITHOUT a CU mask: the part of a trailing update
                              // that runs after the next diagonal block is done (no leaf to starve) gets all 256 CUs (lazy)
   hipStream_t fill_stream;   // internal stream of the look-ahead Cholesky: bordering steps of the inverse (lazy; CUs of upd_stream)
+  int panel_cus;             // CUs of panel_stream when cu_split == 1
   int cu_split;              // 1: the two streams own disjoint CU sets (CU masks), 0: plain priority streams, -1: unknown
   hipEvent_t events[16];     // ring of timing-disabled events for the two-stream hand-offs (lazy)
   int n_events, ev_next;
@@ -48,8 +49,9 @@ struct GemmArgs {
   int col_major;           // enumerate tiles column by column (non-triangular outputs)
   int row_reverse;         // row-major order, last row tile first
   int swz;                 // set by the launcher: XCD-aware 8x8 super-tile mapping of blockIdx -> tile
-  int own_mod, own_off, own_bt;  // c_lower == 2 only: produce the tile rows tm with (tm / own_bt + own_off) % own_mod == 0
+  int own_mod, own_off, own_bt;  // c_lower == 2: produce the tile rows tm with (tm / own_bt + own_off) % own_mod == 0
                            // (block-cyclic block rows of own_bt tile rows; own_mod <= 1: all).  Other tiles exit at once.
+                           // c_lower == 1 (plain enumeration): the same test on the tile COLUMN tn (block-cyclic column blocks)
   int skip_lead;           // c_lower == 2 only: tiles lying entirely inside the leading skip_lead x skip_lead block exit at once
                            // (that block was updated by an earlier launch; skip_lead a multiple of the tile)
   int row_limit;           // c_lower == 2 only: produce only the tiles whose rows lie below row_limit (a multiple of the tile;
@@ -62,6 +64,8 @@ struct GemmArgs {
                            // with row_i0 <= i < row_i1 (row_i1 == 0: all): the sharded LAUUM, block row by block row as the
                            // column blocks of the inverse arrive
   int64_t tile_base;       // set by the launcher: first tile index of this launch in the owned-row enumeration
+  int row_t0, row_t1;      // c_lower == 1, plain enumeration: produce the tile rows row_t0 <= tm < row_t1 only (row_t1 == 0: all)
+  int cu_hint;             // CUs of the stream the launch goes to (0: all 256): scales the automatic tile choice
   int row_mod, row_off;    // c_lower == 1 only: produce the tile rows tm with tm % row_mod == row_off (row_mod <= 1: all);
                            // the sharded LAUUM, one launch per rank over its cyclic share of the 128-row tile rows
 };
@@ -98,7 +102,14 @@ hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int
                                   const int32_t* grp, int S, int kind, int d_split, const double* alpha,
                                   const double* Kinv, int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau,
                                   double* g_U, void* ws, size_t ws_bytes, int shard_nb = 0, int shard_rank = 0,
-                                  int shard_nranks = 1, int batch = 1, int64_t sU = 0, int64_t sK = 0, int64_t sv = 0);
+                                  int shard_nranks = 1, int batch = 1, int64_t sU = 0, int64_t sK = 0, int64_t sv = 0,
+                                  int shard_cols = 0);
+// (shard_cols = 1: the rank owns block-cyclic COLUMN blocks of Kinv's lower triangle instead of block rows)
+// y = sum over the owned column blocks (width nb, block b owned when b % nranks == rank) of T(lower) x  (trans = 0), or
+// y_k = sum_i T[i][k] x_i for the owned columns k and 0 elsewhere (trans = 1)
+hipError_t gpp_launch_trmv_lower_cols(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
+                                      int64_t nb, int rank, int nranks, int trans, void* ws, size_t ws_bytes);
+size_t gpp_trmv_t_ws_bytes(int64_t N);  // scratch of the trans = 1 form (partial sums of the row chunks)
 // (batch > 1: U + b*sU, w + b*D, sf2 + b, alpha + b*sv, Kinv + b*sK; outputs g_w + b*D, g_sf2 + b, g_tau + b*S,
 //  g_U + b*N*dU; the workspace holds batch * gpp_grad_ws_bytes)
 // dst[c][r] = src[r][c] for r < rows, c < cols (64 x 64 tiles through LDS)

@@ -72,6 +72,75 @@ __global__ __launch_bounds__(256) void gpp_trmv_upper(const double* __restrict__
   if (lane == 0) y[j] = acc;
 }
 
+// Column-sharded products with a lower-triangular T of which this rank holds only the column blocks it owns (block-cyclic:
+// columns [b*nb, (b+1)*nb) with b % nranks == rank): the sharded evaluation's z = L^-1 r and alpha = L^-T z from the owned
+// column blocks of L^-1 (the caller all-reduces the partial results).
+//   y_i = sum over owned columns k <= i of T[i][k] x_k        (one wave per row; other columns are never read)
+__global__ __launch_bounds__(256) void gpp_trmv_lower_cols(const double* __restrict__ T, int64_t ldt, int64_t N,
+                                                           const double* __restrict__ x, double* __restrict__ y, int64_t nb,
+                                                           int rank, int nranks) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + wave;
+  if (i >= N) return;
+  const double* row = T + i * ldt;
+  double acc = 0.0;
+  for (int64_t c0 = (int64_t)rank * nb; c0 <= i; c0 += (int64_t)nranks * nb) {
+    const int64_t c1 = (c0 + nb < i + 1) ? c0 + nb : i + 1;  // nb is even: c0 is, so the 16-byte loads are aligned
+    const int64_t len = c1 - c0, len2 = len & ~(int64_t)1;
+    for (int64_t k = 2 * lane; k < len2; k += 128) {
+      const v2d t = *reinterpret_cast<const v2d*>(row + c0 + k);
+      const v2d xx = *reinterpret_cast<const v2d*>(x + c0 + k);
+      acc = fma(t.x, xx.x, acc);
+      acc = fma(t.y, xx.y, acc);
+    }
+    if (lane == 0 && (len & 1)) acc = fma(row[c1 - 1], x[c1 - 1], acc);
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) y[i] = acc;
+}
+
+//   y_k = sum_{i >= k} T[i][k] x_i   for the owned columns k, 0 for the others.  Work-group (g, r): 64 columns (lane = column,
+//   coalesced along the row) x the r-th chunk of rows, the four waves striding over the rows with eight loads in flight each;
+//   the chunks' partial sums are added in a fixed order by the second kernel (deterministic, no float atomics).
+constexpr int TRT_CHUNKS = 16;
+__global__ __launch_bounds__(256) void gpp_trmv_lower_t_cols(const double* __restrict__ T, int64_t ldt, int64_t N,
+                                                             const double* __restrict__ x, double* __restrict__ part, int64_t nb,
+                                                             int rank, int nranks, int64_t chunk) {
+  __shared__ double red[4][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t k0 = (int64_t)blockIdx.x * 64, k = k0 + lane;
+  const bool owned = (int)((k0 / nb) % nranks) == rank;  // nb is a multiple of 64: a group of 64 columns has one owner
+  double acc = 0.0;
+  const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = (r0 + chunk < N) ? r0 + chunk : N;
+  if (owned && k < N && r1 > k0) {
+    int64_t i = (r0 > k0 ? r0 : k0) + wave;
+    const double* p = T + k;
+    for (; i + 28 < r1; i += 32) {  // rows i, i+4, ..., i+28 of this wave: eight independent loads
+      double t[8], xv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        t[u] = p[(i + 4 * u) * ldt];
+        xv[u] = x[i + 4 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc = (i + 4 * u >= k) ? fma(t[u], xv[u], acc) : acc;
+    }
+    for (; i < r1; i += 4)
+      if (i >= k) acc = fma(p[i * ldt], x[i], acc);
+  }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && k < N) part[(int64_t)blockIdx.y * N + k] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+__global__ __launch_bounds__(256) void gpp_trmv_lower_t_finish(const double* __restrict__ part, int64_t N, int chunks,
+                                                               double* __restrict__ y) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= N) return;
+  double s = 0.0;
+  for (int r = 0; r < chunks; ++r) s += part[(int64_t)r * N + k];
+  y[k] = s;
+}
+
 // out3 = { quad = z'z, logdet = 2 sum log L_ii, mll = -0.5 (quad + logdet + N log 2pi) } : one work-group.
 __global__ __launch_bounds__(1024) void gpp_mll_scalars(const double* __restrict__ L, int64_t ld, int64_t N,
                                                         const double* __restrict__ z, double* __restrict__ out3, int64_t sL,
@@ -135,7 +204,7 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
                                                       const double* __restrict__ w, const double* __restrict__ sf2p,
                                                       int kind, int d_split, const double* __restrict__ alpha, const double* __restrict__ Kinv,
                                                       int64_t ldk, int dU, int64_t ntiles, int shard_nb, int shard_rank,
-                                                      int shard_nranks, int64_t sU, int64_t sK, int64_t sv, int64_t ws_stride,
+                                                      int shard_nranks, int shard_cols, int64_t sU, int64_t sK, int64_t sv, int64_t ws_stride,
                                                       double* __restrict__ rec /* [gridDim.x][D+1] */,
                                                       double* __restrict__ wdiag /* [N] */,
                                                       double* __restrict__ gUpart /* [T][N][dU] */) {
@@ -171,7 +240,8 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
     tile_from_index(t, ti, tj);
     const int64_t i0 = ti * GT, j0 = tj * GT;
     // row-sharded evaluation: this rank only holds (and reduces) the block rows of Kinv it owns (block-cyclic)
-    if (shard_nranks > 1 && (int)((i0 / shard_nb) % shard_nranks) != shard_rank) continue;
+    // (shard_cols: the rank holds column blocks of Kinv instead — the back-substituted sharded evaluation)
+    if (shard_nranks > 1 && (int)(((shard_cols ? j0 : i0) / shard_nb) % shard_nranks) != shard_rank) continue;
     const bool diag_tile = (ti == tj);
     __syncthreads();
     for (int e = tid; e < DT * GT; e += 256) {
@@ -436,6 +506,24 @@ hipError_t gpp_launch_trmv_upper(hipStream_t s, const double* T, int64_t ldt, in
   return hipGetLastError();
 }
 
+size_t gpp_trmv_t_ws_bytes(int64_t N) { return (size_t)TRT_CHUNKS * (size_t)N * sizeof(double); }
+
+hipError_t gpp_launch_trmv_lower_cols(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
+                                      int64_t nb, int rank, int nranks, int trans, void* ws, size_t ws_bytes) {
+  if (N <= 0) return hipSuccess;
+  if (nb < 64 || nb % 64 != 0 || nranks < 1 || rank < 0 || rank >= nranks) return hipErrorInvalidValue;
+  if (trans) {
+    if (!ws || ws_bytes < gpp_trmv_t_ws_bytes(N)) return hipErrorInvalidValue;
+    const int64_t chunk = (((N + TRT_CHUNKS - 1) / TRT_CHUNKS) + 31) / 32 * 32;
+    double* part = reinterpret_cast<double*>(ws);
+    hipLaunchKernelGGL(gpp_trmv_lower_t_cols, dim3((unsigned)((N + 63) / 64), TRT_CHUNKS), dim3(256), 0, s, T, ldt, N, x, part, nb,
+                       rank, nranks, chunk);
+    hipLaunchKernelGGL(gpp_trmv_lower_t_finish, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, part, N, TRT_CHUNKS, y);
+  } else
+    hipLaunchKernelGGL(gpp_trmv_lower_cols, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, T, ldt, N, x, y, nb, rank, nranks);
+  return hipGetLastError();
+}
+
 hipError_t gpp_launch_mll_scalars(hipStream_t s, const double* L, int64_t ld, int64_t N, const double* z, double* out3,
                                   int batch, int64_t sL, int64_t sv) {
   if (batch <= 0) return hipSuccess;
@@ -454,7 +542,7 @@ hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int
                                   const int32_t* grp, int S, int kind, int d_split, const double* alpha,
                                   const double* Kinv, int64_t ldk, int dU, double* g_w, double* g_sf2, double* g_tau,
                                   double* g_U, void* ws, size_t ws_bytes, int shard_nb, int shard_rank, int shard_nranks,
-                                  int batch, int64_t sU, int64_t sK, int64_t sv) {
+                                  int batch, int64_t sU, int64_t sK, int64_t sv, int shard_cols) {
   if (kind < 0 || kind > 2) return hipErrorInvalidValue;
   if (batch < 1 || batch > 65535) return hipErrorInvalidValue;
   if (shard_nranks > 1 && (shard_nb < GT || shard_nb % GT != 0 || shard_rank < 0 || shard_rank >= shard_nranks))
@@ -474,7 +562,7 @@ hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int
   }
   auto launch = [&](auto kern) {
     hipLaunchKernelGGL(kern, dim3(nwg, batch), dim3(256), 0, s, U, N, D, w, sf2, kind, d_split, alpha, Kinv, ldk, dU, ntiles,
-                       shard_nb, shard_rank, shard_nranks, sU, sK, sv, ws_stride, rec, wdiag, gUpart);
+                       shard_nb, shard_rank, shard_nranks, shard_cols, sU, sK, sv, ws_stride, rec, wdiag, gUpart);
   };
   const bool mat = kind != 0, hasu = dU > 0;
 #define GPP_GT(DT)                                                                                                   \

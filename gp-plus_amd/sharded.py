@@ -4,31 +4,41 @@ xGMI); every rank calls :func:`sharded_mll` with identical arguments and receive
 
 The reference has no multi-GPU evaluation (its only parallelism is joblib over restarts, optim/mll_scipy.py:287-293);
 this is the same computation as ``linalg.ExactMLLFunction`` (reference call sites optim/mll_torch.py:114-117) with its
-O(N^3) stages split by 1-D block-cyclic BLOCK ROWS of the upper-stored matrices (block height ``nb``, owner = k mod P):
+O(N^3) stages split 1-D block-cyclically (block height / width ``nb``, owner of block k = k mod P):
 
-  build    every rank builds the block rows of Ky it owns                                      (no communication)
-  potrf    right-looking: the owner of block row k factors the diagonal block (leaf kernels), inverts it, solves the
-           block row with one GEMM and BROADCASTS the finished row slab (nb x ld doubles) together with the inverse of
-           the diagonal block; every rank then updates the block rows it owns with one TN GEMM each.  One step of
-           look-ahead: the owner of k+1 updates that row first and factors / broadcasts it on a second stream while
-           the remaining updates of step k run.
-  inverse  column blocks of L^-1 are independent forward substitutions against the (now replicated) factor: the owner of
-           column block c sweeps Y_k = -L_kk^-1 sum_{j<k} L_kj Y_j right-looking (one wide TN GEMM per step); the column
-           blocks are then broadcast so that every rank holds L^-1 (lower) and its mirror (upper).
-  lauum    every rank forms its tile-cyclic share (128-row tile rows) of Ky^-1 = L^-T L^-1, block row c as soon as column
-           block c of the inverse has arrived (Ky^-1[i, j <= i] needs columns i and j only): the product runs on the main
-           stream while the side stream broadcasts the next column block
-  grad     ``gpp_grad_reduce_rows`` over the same tile rows, then ONE all-reduce of D + 1 + S (+ N dU) doubles.
+  build    every rank builds the block ROWS of Ky it owns                                      (no communication)
+  potrf    right-looking over block rows of the upper-stored matrix: the owner of block row k factors and inverts the
+           diagonal block on the 32-CU panel stream, solves the block row with one GEMM on the throughput stream and
+           BROADCASTS the finished row slab (packed: nb x (N - o) doubles) and the diagonal block's inverse; every rank
+           then updates the block rows it owns.  Inside each rank's share the update is split like the single-GPU
+           driver's (gpp_potrf_ws): the rows the next two steps depend on first, then — on the rank whose next diagonal
+           block is being factored meanwhile — a trapezoid of early rows on the CU-masked stream beside that panel and the
+           bulk on the stream WITHOUT a CU mask once the panel is done.  As each row slab becomes final its mirror
+           (L = U^T) is written into the unused strict lower triangle of the same buffer.
+  forward  column blocks of L^-1 are independent forward substitutions against the replicated factor: the owner of column
+           block c sweeps  Y_j = -L_jj^-1 sum_{c<=k<j} L_jk Y_k  right-looking, all its column blocks in ONE batched launch
+           per step and product.
+  z, alpha z = L^-1 r and alpha = L^-T z from the owned column blocks (gpp_trmv_lower_cols) + two all-reduces of N doubles.
+  backward each rank turns ITS column blocks of L^-1 into the same column blocks of Ky^-1 = L^-T L^-1 by BACK-substitution
+           against the replicated factor ("each GPU solves for its own block-columns of L^-T L^-1 E_k —
+           block-parallel, no further comm"): Z_j = L_jj^-T (Y_j - sum_{k>j} U_jk Z_k), right-looking from the last block
+           row up, only the rows at and below each column block's diagonal (Ky^-1 is symmetric), one TN GEMM per step
+           over the lower-triangular tiles of the owned column blocks (gpp_gemm_lower_cols; the factor's mirror makes the
+           product row-contiguous).  Same flops as the LAUUM share it replaces (sum_c (N - c)^2 nb = N^3 / 3 over P),
+           nothing on the wire.
+  grad     ``gpp_grad_reduce_cols`` over the owned column blocks, then ONE all-reduce of D + 1 + S (+ N dU) doubles.
 
-Communication per evaluation: the packed factor slabs (4 N^2 B), the column blocks of the inverse (4 N^2 B) and the
-tiny all-reduce; at C5 that is ~29 GB per GPU against ~2.7e13 flop of GEMM work per GPU.  Memory per GPU: the same three
-N x N buffers as the single-GPU path (86 GB at C5 of 288 GB) — nothing is scattered, so every stage after the
-factorisation reads local memory only.
+Communication per evaluation and GPU: the packed factor slabs (4 N^2 B received) + the diagonal-block inverses (8 N nb B)
++ three small all-reduces — 14.4 GB at C5 for every P; round 2 also moved the inverse's column blocks (another 4 N^2 B).
+Memory per GPU: the same three N x N buffers as the single-GPU path (86 GB at C5 of 288 GB).
 
-Without RCCL (tests: two processes sharing one GPU over "gloo") the broadcasts are staged through host memory.
+Without RCCL (tests: several processes sharing one GPU over "gloo") the collectives are staged through host memory.
+``GPP_SHARDED_FORCE_COLLECTIVES=1`` issues every collective (and the packing around it) even in a group of one rank, so that
+the RCCL branch runs on a single GPU (tests/test_gpu_sharded.py).
 """
 from __future__ import annotations
 
+import os
 import warnings
 from typing import List, Optional, Tuple
 
@@ -50,13 +60,18 @@ class _Comm:
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.direct = dist.get_backend(group) == "nccl"  # RCCL moves device memory itself
+        # data travels (and is packed / unpacked around the collectives) when there is more than one rank — or always, on
+        # request: the RCCL calls, their stream ordering and the buffer reuse then execute in a group of ONE rank too
+        self.travel = self.world > 1 or os.environ.get("GPP_SHARDED_FORCE_COLLECTIVES", "0") not in ("", "0")
+        self.calls = 0  # collectives issued (tests)
 
     def _global(self, r: int) -> int:
         return r if self.group is None else dist.get_global_rank(self.group, r)
 
     def bcast(self, t: torch.Tensor, src: int) -> None:
-        if self.world == 1:
+        if not self.travel:
             return
+        self.calls += 1
         if self.direct:
             dist.broadcast(t, self._global(src), group=self.group)
             return
@@ -66,8 +81,9 @@ class _Comm:
             t.copy_(h)
 
     def allreduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM) -> None:
-        if self.world == 1:
+        if not self.travel:
             return
+        self.calls += 1
         if self.direct:
             dist.all_reduce(t, op=op, group=self.group)
             return
@@ -82,12 +98,14 @@ class ShardedWorkspace:
     def __init__(self, ctx: GppContext, N: int, nb: int):
         dev = ctx.device
         self.N, self.nb = N, nb
-        self.A = square_buffer(N, dev)      # Ky block rows (owned) -> the whole factor U after the broadcasts
-        self.Li = square_buffer(N, dev)     # L^-1 (lower) + mirror (upper)
-        self.Ki = square_buffer(N, dev)     # scratch, then the owned block rows of Ky^-1 (lower)
+        self.A = square_buffer(N, dev)      # upper: Ky block rows (owned) -> the whole factor U; strict lower blocks: its mirror L
+        self.Li = square_buffer(N, dev)     # diagonal blocks: L_kk^-1 (+ mirror); owned column blocks: sums S, then Ky^-1 (lower)
+        self.Ki = square_buffer(N, dev)     # scratch of the factorisation, then the owned column blocks of L^-1 (lower)
         self.ld = self.A.stride(0)
-        self.pack = torch.empty(2 * N * nb, dtype=torch.float64, device=dev)  # two slabs (factor rows / inverse column blocks)
-        self.dbuf = torch.empty(nb * nb, dtype=torch.float64, device=dev)
+        self.pack = torch.empty(N * nb, dtype=torch.float64, device=dev)       # the packed tail of a row slab of the factor
+        self.hbuf = torch.empty(3 * nb * nb, dtype=torch.float64, device=dev)  # its packed head: diagonal block, block k+1, inverse
+        self.comm_stream = torch.cuda.Stream(device=dev)
+        self.dscr = torch.zeros(nb, nb, dtype=torch.float64, device=dev)       # scratch of the back-substitution's diagonal blocks
         self.z = torch.empty(N, dtype=torch.float64, device=dev)
         self.alpha = torch.empty(N, dtype=torch.float64, device=dev)
         self.r = torch.empty(N, dtype=torch.float64, device=dev)
@@ -95,11 +113,6 @@ class ShardedWorkspace:
         self.offs: List[int] = list(range(0, N, nb)) + [N]
         self.info = torch.zeros(len(self.offs), dtype=torch.int32, device=dev)
         self.epoch = 0
-
-    def rows(self, buf: torch.Tensor, o: int, n: int) -> torch.Tensor:
-        """Contiguous slab of ``n`` full rows (including the row padding) of one of the square buffers."""
-        base = buf._base if buf._base is not None else buf
-        return base[o:o + n]
 
 
 _workspaces = {}
@@ -115,151 +128,317 @@ def _workspace(ctx: GppContext, N: int, nb: int) -> ShardedWorkspace:
     return ws
 
 
+class _RowEvents:
+    """Which event marks the latest update of each block row, and on which stream it was recorded: a launch on another
+    stream waits for the events of the rows it touches (launches on the producing stream are ordered anyway)."""
+
+    def __init__(self):
+        self.last = {}
+
+    def produced(self, rows, stream) -> None:
+        rows = list(rows)
+        if not rows:
+            return
+        ev = torch.cuda.Event()
+        ev.record(stream)
+        for i in rows:
+            self.last[i] = (ev, stream)
+
+    def needed(self, rows, stream) -> None:
+        seen = set()
+        for i in rows:
+            hit = self.last.get(i)
+            if hit is not None and hit[1] is not stream and id(hit[0]) not in seen:
+                seen.add(id(hit[0]))
+                stream.wait_event(hit[0])
+
+
+#: one step of look-ahead in the forward / backward sweeps (the small per-step products on a second stream)
+_SWEEP_LOOKAHEAD = os.environ.get("GPP_SHARD_SWEEP_LOOKAHEAD", "0") not in ("", "0")
+#: entries of the trailing matrix the CU-masked stream takes beside a running panel (the single-GPU driver's GPP_SPLIT_ELEMS)
+_EARLY_ELEMS = int(os.environ.get("GPP_SHARD_EARLY_ELEMS", "0"))
+
+
 def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, grp, kind, d_split, jitter: float) -> int:
-    """Distributed build + Cholesky.  Returns the LAPACK-style info (0 = ok) agreed on by all ranks."""
-    N, offs, P, me = ws.N, ws.offs, comm.world, comm.rank
+    """Distributed build + Cholesky.  Returns the LAPACK-style info (0 = ok) agreed on by all ranks.
+
+    Step k, stream by stream (``side`` = the library's 32-CU panel stream, ``upd`` = its 224-CU throughput stream, ``full`` = its
+    stream without a CU mask, ``cs`` = collectives; events in capitals):
+      owner of k   side: wait DIAG(k); factor + invert the diagonal block; FACTORED; solve the HEAD of the row (the columns of
+                         block k+1)
+                   upd : wait FACTORED; solve the TAIL of the row (columns from block k+2 on)
+      everybody    cs  : broadcast head (+ diagonal block and its inverse), then tail  [nothing when there is one rank]
+      owner of k+1 side: on the head: A[k+1, k+1] -= U[k, k+1]^T U[k, k+1]; DIAG(k+1) — the next panel starts here, while the
+                         tail is still being solved / travelling: the chain of diagonal blocks carries no wide launch and never
+                         leaves the 32 panel CUs
+      everybody    upd : on the tail: rest of block row k+1, block row k+2 (the next steps' heads and diagonal blocks depend on
+                         them), a few early rows beside the running panel;  full: the bulk, once that panel is done.
+    """
+    N, offs, P, me, nb = ws.N, ws.offs, comm.world, comm.rank, ws.nb
     nblk = len(offs) - 1
     A, Li, Ki = ws.A, ws.Li, ws.Ki
     main = torch.cuda.current_stream(ctx.index)
-    # The library's two CU-masked streams: diagonal blocks (single-work-group leaves that need a CU to themselves) are
-    # factored on 32 reserved CUs while the other CUs run the trailing updates — see gpp_api.hip, ensure_streams.
-    side, upd = ctx.internal_streams()
+    side, upd, full = ctx.internal_streams()
+    cs = ws.comm_stream
+    owned = lambda a, b: [i for i in range(max(a, 0), min(b, nblk)) if i % P == me]  # noqa: E731
     ws.info.zero_()
-    for k in range(me, nblk, P):
+    for k in owned(0, nblk):
         ctx.kernel_build(U, w, sf2, tau, grp, A, jitter=jitter, kind=kind, d_split=d_split, uplo=UPLO_FULL, row0=offs[k],
                          nrows=offs[k + 1] - offs[k])
-    side.wait_stream(main)
-    upd.wait_stream(main)
-    row_ready = torch.cuda.Event()
-    row_ready.record(main)
+    for s in (side, upd, full, cs):
+        s.wait_stream(main)
+    rows = _RowEvents()   # latest update of each block row (the build is ordered before everything by the waits above)
+    diag_ready = None     # DIAG(k): the diagonal block of the step about to start carries every update
+    pending = None        # the bulk of the previous step's update, held back until this step's panel is enqueued
+
+    def row_update(i, c0, k_o, k_o1, stream):
+        """A[i, c0:] -= U[k, i]^T U[k, c0:] for block row i (columns from c0 on)."""
+        oi, oi1 = offs[i], offs[i + 1]
+        ctx.gemm(1, 0, oi1 - oi, N - c0, k_o1 - k_o, -1.0, A[k_o:k_o1, oi:oi1], A[k_o:k_o1, c0:N], 1.0, A[oi:oi1, c0:N])
+
+    def issue_bulk(job, after=None):
+        o_, o1_, first, arrived_ = job
+        with torch.cuda.stream(full):
+            full.wait_event(arrived_)
+            if after is not None:
+                full.wait_event(after)
+            bulk = owned(first, nblk)
+            if bulk:
+                oc = offs[first]
+                rows.needed(bulk, full)
+                ctx.syrk_rows(A[o_:o1_, oc:N], A[oc:N, oc:N], nb, first, me, P)
+                rows.produced(bulk, full)
+            if o1_ < N:  # the mirror L[o1:, k] = U[k, o1:]^T for the back-substitution (off every critical path)
+                ctx.transpose(A[o_:o1_, o1_:N], A[o1_:N, o_:o1_])
+
     for k in range(nblk):
         o, o1 = offs[k], offs[k + 1]
-        nbk, rem, own = o1 - o, N - o1, (k % P == me)
-        with torch.cuda.stream(side):
-            dblk = ws.dbuf[:nbk * nbk].view(nbk, nbk)
-            if own:
-                side.wait_event(row_ready)  # block row k carries every update of the steps before k
-                Akk, Lkk, Tkk = A[o:o1, o:o1], Li[o:o1, o:o1], Ki[o:o1, o:o1]
-                ctx.potrf(Akk, Lkk, ws.info[k:k + 1], Tkk)
-                ctx.trtri(Akk, Lkk, Tkk)
-                if rem > 0:
-                    # U12 = W_kk^T A12 (W = mirrored inverse of the diagonal block), via the scratch: not in place
-                    ctx.gemm(1, 0, nbk, rem, nbk, 1.0, Lkk, A[o:o1, o1:N], 0.0, Ki[o:o1, o1:N], a_mask=1, khi_mode=1)
-                    A[o:o1, o1:N].copy_(Ki[o:o1, o1:N])
-                dblk.copy_(Lkk)
-            # only the meaningful part of the row slab travels (columns o..N, packed): half the xGMI volume of full rows
-            slab = ws.pack[:nbk * (N - o)].view(nbk, N - o)
-            if own:
-                slab.copy_(A[o:o1, o:N])
-            comm.bcast(slab, k % P)
-            comm.bcast(dblk, k % P)
-            if not own:
-                A[o:o1, o:N].copy_(slab)
-                Li[o:o1, o:o1].copy_(dblk)
-            arrived = torch.cuda.Event()
-            arrived.record(side)
+        o2 = offs[k + 2] if k + 2 <= nblk else N  # end of the head's columns (block k+1)
+        nbk, own = o1 - o, (k % P == me)
+        Lkk = Li[o:o1, o:o1]
+        W = Ki[o:o1]  # scratch of the row solves (the product cannot run in place)
+        head_solved = tail_solved = None
+        if own:
+            with torch.cuda.stream(side):
+                if diag_ready is not None:
+                    side.wait_event(diag_ready)
+                else:
+                    rows.needed([k], side)
+                ctx.potrf(A[o:o1, o:o1], Lkk, ws.info[k:k + 1], Ki[o:o1, o:o1])
+                ctx.trtri(A[o:o1, o:o1], Lkk, Ki[o:o1, o:o1])
+                factored = torch.cuda.Event()
+                factored.record(side)
+                # U12 = W_kk^T A12 (W_kk = mirrored inverse of the diagonal block).  The HEAD (the columns of block k+1) is
+                # solved here, on the panel's own CUs: the chain factor -> head -> next diagonal block -> factor never queues
+                # behind a wide launch of the throughput streams
+                if o2 > o1:
+                    rows.needed([k], side)  # block row k carries every update of the steps before k
+                    ctx.gemm(1, 0, nbk, o2 - o1, nbk, 1.0, Lkk, A[o:o1, o1:o2], 0.0, W[:, o1:o2], a_mask=1, khi_mode=1)
+                    A[o:o1, o1:o2].copy_(W[:, o1:o2])
+                head_solved = torch.cuda.Event()
+                head_solved.record(side)
+            if pending is not None:
+                # the bulk of step k-1 takes every CU, so it starts only when this diagonal block is done (a leaf needs a CU
+                # to itself and would otherwise wait for the whole update to drain)
+                issue_bulk(pending, after=factored)
+                pending = None
+            with torch.cuda.stream(upd):
+                upd.wait_event(factored)
+                rows.needed([k], upd)
+                if N > o2:  # the TAIL of the row (columns from block k+2 on): one wide launch on the throughput CUs
+                    ctx.gemm(1, 0, nbk, N - o2, nbk, 1.0, Lkk, A[o:o1, o2:N], 0.0, W[:, o2:N], a_mask=1, khi_mode=1)
+                    A[o:o1, o2:N].copy_(W[:, o2:N])
+                upd.wait_event(head_solved)  # (TAIL below stands for the whole row)
+                tail_solved = torch.cuda.Event()
+                tail_solved.record(upd)
+        elif pending is not None:  # (cannot happen: a held-back bulk belongs to the rank that factors this block)
+            issue_bulk(pending)
+            pending = None
+        if comm.travel:
+            with torch.cuda.stream(cs):
+                # only the meaningful part of the row travels (columns o..N, packed): half the xGMI volume of full rows
+                wh = o2 - o
+                head = ws.hbuf[:nbk * wh].view(nbk, wh)
+                dblk = ws.hbuf[nbk * wh:nbk * (wh + nbk)].view(nbk, nbk)
+                if own:
+                    cs.wait_event(head_solved)
+                    head.copy_(A[o:o1, o:o2])
+                    dblk.copy_(Lkk)
+                comm.bcast(ws.hbuf[:nbk * (wh + nbk)], k % P)
+                if not own:
+                    A[o:o1, o:o2].copy_(head)
+                    Lkk.copy_(dblk)
+                head_arrived = torch.cuda.Event()
+                head_arrived.record(cs)
+                if N > o2:
+                    tail = ws.pack[:nbk * (N - o2)].view(nbk, N - o2)
+                    if own:
+                        cs.wait_event(tail_solved)
+                        tail.copy_(A[o:o1, o2:N])
+                    comm.bcast(ws.pack[:nbk * (N - o2)], k % P)
+                    if not own:
+                        A[o:o1, o2:N].copy_(tail)
+                arrived = torch.cuda.Event()
+                arrived.record(cs)
+        else:
+            head_arrived, arrived = head_solved, tail_solved
+        if k + 1 >= nblk:
+            break
+        # ---- this rank's share of the trailing update A[i, i:] -= U[k, i]^T U[k, i:], i > k -------------------------------
+        panel_here = (k + 1) % P == me  # the next diagonal block is factored on THIS GPU while the update runs
+        rem = N - o1
+        extra = max(0, -(-_EARLY_ELEMS // max(rem, 1)) // nb - 2) if panel_here else 0
+        e_end = min(k + 3 + extra, nblk)  # block rows [k+3, e_end) go early; [e_end, nblk) are the bulk
+        if nblk - e_end < 2:
+            e_end = nblk
+        diag_ready = None
+        if panel_here:
+            with torch.cuda.stream(side):  # the next diagonal block, as soon as the head is here (panel CUs again)
+                side.wait_event(head_arrived)
+                rows.needed([k + 1], side)
+                ctx.gemm(1, 0, o2 - o1, o2 - o1, nbk, -1.0, A[o:o1, o1:o2], A[o:o1, o1:o2], 1.0, A[o1:o2, o1:o2], c_tri=2)
+                diag_ready = torch.cuda.Event()
+                diag_ready.record(side)
         with torch.cuda.stream(upd):
             upd.wait_event(arrived)
-            if k + 1 < nblk:
-                # block row k+1 first (its owner factors it next), then every other owned block row in ONE launch
-                o2 = offs[k + 2] if k + 2 <= nblk else N
-                if (k + 1) % P == me:
-                    ctx.gemm(1, 0, o2 - o1, N - o1, nbk, -1.0, A[o:o1, o1:o2], A[o:o1, o1:N], 1.0, A[o1:o2, o1:N])
-                    row_ready = torch.cuda.Event()
-                    row_ready.record(upd)
-                if o2 < N:
-                    ctx.syrk_rows(A[o:o1, o2:N], A[o2:N, o2:N], ws.nb, k + 2, me, P)
-    main.wait_stream(side)
-    main.wait_stream(upd)
+            if panel_here and N > o2:
+                row_update(k + 1, o2, o, o1, upd)  # the rest of block row k+1: the next step's head and tail come from it
+                rows.produced([k + 1], upd)
+            for i in owned(k + 2, e_end):  # block row k+2 (the diagonal block after next), then the early rows: one launch each
+                rows.needed([i], upd)
+                row_update(i, offs[i], o, o1, upd)
+                rows.produced([i], upd)
+        job = (o, o1, e_end, arrived)
+        if panel_here:
+            pending = job  # issued in the next iteration, behind that panel
+        else:
+            issue_bulk(job)
+    if pending is not None:
+        issue_bulk(pending)
+    for s in (side, upd, full, cs):
+        main.wait_stream(s)
     info = ws.info.max().to(torch.int32).reshape(1)
     comm.allreduce(info, dist.ReduceOp.MAX)
     return int(info.item())
 
 
-def _inverse(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
-    """L^-1 (lower) and its mirror (upper) on every rank, from the replicated factor and diagonal-block inverses."""
-    N, offs, P, me = ws.N, ws.offs, comm.world, comm.rank
+def _first_owned(ws: ShardedWorkspace, comm: _Comm) -> Optional[int]:
+    return comm.rank if comm.rank < len(ws.offs) - 1 else None
+
+
+def _forward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
+    """The owned column blocks of L^-1 (rows at and below their diagonal block) into ``Ki``, from the replicated factor and
+    diagonal-block inverses: forward substitution of all owned column blocks together, one block row j at a time.  The owned
+    blocks up to j (c = me, me+P, ... <= j, all nb wide) sit at the regular column spacing P*nb, so each step is ONE batched
+    launch per product:
+        Y_j[c] = -X_jj S_j[c]                (X_jj^T = the mirror in the upper part of the diagonal block; finished rows go to ``Ki``;
+                                              the own block of the step is Y_j[j] = X_jj itself)
+        S_k[c] += L[k, j] Y_j[c],  k > j     (L[k, j] = U[j, k]^T, shared by the whole batch; the sums S live in ``Li``)
+    with one step of look-ahead: the update's first block row (k = j+1) is issued on its own, and the small product of step j+1
+    then runs on a second stream beside the rest of step j's update instead of alone on the chip."""
+    N, offs, P, me, nb = ws.N, ws.offs, comm.world, comm.rank, ws.nb
     nblk = len(offs) - 1
     A, Li, Ki = ws.A, ws.Li, ws.Ki
-    nb, ld = ws.nb, ws.ld
-    Li_base = Li._base if Li._base is not None else Li
-    Ki_base = Ki._base if Ki._base is not None else Ki
-    for c in range(me, nblk, P):
-        oc, oc1 = offs[c], offs[c + 1]
-        if oc1 < N:
-            Li[oc1:N, oc:oc1].zero_()
-    # Forward substitution of all owned column blocks together, one block row j at a time.  The owned blocks left of j
-    # (c = me, me+P, ... < j, all nb wide) sit at the regular column spacing P*nb, so each step is ONE batched launch
-    # per product:  Y_j[c] = -X_jj S_j[c]  (X_jj^T = the mirror in the upper part of the diagonal block), then
-    # S_k[c] += L[k, j] Y_j[c] for every block k below (L[k, j] = U[j, k]^T, shared by the whole batch).
-    oc0 = offs[me] if me < nblk else 0
-    for j in range(nblk):
+    if _first_owned(ws, comm) is None:
+        return
+    oc0 = offs[me]
+    main = torch.cuda.current_stream(ctx.index)
+    aux = ctx.internal_streams()[2] if _SWEEP_LOOKAHEAD else main
+    aux.wait_stream(main)
+    for c in range(me, nblk - 1, P):  # the sums of the owned column blocks start from zero
+        Li[offs[c + 1]:N, offs[c]:offs[c + 1]].zero_()
+    row_done = torch.cuda.Event()  # block row j of the sums is complete
+    row_done.record(main)
+    for j in range(me, nblk):
         oj, oj1 = offs[j], offs[j + 1]
         nbj = oj1 - oj
-        nleft = (j - me + P - 1) // P if j > me else 0
-        if nleft > 0:
-            ctx.gemm_batched(1, 0, nbj, nb, nbj, -1.0, Li[oj:oj1, oj:oj1], 0, Li[oj:oj1, oc0:oc0 + nb], P * nb, 0.0,
-                             Ki[oj:oj1, oc0:oc0 + nb], P * nb, nleft, a_mask=1, khi_mode=1)
-            shape, strides, start = (nbj, nleft, nb), (ld, P * nb, 1), oj * ld + oc0
-            Li_base.as_strided(shape, strides, start).copy_(Ki_base.as_strided(shape, strides, start))
-            if oj1 < N:
-                ctx.gemm_batched(1, 0, N - oj1, nb, nbj, 1.0, A[oj:oj1, oj1:N], 0, Li[oj:oj1, oc0:oc0 + nb], P * nb, 1.0,
-                                 Li[oj1:N, oc0:oc0 + nb], P * nb, nleft)
-        if j % P == me and oj1 < N:
-            # own column block starts here: Y_j = X_jj itself (lower triangular; its slot also holds the mirror above the
-            # diagonal, masked out: keep k >= n)
-            ctx.gemm(1, 0, N - oj1, nbj, nbj, 1.0, A[oj:oj1, oj1:N], Li[oj:oj1, oj:oj1], 1.0, Li[oj1:N, oj:oj1], b_mask=2,
-                     klo_mode=2)
+        nleft = len(range(me, j, P))
+        own = j % P == me
+        with torch.cuda.stream(aux):
+            aux.wait_event(row_done)
+            if nleft > 0:
+                ctx.gemm_batched(1, 0, nbj, nb, nbj, -1.0, Li[oj:oj1, oj:oj1], 0, Li[oj:oj1, oc0:oc0 + nb], P * nb, 0.0,
+                                 Ki[oj:oj1, oc0:oc0 + nb], P * nb, nleft, a_mask=1, khi_mode=1)
+            if own:  # Y_j[j] = X_jj: lower triangle, zeros above (its slot in Li also holds the mirror)
+                Ki[oj:oj1, oj:oj1].copy_(Li[oj:oj1, oj:oj1])
+                Ki[oj:oj1, oj:oj1].tril_()
+            y_done = torch.cuda.Event()
+            y_done.record(aux)
+        nb_all = nleft + (1 if own else 0)
+        if oj1 < N and nb_all > 0:
+            main.wait_event(y_done)
+            oj2 = offs[j + 2]
+            for r0, r1 in (((oj1, oj2), (oj2, N)) if _SWEEP_LOOKAHEAD else ((oj1, N),)):  # block row j+1 first: the next step's small product waits for it only
+                if r1 > r0:
+                    ctx.gemm_batched(1, 0, r1 - r0, nb, nbj, 1.0, A[oj:oj1, r0:r1], 0, Ki[oj:oj1, oc0:oc0 + nb], P * nb, 1.0,
+                                     Li[r0:r1, oc0:oc0 + nb], P * nb, nb_all)
+                if r1 == oj2 and _SWEEP_LOOKAHEAD:
+                    row_done = torch.cuda.Event()
+                    row_done.record(main)
+        else:
+            main.wait_event(y_done)
+    main.wait_stream(aux)
 
 
-def _exchange_inverse(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, with_lauum: bool) -> None:
-    """Broadcast the column blocks of L^-1 (packed: the rows below each diagonal block) so that every rank holds L^-1 (lower)
-    and its mirror (upper) — and, when the gradient is wanted, PIPELINE this rank's share of Ky^-1 = L^-T L^-1 with the
-    broadcasts: Ky^-1[i, j <= i] needs the column blocks i and j of L^-1 only, so the tile rows of block row c are formed
-    (``gpp_lauum_rows_range``, on the calling stream) as soon as column block c has arrived, while the side stream moves
-    column block c+1.  4 N^2 bytes per GPU travel here against N^3 / (3 P) flops of product per GPU: at C5 on 8 GPUs 14 GB
-    beside 9e12 flop, i.e. comparable times — serialised they would add up."""
-    N, offs, P, me = ws.N, ws.offs, comm.world, comm.rank
+def _vectors(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, need_alpha: bool) -> None:
+    """z = L^-1 r, the scalars of the MLL, and alpha = L^-T z, from the owned column blocks of L^-1 in ``Ki``: each rank forms its
+    part (sums over its columns / its entries) and the parts are added by an all-reduce of N doubles."""
+    P, me, nb = comm.world, comm.rank, ws.nb
+    ctx.trmv_lower_cols(ws.Ki, ws.r, ws.z, nb, me, P, trans=False)
+    comm.allreduce(ws.z)
+    ctx.mll_scalars(ws.A, ws.z, ws.out3)
+    if need_alpha:
+        ctx.trmv_lower_cols(ws.Ki, ws.z, ws.alpha, nb, me, P, trans=True)
+        comm.allreduce(ws.alpha)
+
+
+def _backward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
+    """The owned column blocks of Ky^-1 = L^-T L^-1 (rows at and below their diagonal block) into ``Li``, by back-substitution of
+    the owned column blocks Y of L^-1 (in ``Ki``) against the replicated factor:  U[c:, c:] Z = Y, block row j from the last
+    one up:   Z_j = X_jj^T Y_j   (X_jj = L_jj^-1: the lower part of the diagonal block of ``Li``), then the right-looking update
+    Y_i -= U[i, j] Z_j of every block row c <= i < j — ONE TN GEMM per step over the lower-triangular tiles of the owned
+    column blocks, its row-contiguous left operand being the factor's mirror L[j, i] in the strict lower triangle of ``A``.
+    One step of look-ahead as in ``_forward``: block row j-1 of the update first, the small products of step j-1 on a second
+    stream beside the rest.  No communication (bullet 4)."""
+    offs, P, me, nb = ws.offs, comm.world, comm.rank, ws.nb
     nblk = len(offs) - 1
-    Li = ws.Li
+    A, Li, Ki = ws.A, ws.Li, ws.Ki
+    if _first_owned(ws, comm) is None:
+        return
+    oc0 = offs[me]
     main = torch.cuda.current_stream(ctx.index)
-    side, _ = ctx.internal_streams()
-    side.wait_stream(main)  # the sweeps that produced the owned column blocks
-    # two packing buffers so that the unpack of block c and the broadcast of block c+1 never share memory
-    half = ws.pack.numel() // 2
-    bounds, b = [], 0  # exclusive ends of the groups of block rows: halves of what is left, at most 6 groups
-    if P == 1:
-        bounds, b = [nblk], nblk  # nothing travels: one launch, as on the single-GPU path
-    while b < nblk:
-        b = nblk if len(bounds) == 5 else b + max(1, (nblk - b + 1) // 2)
-        bounds.append(b)
-    group_start = 0
-    for c in range(nblk):
-        oc, oc1 = offs[c], offs[c + 1]
-        if oc1 < N:
-            wc = oc1 - oc
-            with torch.cuda.stream(side):
-                if P > 1:
-                    base = (c & 1) * half
-                    buf = ws.pack[base:base + (N - oc1) * wc].view(N - oc1, wc)
-                    if c % P == me:
-                        buf.copy_(Li[oc1:N, oc:oc1])
-                    comm.bcast(buf, c % P)
-                    if c % P != me:
-                        Li[oc1:N, oc:oc1].copy_(buf)
-                ctx.transpose(Li[oc1:N, oc:oc1], Li[oc:oc1, oc1:N])  # mirror (tiled through LDS: gpp_transpose)
-        # (the last column block is its diagonal block, which every rank already has)
-        if with_lauum and c + 1 == bounds[0]:
-            # a GROUP of block rows per launch: one launch per block row leaves the early rows (a handful of tiles with the
-            # longest K ranges, several ms each) alone on the chip — measured with one rank at N = 20000: 70 ms for 20
-            # launches against 41 ms for the single launch.  Groups halve what is left ([0, 1/2), [1/2, 3/4), ...): every
-            # launch has hundreds of tiles, and the heavy early broadcasts still overlap the previous group's product.
-            arrived = torch.cuda.Event()
-            arrived.record(side)
-            main.wait_event(arrived)
-            ctx.lauum_rows_range(ws.Li, ws.Ki, me, P, offs[group_start], oc1)
-            group_start = bounds.pop(0)
-    main.wait_stream(side)
+    aux = ctx.internal_streams()[2] if _SWEEP_LOOKAHEAD else main
+    row_done = torch.cuda.Event()
+    row_done.record(main)
+    for j in range(nblk - 1, me - 1, -1):
+        oj, oj1 = offs[j], offs[j + 1]
+        nbj = oj1 - oj
+        nleft = len(range(me, j, P))  # owned column blocks strictly left of j
+        Xjj = Li[oj:oj1, oj:oj1]
+        with torch.cuda.stream(aux):
+            aux.wait_event(row_done)
+            if nleft > 0:
+                ctx.gemm_batched(1, 0, nbj, nb, nbj, 1.0, Xjj, 0, Ki[oj:oj1, oc0:oc0 + nb], P * nb, 0.0, Li[oj:oj1, oc0:oc0 + nb],
+                                 P * nb, nleft, a_mask=2, klo_mode=1)
+            if j % P == me:
+                # the diagonal block of Ky^-1: both operands lower triangular, only its lower part is wanted (and only the lower
+                # part of Y_j[j] is kept up to date) — the LAUUM shape; through the scratch, the product cannot run in place
+                d = ws.dscr[:nbj, :nbj]
+                ctx.gemm(1, 0, nbj, nbj, nbj, 1.0, Xjj, Ki[oj:oj1, oj:oj1], 0.0, d, a_mask=2, b_mask=2, klo_mode=3, c_tri=1)
+                Xjj.copy_(d)
+            z_done = torch.cuda.Event()
+            z_done.record(aux)
+        main.wait_event(z_done)
+        if nleft > 0:
+            M = oj - oc0
+            lo = max(offs[j - 1] - oc0, 0)
+            for r0, r1 in (((lo, M), (0, lo)) if _SWEEP_LOOKAHEAD else ((0, M),)):  # block row j-1 first
+                if r1 > r0:
+                    ctx.gemm_lower_cols(A[oj:oj1, oc0:oj], Li[oj:oj1, oc0:oj], Ki[oc0:oj, oc0:oj], -1.0, 1.0, nb, me, me, P, r0, r1)
+                if r0 == lo and _SWEEP_LOOKAHEAD:
+                    row_done = torch.cuda.Event()
+                    row_done.record(main)
+    main.wait_stream(aux)
 
 
 class ShardedMLLFunction(torch.autograd.Function):
@@ -297,13 +476,13 @@ class ShardedMLLFunction(torch.autograd.Function):
             warnings.warn(f"A not p.d., added jitter of {used:.1e} to the diagonal", RuntimeWarning)
         need_grad = any(ctx.needs_input_grad[:6])
         with _stage("shard_inverse"):
-            _inverse(gctx, comm, ws)
-            # (with a gradient: this rank's share of Ky^-1 is formed here too, block row by block row behind the broadcasts)
-            _exchange_inverse(gctx, comm, ws, with_lauum=need_grad)
+            _forward(gctx, comm, ws)
         torch.sub(f64(y), f64(mean), out=ws.r)
-        gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
+        _vectors(gctx, comm, ws, need_alpha=need_grad)
         if need_grad:
-            gctx.alpha(ws.Li, ws.z, ws.alpha)
+            with _stage("shard_backsolve"):
+                _backward(gctx, comm, ws)
+        ws.comm_calls = comm.calls  # (tests: the collectives really ran)
         ctx.saved = (gctx, comm, ws, ws.epoch, Ud, wd, sd, grp, td.numel(), kind, d_split, dU)
         ctx.in_dtypes = (U.dtype, w.dtype, sf2.dtype, tau.dtype, mean.dtype, y.dtype)
         ctx.shapes = (sf2.shape, tau.shape)
@@ -322,9 +501,10 @@ class ShardedMLLFunction(torch.autograd.Function):
         flat = torch.zeros(D + 1 + S + nU, dtype=torch.float64, device=dev)
         g_w, g_s, g_t = flat[:D], flat[D:D + 1], flat[D + 1:D + 1 + S]
         g_Ud = flat[D + 1 + S:].view(N, dU) if need_U else None
-        gctx.grad_reduce_rows(Ud, wd, sd, grp, S, ws.alpha, ws.Ki, dU if need_U else 0, 128, comm.rank, comm.world, g_w,
+        gctx.grad_reduce_cols(Ud, wd, sd, grp, S, ws.alpha, ws.Li, dU if need_U else 0, ws.nb, comm.rank, comm.world, g_w,
                               g_s, g_t, g_Ud, kind=kind, d_split=d_split)
         comm.allreduce(flat)
+        ws.comm_calls = comm.calls
         g_U = None
         if ctx.needs_input_grad[0]:
             g_U = torch.zeros(N, D, dtype=torch.float64, device=dev)

@@ -61,8 +61,9 @@ int gpp_set_stream(gpp_handle_t h, void* stream);
  * calling stream waits for all of them before the entry point's work is complete in stream order.
  * The first two are exposed here, with their disjoint CU sets: which = 0 the latency stream (32 CUs,
  * one per shader engine) on which gpp_potrf_ws factors diagonal blocks, which = 1 the throughput stream (the other CUs)
- * of its trailing updates.  A host-side driver that overlaps its own panel factorisations with its own updates (the
- * sharded evaluation, gp-plus_amd/sharded.py) enqueues on them through gpp_set_stream.  *out receives a hipStream_t. */
+ * of its trailing updates, which = 2 the stream without a CU mask.  A host-side driver that overlaps its own panel
+ * factorisations with its own updates (the sharded evaluation, gp-plus_amd/sharded.py) enqueues on them through
+ * gpp_set_stream.  *out receives a hipStream_t. */
 int gpp_internal_stream(gpp_handle_t h, int which, void** out);
 size_t gpp_workspace_bytes(gpp_handle_t h, int op, int64_t N, int64_t M, int D, int S);
 int gpp_set_workspace(gpp_handle_t h, void* ws, size_t bytes);
@@ -114,6 +115,28 @@ int gpp_lauum(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double
 int gpp_syrk_rows(gpp_handle_t h, const double* Urow, int64_t ldu, double* C, int64_t ldc, int64_t Nt, int64_t K, int64_t nb,
                   int64_t first_block, int rank, int nranks);
 
+/* One right-looking step of the sharded evaluation's BACK-substitution ("each GPU solves for its own
+ * block-columns of L^-T L^-1 E_k"): C(lower triangle of M x M) = beta C + alpha A^T B on the column blocks (width nb, a multiple
+ * of 128) this rank owns — column block i of C (0-based) is global block first_block + i, owned when
+ * (first_block + i) % nranks == rank; other ranks' column blocks are neither read nor written.  A: K x M (rows of the factor's
+ * mirror L = U^T), B: K x M (the just-solved block row of Ky^-1), both row-contiguous.  Only the rows [row0, row1) of C are produced
+ * (row0 a multiple of 128): the block row the next step depends on is issued first, the rest behind it.  Replaces the broadcast of the inverse's
+ * column blocks + the LAUUM share (gpp_lauum_rows_range); reference counterpart: ATen cholesky_backward, optim/mll_torch.py:117. */
+int gpp_gemm_lower_cols(gpp_handle_t h, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
+                        int64_t M, int64_t K, double alpha, double beta, int64_t nb, int64_t first_block, int rank, int nranks,
+                        int64_t row0, int64_t row1);
+
+/* Products with a lower-triangular T of which only the block-cyclically owned COLUMN blocks (width nb, a multiple of 64; block
+ * b owned when b % nranks == rank) exist on this rank:  trans = 0: y_i = sum over owned columns k <= i of T[i][k] x_k (this
+ * rank's part of z = L^-1 r);  trans = 1: y_k = sum_{i >= k} T[i][k] x_i for the owned columns k and 0 for the others (this
+ * rank's entries of alpha = L^-T z).  The caller sums the results of all ranks (one all-reduce of N doubles each). */
+int gpp_trmv_lower_cols(gpp_handle_t h, const double* T, int64_t ldt, int64_t N, const double* x, double* y, int64_t nb, int rank,
+                        int nranks, int trans);
+
+/* out3 = { quad = z'z, logdet = 2 sum log U_ii, mll = -0.5*(quad + logdet + N log 2pi) } from a z the caller already holds
+ * (the second half of gpp_mll_reduce; optim/mll_torch.py:116). */
+int gpp_mll_scalars(gpp_handle_t h, const double* U, int64_t ld, int64_t N, const double* z, double* out3);
+
 /* The share of gpp_lauum owned by one rank of a sharded evaluation: the 128-row tile rows t of Kinv with
  * t % nranks == rank, in ONE launch (cyclic at tile granularity: every rank gets the same mix of short and long rows).
  * Linv must be complete on this rank; the other tile rows of Kinv are not touched. */
@@ -156,6 +179,13 @@ int gpp_grad_reduce(gpp_handle_t h, const double* U, int64_t N, int D, const dou
  * read; the outputs are this rank's PARTIAL sums (the caller all-reduces them).  nranks == 1 is gpp_grad_reduce.
  */
 int gpp_grad_reduce_rows(gpp_handle_t h, const double* U, int64_t N, int D, const double* w, const double* sf2,
+                         const int32_t* grp, int S, int kind, int d_split, const double* alpha, const double* Kinv,
+                         int64_t ldk, int dU, int64_t nb, int rank, int nranks, double* g_w, double* g_sf2, double* g_tau,
+                         double* g_U);
+
+/* The same reduction over the block-cyclically owned COLUMN blocks of Kinv's lower triangle (columns [b*nb, (b+1)*nb) with
+ * b % nranks == rank): what a rank holds after the sharded back-substitution (gpp_gemm_lower_cols). */
+int gpp_grad_reduce_cols(gpp_handle_t h, const double* U, int64_t N, int D, const double* w, const double* sf2,
                          const int32_t* grp, int S, int kind, int d_split, const double* alpha, const double* Kinv,
                          int64_t ldk, int dU, int64_t nb, int rank, int nranks, double* g_w, double* g_sf2, double* g_tau,
                          double* g_U);

@@ -1,13 +1,14 @@
-"""Sharded single evaluation (gp-plus_amd/sharded.py, SURVEY.md §8(e) mode 2): two ranks against the single-GPU path.
-On a box with one GPU both ranks share it and communicate over gloo; with >= 2 GPUs they use RCCL."""
+"""Sharded single evaluation (gp-plus_amd/sharded.py, SURVEY.md §8(e) mode 2): two and more ranks against the single-GPU path.
+On a box with one GPU the ranks share it and communicate over gloo; with one GPU per rank they use RCCL.  The RCCL branch
+itself is exercised on one GPU by a group of ONE rank with every collective forced (GPP_SHARDED_FORCE_COLLECTIVES)."""
 import json, os, subprocess, sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, world=2, port=29531):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run(args, world=2, port=29531, **extra_env):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "workers", "sharded_worker.py")] + [str(a) for a in args]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
@@ -44,6 +45,24 @@ def test_sharded_matches_single_gpu(N, D, nb, kind, S, dU):
 ])
 def test_sharded_more_ranks_and_block_counts(world, N, D, nb, kind, S, dU):
     out = _run([N, D, nb, kind, S, dU], world=world, port=29560 + (N * 7 + world * 13 + nb) % 400)  # distinct rendezvous ports
+    for name, e in out["err"].items():
+        assert e < 1e-9, (name, e, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,D,nb,kind,S,dU", [
+    (20000, 8, 1024, 0, 1, 0),   # the C2 size: 20 slab broadcasts of up to 164 MB, the split updates and the panel stream around them
+    (3000, 6, 256, 0, 2, 2),     # ragged last block, per-group noise, manifold gradients (the all-reduce carries N dU doubles)
+])
+def test_sharded_rccl_branch_with_one_rank(N, D, nb, kind, S, dU):
+    """``init_process_group("nccl", world_size=1)`` + GPP_SHARDED_FORCE_COLLECTIVES=1: ``_Comm.direct`` — dist.broadcast /
+    all_reduce on device memory from the CU-masked side stream, the packing buffers' reuse, RCCL's own stream ordered against
+    the library's three internal streams — runs on the 1-GPU box, and must reproduce the single-GPU path."""
+    out = _run([N, D, nb, kind, S, dU], world=1, port=29900 + N % 50, GPP_TEST_BACKEND="nccl",
+               GPP_SHARDED_FORCE_COLLECTIVES="1")
+    assert out["backend"] == "nccl"
+    nblk = -(-N // nb)
+    assert out["collectives"] >= 2 * nblk + 2, out  # head + tail per block row (the last has no tail), info, z, alpha, gradient
     for name, e in out["err"].items():
         assert e < 1e-9, (name, e, out)
 

@@ -20,6 +20,32 @@ from gpplus_amd.linalg import KernelSpec, exact_mll
 from gpplus_amd import settings
 
 
+def same_as_rank0(flat, dev):
+    """Every rank must hold the sharded result rank 0 holds, bit for bit: rank 0's values are broadcast and compared."""
+    flat = flat.detach().to(dev).reshape(-1).clone()
+    ref = flat.clone()
+    if dist.get_backend() == "nccl":
+        dist.broadcast(ref, 0)
+    else:
+        h = ref.cpu(); dist.broadcast(h, 0); ref = h.to(dev)
+    return bool(torch.equal(flat, ref))
+
+
+def pick_device_and_backend():
+    """One GPU per rank and RCCL when the node has enough GPUs; otherwise every rank on cuda:0 over gloo (host-staged)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    one_each = torch.cuda.device_count() >= world
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if one_each else 0)
+    torch.cuda.set_device(dev)
+    force = os.environ.get("GPP_TEST_BACKEND")  # "nccl": a one-rank RCCL group on the 1-GPU box
+    backend = force or ("nccl" if one_each else "gloo")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
+    return dev
+
+
 def model_case(rank, world, dev, N, nb):
     """The same comparison through the GP_Plus API (mixed inputs: manifold-encoded categoricals, Examples/02 shape)."""
     from gpplus_amd.models import GP_Plus
@@ -46,7 +72,7 @@ def model_case(rank, world, dev, N, nb):
     if rank == 0:
         e = float((out["sharded"] - out["single"]).abs().max() / out["single"].abs().max())
         emit("RESULT " + json.dumps({"err": {"loss_and_grads": e}, "mll": float(out["single"][0]), "backend": dist.get_backend()}))
-    emit(f"RANK{rank} same_as_rank0=True")
+    emit(f"RANK{rank} same_as_rank0={same_as_rank0(out['sharded'], dev)}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -58,10 +84,11 @@ def config_case(name, sharded, nb):
     from gpplus_amd.gpcore import ExactMarginalLogLikelihood
     from gpplus_amd.test_functions.baseline_configs import apply_theta, make_config
     rank = int(os.environ.get("RANK", "0"))
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
     if sharded:
-        dist.init_process_group("nccl" if torch.cuda.device_count() >= int(os.environ["WORLD_SIZE"]) else "gloo")
+        dev = pick_device_and_backend()
+    else:
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(dev)
     X, y, kw, theta = make_config(name)
     torch.manual_seed(0)
     m = GP_Plus(X, y, dtype=torch.float64, device=str(dev), **kw)
@@ -78,7 +105,8 @@ def config_case(name, sharded, nb):
                 vals[n] = p.grad.detach().cpu().reshape(-1).tolist()
         emit("RESULT " + json.dumps({"values": vals}))
     if sharded:
-        emit(f"RANK{rank} same_as_rank0=True")
+        mine = torch.cat([loss.detach().reshape(1)] + [p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
+        emit(f"RANK{rank} same_as_rank0={same_as_rank0(mine, dev)}")
         dist.barrier()
         dist.destroy_process_group()
 
@@ -87,11 +115,7 @@ def main():
     if len(sys.argv) > 2 and sys.argv[1] == "config":
         return config_case(sys.argv[2], sys.argv[3] == "sharded", int(sys.argv[4]))
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    ngpu = torch.cuda.device_count()
-    one_each = ngpu >= world
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if one_each else 0)
-    torch.cuda.set_device(dev)
-    dist.init_process_group("nccl" if one_each else "gloo")
+    dev = pick_device_and_backend()
     N, D, nb, kind, S, dU = (int(a) for a in sys.argv[1:7])
     if len(sys.argv) > 7 and sys.argv[7] == "model":
         return model_case(rank, world, dev, N, nb)
@@ -117,19 +141,15 @@ def main():
         res[mode] = [mll.detach().cpu().reshape(1), w.grad.cpu(), sf2.grad.cpu().reshape(1), tau.grad.cpu(),
                      mean.grad.cpu()] + ([Ud.grad.cpu()[:, :dU].reshape(-1)] if dU > 0 else [])
     # every rank must hold the same sharded result
-    flat = torch.cat([t.reshape(-1) for t in res["sharded"]]).to(dev)
-    ref = flat.clone()
-    if dist.get_backend() == "nccl":
-        dist.broadcast(ref, 0)
-    else:
-        h = ref.cpu(); dist.broadcast(h, 0); ref = h.to(dev)
-    same = bool(torch.equal(flat, ref))
+    same = same_as_rank0(torch.cat([t.reshape(-1) for t in res["sharded"]]), dev)
     if rank == 0:
         names = ["mll", "g_w", "g_sf2", "g_tau", "g_mean"] + (["g_U"] if dU > 0 else [])
         err = {}
         for n, a, b in zip(names, res["sharded"], res["single"]):
             err[n] = float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
-        emit("RESULT " + json.dumps({"err": err, "mll": float(res["single"][0]), "backend": dist.get_backend()}))
+        from gpplus_amd import sharded as _sh
+        calls = sum(getattr(w, "comm_calls", 0) for w in _sh._workspaces.values())
+        emit("RESULT " + json.dumps({"err": err, "mll": float(res["single"][0]), "backend": dist.get_backend(), "collectives": calls}))
     emit(f"RANK{rank} same_as_rank0={same}")
     dist.barrier()
     dist.destroy_process_group()

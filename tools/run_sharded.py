@@ -28,18 +28,18 @@ def main():
     for rep in range(reps + 1):
         sync(); t0 = time.perf_counter()
         info = sharded._factor(ctx, comm, ws, U, w, sf2, tau, None, 0, 0, 0.0); sync(); t1 = time.perf_counter()
-        sharded._inverse(ctx, comm, ws); sync(); t2 = time.perf_counter()
-        sharded._exchange_inverse(ctx, comm, ws, True)  # column-block broadcasts pipelined with this rank's share of Ky^-1
-        torch.sub(y, mean, out=ws.r); ctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3); ctx.alpha(ws.Li, ws.z, ws.alpha)
-        sync(); t3 = time.perf_counter()
+        sharded._forward(ctx, comm, ws); sync(); t2 = time.perf_counter()
+        torch.sub(y, mean, out=ws.r); sharded._vectors(ctx, comm, ws, True); sync(); t3 = time.perf_counter()
+        sharded._backward(ctx, comm, ws)  # this rank's column blocks of Ky^-1 by back-substitution: nothing travels
+        sync(); t4 = time.perf_counter()
         flat = torch.zeros(D + 2, dtype=torch.float64, device=dev)
-        ctx.grad_reduce_rows(U, w, sf2, None, 1, ws.alpha, ws.Ki, 0, 128, comm.rank, comm.world, flat[:D], flat[D:D + 1], flat[D + 1:], None)
-        comm.allreduce(flat); sync(); t4 = time.perf_counter()
+        ctx.grad_reduce_cols(U, w, sf2, None, 1, ws.alpha, ws.Li, 0, nb, comm.rank, comm.world, flat[:D], flat[D:D + 1], flat[D + 1:], None)
+        comm.allreduce(flat); sync(); t5 = time.perf_counter()
         if rank == 0 and rep > 0:
-            tot = t4 - t0
-            print("N=%d D=%d nb=%d ranks=%d backend=%s info=%d: factor %.1f ms, inverse sweeps %.1f ms, exchange+lauum %.1f ms, grad %.1f ms; total %.1f ms -> %.3f evals/s, %.1f TFLOP/s (N^3), mll=%.6f"
-                  % (N, D, nb, world, dist.get_backend(), info, 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t4 - t3), 1e3 * tot, 1 / tot,
-                     N ** 3 / tot / 1e12, ws.out3[2].item()), flush=True)
+            tot = t5 - t0
+            print("N=%d D=%d nb=%d ranks=%d backend=%s info=%d: factor %.1f ms, forward sweeps %.1f ms, z/alpha %.1f ms, back-substitution %.1f ms, grad %.1f ms; total %.1f ms -> %.3f evals/s, %.1f TFLOP/s (N^3) per GPU, mll=%.6f"
+                  % (N, D, nb, world, dist.get_backend(), info, 1e3 * (t1 - t0), 1e3 * (t2 - t1), 1e3 * (t3 - t2), 1e3 * (t4 - t3), 1e3 * (t5 - t4), 1e3 * tot, 1 / tot,
+                     N ** 3 / tot / 1e12 / world, ws.out3[2].item()), flush=True)
     dist.destroy_process_group()
 
 if __name__ == "__main__":
