@@ -84,18 +84,33 @@ def _host_cpus():
     return (len(cores) or logical), logical, model
 
 
-def cpu_baseline(mode="single"):
+def _free_host_gb():
+    try:
+        import psutil
+        return psutil.virtual_memory().available / 2 ** 30
+    except Exception:
+        pass
+    try:
+        with open("/proc/meminfo") as fh:
+            for line in fh:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 2 ** 20
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline(mode="full"):
     """Oracle loss+grad (= optim/mll_torch.py:114-117 on the CPU oracle, plain PyTorch fp64 with the Cholesky forced) on
-    this box's host cores, on the C2 generator.
+    this box's host cores, on the C2 generator — BASELINE.md §3.
 
     Thread count: PyTorch's CPU ops oversubscribe badly at these sizes with every hardware thread (256 threads were 10x
-    slower than 32 on the 2 x 64-core host of round 1), so a ladder N = 2048, 4096, 8192 is timed with min(32, logical
-    CPUs) threads, the last size is re-timed with 4x as many, and the faster thread count is used for what follows.
-      mode "single" (default)  ONE timed evaluation at the full N = 20 000 (after the ladder as warm-up): a measurement,
-                               not an extrapolation, inside ~1.5 min of host time;
-      mode "full"              BASELINE.md §3's protocol: 1 warm-up + median of 3 evaluations at N = 20 000 (~5 min);
-      mode "ladder"            the bounded sample only, scaled by N^3 (for hosts with < 64 GB of free memory).
-    ``cores`` is the number of threads actually used; the host's physical / logical CPU counts are given beside it."""
+    slower than 32 on the 2 x 64-core host of round 1), so the count is CHOSEN by timing N = 8192 with 32, 64 and 128 threads
+    (capped at the host's physical cores) and the fastest is used for what follows.
+      mode "full" (default)    BASELINE.md §3's protocol: 1 warm-up + median of 3 evaluations at N = 20 000 (~4 min);
+      mode "single"            ONE timed evaluation at N = 20 000 after the thread sweep as warm-up (~1.5 min);
+      mode "ladder"            the bounded sample only, scaled by N^3 (forced when the host has < 64 GB of free memory).
+    ``threads`` is the number of threads used, ``cores`` the host's physical cores."""
     from oracle.gp_oracle import OracleGP
 
     phys, logical, model = _host_cpus()
@@ -112,33 +127,27 @@ def cpu_baseline(mode="single"):
         o.loss_and_grad()
         return time.perf_counter() - t0
 
-    th = min(32, logical)
-    one(512, th)  # thread pool, allocator
-    ladder = [(n, one(n, th)) for n in (2048, 4096, 8192)]
-    n_s, t_s = ladder[-1]
-    best_th = th
-    th2 = min(4 * th, logical)
-    if th2 > th:
-        t2 = one(n_s, th2)
-        if t2 < t_s:
-            t_s, best_th = t2, th2
-    try:
-        import psutil
-        free_gb = psutil.virtual_memory().available / 2 ** 30
-    except Exception:
-        free_gb = 0.0
+    cands = sorted({min(t, phys, logical) for t in (32, 64, 128)})
+    one(512, cands[0])  # thread pool, allocator
+    ladder = [(n, one(n, cands[0])) for n in (2048, 4096)]
+    n_s = 8192
+    sweep = {t: one(n_s, t) for t in cands}
+    best_th = min(sweep, key=sweep.get)
+    t_s = sweep[best_th]
+    ladder.append((n_s, t_s))
+    free_gb = _free_host_gb()
     if mode != "ladder" and free_gb < 64:
         mode = "ladder"  # autograd through the dense N = 20 000 Cholesky holds ~45 GB of N x N fp64 temporaries
-    base = {"unit": "evals/s", "cores": best_th, "threads": best_th, "host_physical_cores": phys,
+    base = {"unit": "evals/s", "cores": phys, "threads": best_th, "host_physical_cores": phys,
             "host_logical_cpus": logical, "host_cpu": model, "kind": "port",
-            "ladder_s": {str(a): round(b, 3) for a, b in ladder}, "ladder_threads": th}
+            "ladder_s": {str(a): round(b, 3) for a, b in ladder}, "ladder_threads": cands[0],
+            "thread_sweep_s_at_8192": {str(t): round(v, 3) for t, v in sweep.items()}}
     if mode == "ladder":
         est = t_s * (N_C2 / n_s) ** 3
         base.update(value=1.0 / est, measured_at_N=n_s, seconds_per_eval=est,
                     sample=f"oracle loss+grad timed at N={n_s} ({t_s:.2f} s, {best_th} threads) and scaled by "
                            f"(20000/{n_s})^3 = {est:.0f} s/eval (extrapolated: {free_gb:.0f} GB of host memory free)")
         return base
-    times = []
     if mode == "full":
         one(N_C2, best_th)  # warm-up at full size
         times = [one(N_C2, best_th) for _ in range(3)]
@@ -147,10 +156,10 @@ def cpu_baseline(mode="single"):
     else:
         sec = one(N_C2, best_th)
         times = [sec]
-        what = f"ONE evaluation at N={N_C2} after the ladder as warm-up"
-    base.update(value=1.0 / sec, measured_at_N=N_C2, seconds_per_eval=sec,
-                sample=f"oracle loss+grad, {what}: {sec:.1f} s/eval with {best_th} threads on {phys} physical cores "
-                       f"({logical} logical, {model}); same C2 generator and theta1 as the GPU leg")
+        what = f"ONE evaluation at N={N_C2} after the thread sweep as warm-up"
+    base.update(value=1.0 / sec, measured_at_N=N_C2, seconds_per_eval=sec, samples_s=[round(t, 2) for t in times],
+                sample=f"oracle loss+grad, {what}: {sec:.1f} s/eval with {best_th} threads (fastest of {cands} at N={n_s}) on "
+                       f"{phys} physical cores ({logical} logical, {model}); same C2 generator and theta1 as the GPU leg")
     return base
 
 
@@ -163,20 +172,77 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def count_gpus():
+    """GPUs of this node WITHOUT touching the HIP runtime (the launcher must stay a process that never initialised a GPU):
+    ``GPP_BENCH_NGPUS`` if set, else the KFD topology (nodes with SIMDs are GPUs, CPU nodes have none), narrowed by
+    ROCR_/HIP_VISIBLE_DEVICES.  None when the topology is not readable."""
+    if os.environ.get("GPP_BENCH_NGPUS"):
+        return int(os.environ["GPP_BENCH_NGPUS"])
+    root = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        nodes = os.listdir(root)
+    except OSError:
+        return None
+    n = 0
+    for d in nodes:
+        try:
+            with open(os.path.join(root, d, "properties")) as fh:
+                props = dict(line.split()[:2] for line in fh if len(line.split()) >= 2)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(args, argv):
-    """``--gpus N`` (N > 1) outside torch.distributed.run: start N fresh ranks as a child process tree (this process has
-    not initialised a GPU), relay their output and return the launcher's exit status."""
+    """``--gpus N`` (N > 1) outside torch.distributed.run: start N fresh ranks as a child process tree (this process never
+    touches the HIP runtime), relay their output line by line and return 0 iff rank 0's JSON line was relayed — whatever
+    became of the ranks afterwards (a hung second leg is ended by the ranks' own watchdogs, or here after ``--launch-timeout``)."""
     if not args.dry_run:
-        have = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
-        if have < args.gpus:
-            print(f"bench.py --gpus {args.gpus}: this node exposes {have} GPU(s)", file=sys.stderr)
+        have = count_gpus()
+        if have is None or have < args.gpus:
+            print(f"bench.py --gpus {args.gpus}: this node exposes {have or 0} GPU(s)"
+                  + ("" if have is not None else " (no KFD topology under /sys/class/kfd)"), file=sys.stderr)
             return 2
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
                MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
-    proc = subprocess.run(cmd, env=env)
-    return proc.returncode
+    import threading
+
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)
+    relayed = {"line": False}
+
+    def pump():
+        for line in proc.stdout:
+            sys.stdout.write(line)
+            sys.stdout.flush()
+            if line.startswith("{") and '"metric"' in line:
+                relayed["line"] = True
+
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    try:
+        proc.wait(timeout=args.launch_timeout)
+    except subprocess.TimeoutExpired:
+        print(f"bench.py: the ranks did not finish within {args.launch_timeout} s; ending them", file=sys.stderr)
+        try:
+            os.killpg(proc.pid, 15)  # the process group this launcher started (start_new_session), nothing else
+            proc.wait(timeout=20)
+        except Exception:
+            try:
+                os.killpg(proc.pid, 9)
+            except Exception:
+                pass
+    t.join(timeout=10)
+    if relayed["line"]:
+        return 0
+    return proc.returncode if proc.returncode not in (0, None) else 1
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -215,11 +281,22 @@ def _stage_table(events, N, share=1):
 
 
 def _pmc_record(name):
+    """HBM-side bytes of a stage from a committed rocprofv3 --pmc collection (it cannot run inside this process).  A record
+    names the kernel build it was collected with (``lib_signature`` = the source hash in gpp_version()); one collected with
+    another build is REFUSED — traffic is then reported as null with the reason, never silently stale."""
     p = os.path.join(ROOT, "profiles", name)
-    if os.path.exists(p):
-        with open(p) as fh:
-            return json.load(fh)
-    return None
+    if not os.path.exists(p):
+        return None
+    with open(p) as fh:
+        rec = json.load(fh)
+    from gpplus_amd import _lib
+
+    have = _lib.load().gpp_version().decode()
+    sig = rec.get("lib_signature")
+    if not sig or sig not in have:
+        return {"traffic_bytes_per_launch": None,
+                "note": f"profiles/{name} was collected with kernel build '{sig}', this library is '{have}': refused"}
+    return rec
 
 
 def run_replicas(args, dist, dev, rank, world, local_rank):
@@ -286,14 +363,15 @@ def run_replicas(args, dist, dev, rank, world, local_rank):
         eval_tf = N ** 3 / (elapsed / args.steps) / 1e12
         # HBM-side bytes come from committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside this
         # process); they only apply to the size they were collected at
-        pmc_l = _pmc_record("r02_lauum_pmc.json") if N == N_C2 else None
-        pmc_p = _pmc_record("r02_potrf_pmc.json") if N == N_C2 else None
+        pmc_l = _pmc_record("r03_lauum_pmc.json") if N == N_C2 else None
+        pmc_p = _pmc_record("r03_potrf_pmc.json") if N == N_C2 else None
+        pmc_t = _pmc_record("r03_trtri_pmc.json") if N == N_C2 else None
         third = N ** 3 / 3
         entries = []
         for name, kernel, pmc in (
                 ("potrf", "gpp_potrf_ws: look-ahead blocked Cholesky; ~500 launches of gpp_gemm_f64<2,64,64,0,16,2> (trailing "
                           "updates, row solves) + gpp_leaf_potrf_inv on CU-masked streams", pmc_p),
-                ("trtri", "gpp_trtri: batched pair merges, gpp_gemm_f64<2,64,64,0,16,2>", None),
+                ("trtri", "gpp_trtri: batched pair merges, gpp_gemm_f64<2,64,64,0,16,2>", pmc_t),
                 ("lauum", "gpp_gemm_f64<2, 64, 64, 1, 16, 2> (Kinv = Linv^T Linv, ONE lower-triangular TN launch)", pmc_l)):
             if name in stage_rate:
                 entries.append({"stage": name, "kernel": kernel, "achieved": stage_rate[name],
@@ -411,7 +489,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--n", type=int, default=None, help="problem size (default: 20000 = C2; 60000 = C5 for --mode sharded)")
-    ap.add_argument("--cpu-baseline", choices=["single", "full", "ladder", "none"], default="single")
+    ap.add_argument("--cpu-baseline", choices=["single", "full", "ladder", "none"], default="full",
+                    help="full (default): BASELINE.md section 3 - 1 warm-up + median of 3 evaluations at N=20000 (~4 min of host time)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=1,
                     help="independent replicas evaluated concurrently on this GPU (one host thread + HIP stream + "
@@ -424,6 +503,7 @@ def main():
     ap.add_argument("--sharded-steps", type=int, default=2)
     ap.add_argument("--sharded-warmup", type=int, default=1)
     ap.add_argument("--sharded-timeout", type=float, default=600.0, help="seconds before rank 0 gives up on the sharded leg")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launcher waits for its ranks")
     ap.add_argument("--dry-run", action="store_true", help="exercise the launch path only (gloo, no GPU work)")
     args = ap.parse_args()
 
@@ -462,16 +542,24 @@ def main():
             # the second leg must never cost the first its JSON line: a failure is reported inside the line (all ranks reach
             # the same branch: the sharded evaluation fails or succeeds collectively, and a hang is bounded by the
             # process-group timeout)
-            # ... and neither can a hang (the RCCL branch of the sharded evaluation has never run on real links): after
-            # ``--sharded-timeout`` seconds rank 0 prints the replica line with the failure recorded and leaves
+            # ... and neither can a hang: after ``--sharded-timeout`` seconds rank 0 prints the replica line with the failure
+            # recorded and every rank leaves (non-zero)
             watchdog = None
-            if rank == 0 and args.sharded_timeout > 0:
+            if args.sharded_timeout > 0:
                 import threading
 
                 def give_up():
-                    out["sharded"] = {"error": f"no result within {args.sharded_timeout} s (hang in the sharded leg)"}
-                    print(json.dumps(out), flush=True)
-                    os._exit(0)
+                    # EVERY rank runs this timer: rank 0 prints the replica line with the failure recorded, then each rank tries
+                    # to tear the process group down (bounded) and leaves with a NON-zero status — a hung collective must not
+                    # read as success, and no rank stays behind inside it.  The launcher (spawn_ranks) returns 0 iff the line
+                    # was relayed.
+                    if rank == 0:
+                        out["sharded"] = {"error": f"no result within {args.sharded_timeout} s (hang in the sharded leg)"}
+                        print(json.dumps(out), flush=True)
+                    closer = threading.Thread(target=lambda: dist.destroy_process_group(), daemon=True)
+                    closer.start()
+                    closer.join(timeout=10)
+                    os._exit(3)
 
                 watchdog = threading.Timer(args.sharded_timeout, give_up)
                 watchdog.daemon = True

@@ -507,7 +507,10 @@ int check_mat(const void* p, int64_t ld, int64_t n, int argi) {
 
 extern "C" {
 
-const char* gpp_version(void) { return "gpp_hip 0.1 (gfx950, fp64 MFMA)"; }
+#ifndef GPP_SRC_HASH
+#define GPP_SRC_HASH "unknown"
+#endif
+const char* gpp_version(void) { return "gpp_hip 0.3 (gfx950, fp64 MFMA) src " GPP_SRC_HASH; }
 
 int gpp_create(gpp_handle_t* out, int device) {
   if (!out) return -1;
