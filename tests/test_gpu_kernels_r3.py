@@ -1,0 +1,213 @@
+"""Round-3 kernel parity through the C ABI against numpy fp64:
+  * wide feature counts (D = 17, 33, 49, 64: the DT = 32 / 64 instantiations of gpp_grad_tiles, the > 48 KiB LDS opt-in of
+    gpp_cov_tile) for the RBF and both Matern kinds, with and without feature gradients;
+  * the column-sharded pieces of the back-substituted sharded evaluation: gpp_gemm_lower_cols, gpp_trmv_lower_cols,
+    gpp_mll_scalars, gpp_grad_reduce_cols;
+  * argument checks that guard the kernels' 16-byte accesses."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a):
+    return torch.as_tensor(np.ascontiguousarray(a), device="cuda")
+
+
+def _sq(n, fill=None):
+    from gpplus_amd.backend import square_buffer
+
+    m = square_buffer(n, "cuda")
+    m.fill_(float("nan") if fill is None else fill)
+    return m
+
+
+def _kernel_and_derivs(Ua, Ub, w, sf2, kind, d_split):
+    """K, dK/d(-r2_rbf), dK/d(-r2_mat) of sf2 * exp(-r2_rbf) * m(r2_mat) with r2 = sum_d w_d (ua_d - ub_d)^2 over the RBF dims
+    (d < d_split, or all of them for kind 0) and the Matern dims (kernels/matern.py:4-8: nu = 3/2, 5/2 with l_d = (2 w_d)^-1/2)."""
+    diff = Ua[:, None, :] - Ub[None, :, :]
+    dsp = Ua.shape[1] if kind == 0 else d_split
+    r2r = (diff[:, :, :dsp] ** 2 * w[:dsp]).sum(-1)
+    r2m = (diff[:, :, dsp:] ** 2 * w[dsp:]).sum(-1)
+    er = np.exp(-r2r)
+    if kind == 0:
+        m, dm = np.ones_like(r2m), np.zeros_like(r2m)
+    elif kind == 1:
+        a = np.sqrt(6.0 * r2m)
+        m, dm = (1 + a) * np.exp(-a), 3.0 * np.exp(-a)
+    else:
+        a = np.sqrt(10.0 * r2m)
+        m, dm = (1 + a + a * a / 3.0) * np.exp(-a), (5.0 / 3.0) * (1 + a) * np.exp(-a)
+    return sf2 * er * m, sf2 * er * m, sf2 * er * dm, diff, dsp
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("d,dU", [(17, 0), (17, 3), (33, 0), (33, 5), (49, 2), (64, 0), (64, 4)])
+def test_wide_feature_counts(gpu_ctx, d, dU, kind):
+    n, m, S = 200, 70, 2
+    rng = np.random.default_rng(100 * d + kind)
+    U = rng.standard_normal((n, d)) * 0.5
+    Ua = rng.standard_normal((m, d)) * 0.5
+    w = rng.uniform(0.02, 0.2, d)
+    sf2 = 0.83
+    d_split = 0 if kind == 0 else max(dU, 2)  # the manifold dims stay RBF (models/gp_plus.py:223-226), the others Matern
+    tau = np.array([2e-3, 3e-2])
+    grp = rng.integers(0, S, n).astype(np.int32)
+    K, _, _, _, _ = _kernel_and_derivs(U, U, w, sf2, kind, d_split)
+    ref = K + np.diag(tau[grp] + 1e-6)
+    dUm, dw = _dev(U), _dev(w)
+    dsf2 = torch.tensor([sf2], dtype=torch.float64, device="cuda")
+    for uplo, pick in ((0, lambda x: x), (2, np.triu)):
+        out = _sq(n, fill=-7.0)
+        gpu_ctx.kernel_build(dUm, dw, dsf2, _dev(tau), _dev(grp), out, jitter=1e-6, kind=kind, d_split=d_split, uplo=uplo)
+        np.testing.assert_allclose(pick(out.cpu().numpy()), pick(ref), rtol=1e-12, atol=1e-14)
+    cross = torch.empty(m, (n + 15) // 16 * 16, dtype=torch.float64, device="cuda")[:, :n]
+    gpu_ctx.cross_kernel(_dev(Ua), dUm, dw, dsf2, cross, kind=kind, d_split=d_split)
+    Kc, _, _, _, _ = _kernel_and_derivs(Ua, U, w, sf2, kind, d_split)
+    np.testing.assert_allclose(cross.cpu().numpy(), Kc, rtol=1e-12, atol=1e-14)
+
+    # gradient reduction against the written-out sums, with an arbitrary symmetric matrix in the place of Ky^-1
+    alpha = rng.standard_normal(n)
+    Kinv = rng.standard_normal((n, n))
+    Kinv = Kinv + Kinv.T
+    W = 0.5 * (np.outer(alpha, alpha) - Kinv)
+    K, Gr, Gm, diff, dsp = _kernel_and_derivs(U, U, w, sf2, kind, d_split)
+    g_w = np.array([(W * (Gr if k < dsp else Gm) * (-(diff[:, :, k] ** 2))).sum() for k in range(d)])
+    g_sf2 = (W * K).sum() / sf2
+    g_tau = np.array([np.diag(W)[grp == s].sum() for s in range(S)])
+    g_U = np.stack([2 * (W * (Gr if k < dsp else Gm) * (-2 * w[k]) * diff[:, :, k]).sum(1) for k in range(dU)], 1) if dU else None
+    Ki = _sq(n)
+    Ki.copy_(_dev(np.tril(Kinv) + np.triu(np.full((n, n), 1e30), 1)))  # the strict upper triangle must never be used
+    gw = torch.empty(d, dtype=torch.float64, device="cuda")
+    gs = torch.empty(1, dtype=torch.float64, device="cuda")
+    gt = torch.empty(S, dtype=torch.float64, device="cuda")
+    gU = torch.empty(n, dU, dtype=torch.float64, device="cuda") if dU else None
+    gpu_ctx.grad_reduce(dUm, dw, dsf2, _dev(grp), S, _dev(alpha), Ki, dU, gw, gs, gt, gU, kind=kind, d_split=d_split)
+    sc = lambda x: 1e-10 * np.abs(x).max() + 1e-13
+    np.testing.assert_allclose(gw.cpu().numpy(), g_w, rtol=1e-9, atol=sc(g_w))
+    np.testing.assert_allclose(gs.cpu().numpy()[0], g_sf2, rtol=1e-9, atol=sc(g_sf2))
+    np.testing.assert_allclose(gt.cpu().numpy(), g_tau, rtol=1e-9, atol=sc(g_tau))
+    if dU:
+        np.testing.assert_allclose(gU.cpu().numpy(), g_U, rtol=1e-9, atol=sc(g_U))
+
+
+def test_grad_reduce_rejects_views_its_vector_loads_cannot_take(gpu_ctx):
+    """gpp_grad_tiles reads Kinv with 16-byte loads: an odd leading dimension or a base that is not 16-byte aligned is a bad
+    argument (LAPACK-style negative status -> GppError), never a misaligned access."""
+    from gpplus_amd._lib import GppError
+
+    n, d = 130, 3
+    U = torch.randn(n, d, dtype=torch.float64, device="cuda")
+    w = torch.full((d,), 0.1, dtype=torch.float64, device="cuda")
+    sf2 = torch.tensor([1.0], dtype=torch.float64, device="cuda")
+    al = torch.zeros(n, dtype=torch.float64, device="cuda")
+    out = [torch.empty(d, dtype=torch.float64, device="cuda"), torch.empty(1, dtype=torch.float64, device="cuda"),
+           torch.empty(1, dtype=torch.float64, device="cuda")]
+    odd = torch.zeros(n, n + 1, dtype=torch.float64, device="cuda")  # ld = 131
+    with pytest.raises(GppError, match="bad argument"):
+        gpu_ctx.grad_reduce(U, w, sf2, None, 1, al, odd[:, :n], 0, *out, None)
+    shifted = torch.zeros(n, n + 14, dtype=torch.float64, device="cuda")[:, 1:n + 1]  # even ld, base 8 bytes off
+    with pytest.raises(GppError, match="bad argument"):
+        gpu_ctx.grad_reduce(U, w, sf2, None, 1, al, shifted, 0, *out, None)
+
+
+@pytest.mark.parametrize("nranks,nb,n", [(1, 128, 700), (2, 128, 700), (3, 256, 1500), (4, 128, 900)])
+def test_gemm_lower_cols_covers_the_owned_column_blocks_once(gpu_ctx, nranks, nb, n):
+    """C(lower) = beta C + alpha A^T B restricted to block-cyclic column blocks and to a band of rows: the ranks' shares (in
+    two row bands each) tile the lower triangle exactly once, nothing else is touched."""
+    K = 192
+    rng = np.random.default_rng(n + nranks)
+    A, B, C0 = rng.standard_normal((K, n)), rng.standard_normal((K, n)), rng.standard_normal((n, n))
+    ref = C0 - A.T @ B
+    dA = torch.zeros(K, (n + 15) // 16 * 16, dtype=torch.float64, device="cuda")[:, :n]
+    dB = torch.zeros(K, (n + 15) // 16 * 16, dtype=torch.float64, device="cuda")[:, :n]
+    dA.copy_(_dev(A))
+    dB.copy_(_dev(B))
+    first_block = 2  # the region's first column block is global block 2
+    split = (n // 2) // 128 * 128
+    hits = np.zeros((n, n), dtype=int)
+    for r in range(nranks):
+        C = _sq(n)
+        C.copy_(_dev(C0))
+        gpu_ctx.gemm_lower_cols(dA, dB, C, -1.0, 1.0, nb, first_block, r, nranks, split, n)  # lower band first (as the sweep does)
+        gpu_ctx.gemm_lower_cols(dA, dB, C, -1.0, 1.0, nb, first_block, r, nranks, 0, split)
+        got = C.cpu().numpy()
+        ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+        mine = (jj <= ii) & (((jj // nb) + first_block) % nranks == r)
+        np.testing.assert_allclose(got[mine], ref[mine], rtol=1e-12, atol=1e-12)
+        np.testing.assert_array_equal(got[~mine], C0[~mine])  # other ranks' column blocks and the upper triangle: untouched
+        hits += mine
+    ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    assert (hits[jj <= ii] == 1).all() and (hits[jj > ii] == 0).all()
+
+
+@pytest.mark.parametrize("nranks,nb,n", [(1, 128, 513), (2, 128, 1000), (3, 256, 1500)])
+def test_trmv_lower_cols_and_mll_scalars(gpu_ctx, nranks, nb, n):
+    """z = L^-1 r and alpha = L^-T z from column blocks: the ranks' partial results add up to the dense products, whatever sits
+    in the blocks a rank does not own (NaN here) or above the diagonal."""
+    rng = np.random.default_rng(n)
+    T = np.tril(rng.standard_normal((n, n)))
+    x = rng.standard_normal(n)
+    z_ref, a_ref = T @ x, T.T @ x
+    zs, as_ = np.zeros(n), np.zeros(n)
+    for r in range(nranks):
+        Tm = np.full((n, n), np.nan)
+        for c0 in range(0, n, nb):
+            if (c0 // nb) % nranks == r:
+                Tm[:, c0:c0 + nb] = T[:, c0:c0 + nb] + np.triu(np.full((n, n), 1e30), 1)[:, c0:c0 + nb]
+        dT = _sq(n)
+        dT.copy_(_dev(Tm))
+        y = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        gpu_ctx.trmv_lower_cols(dT, _dev(x), y, nb, r, nranks, trans=False)
+        zs += y.cpu().numpy()
+        y2 = torch.full((n,), float("nan"), dtype=torch.float64, device="cuda")
+        gpu_ctx.trmv_lower_cols(dT, _dev(x), y2, nb, r, nranks, trans=True)
+        got = y2.cpu().numpy()
+        own = ((np.arange(n) // nb) % nranks) == r
+        assert (got[~own] == 0).all()
+        as_ += got
+    np.testing.assert_allclose(zs, z_ref, rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(as_, a_ref, rtol=1e-11, atol=1e-11)
+    # scalars from a given z: quad = z'z, logdet = 2 sum log U_ii
+    Uf = _sq(n)
+    diag = rng.uniform(0.5, 2.0, n)
+    Uf.copy_(_dev(np.diag(diag) + np.triu(rng.standard_normal((n, n)), 1)))
+    out3 = torch.empty(3, dtype=torch.float64, device="cuda")
+    gpu_ctx.mll_scalars(Uf, _dev(z_ref), out3)
+    quad, logdet = z_ref @ z_ref, 2 * np.log(diag).sum()
+    np.testing.assert_allclose(out3.cpu().numpy(), [quad, logdet, -0.5 * (quad + logdet + n * np.log(2 * np.pi))], rtol=1e-12)
+
+
+@pytest.mark.parametrize("nranks,nb", [(2, 128), (3, 256)])
+def test_grad_reduce_cols_partial_sums_add_up(gpu_ctx, nranks, nb):
+    n, d, S, dU = 900, 6, 2, 2
+    rng = np.random.default_rng(9)
+    U = _dev(rng.standard_normal((n, d)))
+    w = _dev(rng.uniform(0.05, 0.6, d))
+    grp = _dev(rng.integers(0, S, n).astype(np.int32))
+    sf2 = torch.tensor([0.9], dtype=torch.float64, device="cuda")
+    al = _dev(rng.standard_normal(n))
+    Kf = rng.standard_normal((n, n))
+    Kf = np.tril(Kf + Kf.T)
+    Ki = _sq(n)
+    Ki.copy_(_dev(Kf))
+    mk = lambda: [torch.empty(d, dtype=torch.float64, device="cuda"), torch.empty(1, dtype=torch.float64, device="cuda"),
+                  torch.empty(S, dtype=torch.float64, device="cuda"), torch.empty(n, dU, dtype=torch.float64, device="cuda")]
+    ref = mk()
+    gpu_ctx.grad_reduce(U, w, sf2, grp, S, al, Ki, dU, *ref)
+    acc = [torch.zeros_like(t) for t in ref]
+    for r in range(nranks):
+        Km = np.full((n, n), np.nan)  # a rank holds its own column blocks only
+        for c0 in range(0, n, nb):
+            if (c0 // nb) % nranks == r:
+                Km[:, c0:c0 + nb] = Kf[:, c0:c0 + nb]
+        Kr = _sq(n)
+        Kr.copy_(_dev(Km))
+        part = mk()
+        gpu_ctx.grad_reduce_cols(U, w, sf2, grp, S, al, Kr, dU, nb, r, nranks, *part)
+        for a, p_ in zip(acc, part):
+            assert torch.isfinite(p_).all()
+            a += p_
+    for a, t in zip(acc, ref):
+        np.testing.assert_allclose(a.cpu().numpy(), t.cpu().numpy(), rtol=1e-10, atol=1e-10 * float(t.abs().max()))
