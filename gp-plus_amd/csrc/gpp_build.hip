@@ -20,13 +20,13 @@ constexpr int TB = 64;
 constexpr int DMAX = 64;
 
 __device__ __forceinline__ double kfun(double r2_rbf, double r2_mat, int kind) {
-  double v = exp(-r2_rbf);
+  double v = gpp_exp_nonpos(-r2_rbf);
   if (kind == 1) {  // Matern 3/2 in the scaled distance r = sqrt(2 * r2_mat)  (gpytorch MaternKernel nu=1.5)
     const double r = sqrt(3.0 * 2.0 * r2_mat);
-    v *= (1.0 + r) * exp(-r);
+    v *= (1.0 + r) * gpp_exp_nonpos(-r);
   } else if (kind == 2) {  // Matern 5/2
     const double r = sqrt(5.0 * 2.0 * r2_mat);
-    v *= (1.0 + r + r * r * (1.0 / 3.0)) * exp(-r);
+    v *= (1.0 + r + r * r * (1.0 / 3.0)) * gpp_exp_nonpos(-r);
   }
   return v;
 }

@@ -313,14 +313,14 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
           const int64_t j = j0 + 4 * tx + b;
           double g = 0.0, gm = 0.0;
           if (i < N && j <= i) {
-            const double er = exp(-r2[a][b]);
+            const double er = gpp_exp_nonpos(-r2[a][b]);
             double kv = er, kd = 0.0;
             if (MAT && kind == 1) {
-              const double aa = sqrt(6.0 * r2m[a][b]), ea = exp(-aa);
+              const double aa = sqrt(6.0 * r2m[a][b]), ea = gpp_exp_nonpos(-aa);
               kv = er * (1.0 + aa) * ea;
               kd = er * 3.0 * ea;
             } else if (MAT && kind == 2) {
-              const double aa = sqrt(10.0 * r2m[a][b]), ea = exp(-aa);
+              const double aa = sqrt(10.0 * r2m[a][b]), ea = gpp_exp_nonpos(-aa);
               kv = er * (1.0 + aa + aa * aa * (1.0 / 3.0)) * ea;
               kd = er * (5.0 / 3.0) * (1.0 + aa) * ea;
             }

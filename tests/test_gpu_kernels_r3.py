@@ -211,3 +211,18 @@ def test_grad_reduce_cols_partial_sums_add_up(gpu_ctx, nranks, nb):
             a += p_
     for a, t in zip(acc, ref):
         np.testing.assert_allclose(a.cpu().numpy(), t.cpu().numpy(), rtol=1e-10, atol=1e-10 * float(t.abs().max()))
+
+
+def test_exp_for_nonpositive_arguments_is_accurate_to_a_few_ulp(gpu_ctx):
+    """gpp_exp_nonpos (the branch-free exp of the covariance kernels) against numpy.exp over [-745, 0]: the parity bars of the
+    kernels built on it are 1e-12 and tighter."""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location(
+        "exp_check", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "exp_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rel, ulp, den = mod.max_rel_err(400_000)
+    assert ulp <= 4.0 and rel < 1e-15, (rel, ulp)
+    assert den < 1e-307
