@@ -20,6 +20,7 @@
 #include "gpp_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 typedef double v2d __attribute__((ext_vector_type(2)));
 typedef double v4d __attribute__((ext_vector_type(4)));
