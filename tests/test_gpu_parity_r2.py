@@ -449,5 +449,5 @@ def test_bench_line_contract(gpu_ctx):
     assert rf["bound"] == "mfma" and rf["peak"] == 78.6 and 0 < rf["frac"] < 1 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     stages = {e["stage"] for e in rf["entries"]}
     assert {"potrf", "trtri", "lauum"} <= stages
-    # the stage events cover the step (no work outside the timed stages): their sum is within 25 % of ms_per_step at this size
+    # the stage events lie inside the step: their sum cannot exceed ms_per_step (5 % allowance for event resolution at this size)
     assert sum(rec["stages"]["ms"].values()) <= 1.05 * rec["ms_per_step"]
