@@ -205,14 +205,16 @@ def spawn_ranks(args, argv):
     became of the ranks afterwards (a hung second leg is ended by the ranks' own watchdogs, or here after ``--launch-timeout``)."""
     if not args.dry_run:
         have = count_gpus()
-        if have is None or have < args.gpus:
+        if not args.share_gpu and (have is None or have < args.gpus):
             print(f"bench.py --gpus {args.gpus}: this node exposes {have or 0} GPU(s)"
                   + ("" if have is not None else " (no KFD topology under /sys/class/kfd)"), file=sys.stderr)
             return 2
+    # the ranks' own arguments travel in the environment: on the launcher's command line an option such as ``--n`` is an
+    # ambiguous abbreviation of torch.distributed.run's own options and is rejected before it reaches the script
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"),
-               MASTER_ADDR="127.0.0.1")
+               MASTER_ADDR="127.0.0.1", GPP_BENCH_ARGV=json.dumps(argv))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)]
     import threading
 
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1, start_new_session=True)
@@ -262,7 +264,7 @@ def _bracket(dist, dev, fn):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, out
@@ -465,6 +467,30 @@ def run_sharded(args, dist, dev, rank, world, n, steps, warmup):
     return out
 
 
+def start_watchdog(seconds, rank, line, dist):
+    """Timer on EVERY rank around the sharded leg: when it fires, rank 0 prints the replica line (``line``, a dict) with the
+    failure recorded, then each rank tries to tear the process group down (bounded) and leaves with a NON-zero status — a hung
+    collective must not read as success, and no rank stays behind inside it.  The launcher (spawn_ranks) returns 0 iff the
+    line was relayed.  Returns the timer (cancel it when the leg returns) or None."""
+    if seconds <= 0:
+        return None
+    import threading
+
+    def give_up():
+        if rank == 0:
+            line["sharded"] = {"error": f"no result within {seconds} s (hang in the sharded leg)"}
+            print(json.dumps(line), flush=True)
+        closer = threading.Thread(target=lambda: dist.destroy_process_group(), daemon=True)
+        closer.start()
+        closer.join(timeout=10)
+        os._exit(3)
+
+    t = threading.Timer(seconds, give_up)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def dry_run(args, rank, world):
     """Launch-path check without GPUs: gloo rendezvous, barrier, MAX all-reduce, one JSON line from rank 0."""
     import torch.distributed as dist
@@ -476,9 +502,17 @@ def dry_run(args, rank, world):
         t = torch.tensor([float(rank)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert int(t.item()) == world - 1
+    line = {"metric": "MLL evals/sec (fwd+grad), NxN exact GP, N=20k d=8", "value": None, "unit": "evals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True}
+    if args.fake_hang and world > 1:
+        # a second leg that never returns on the other ranks: the watchdog path of the real run, without GPUs
+        watchdog = start_watchdog(args.sharded_timeout, rank, line, dist)
+        if rank != 0:
+            time.sleep(10 ** 6)
+        dist.barrier()  # (never completes)
+        watchdog.cancel()
     if rank == 0:
-        print(json.dumps({"metric": "MLL evals/sec (fwd+grad), NxN exact GP, N=20k d=8", "value": None, "unit": "evals/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True}), flush=True)
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
@@ -505,7 +539,12 @@ def main():
     ap.add_argument("--sharded-timeout", type=float, default=600.0, help="seconds before rank 0 gives up on the sharded leg")
     ap.add_argument("--launch-timeout", type=float, default=1500.0, help="seconds the self-launcher waits for its ranks")
     ap.add_argument("--dry-run", action="store_true", help="exercise the launch path only (gloo, no GPU work)")
-    args = ap.parse_args()
+    ap.add_argument("--fake-hang", action="store_true", help="with --dry-run: the other ranks never return (tests the watchdog)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="TEST MODE: all ranks use cuda:0 and talk over gloo (exercises the N > 1 code path of both legs on a "
+                         "1-GPU box; not a measurement)")
+    forwarded = os.environ.get("GPP_BENCH_ARGV") if "WORLD_SIZE" in os.environ and len(sys.argv) == 1 else None
+    args = ap.parse_args(json.loads(forwarded)) if forwarded else ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args, sys.argv[1:]))
@@ -517,6 +556,8 @@ def main():
         return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the exact-GP path has no CPU fallback")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -524,7 +565,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     elif args.mode == "sharded":
         import torch.distributed as dist  # the sharded evaluation wants a process group even when it has one rank
@@ -544,26 +588,7 @@ def main():
             # process-group timeout)
             # ... and neither can a hang: after ``--sharded-timeout`` seconds rank 0 prints the replica line with the failure
             # recorded and every rank leaves (non-zero)
-            watchdog = None
-            if args.sharded_timeout > 0:
-                import threading
-
-                def give_up():
-                    # EVERY rank runs this timer: rank 0 prints the replica line with the failure recorded, then each rank tries
-                    # to tear the process group down (bounded) and leaves with a NON-zero status — a hung collective must not
-                    # read as success, and no rank stays behind inside it.  The launcher (spawn_ranks) returns 0 iff the line
-                    # was relayed.
-                    if rank == 0:
-                        out["sharded"] = {"error": f"no result within {args.sharded_timeout} s (hang in the sharded leg)"}
-                        print(json.dumps(out), flush=True)
-                    closer = threading.Thread(target=lambda: dist.destroy_process_group(), daemon=True)
-                    closer.start()
-                    closer.join(timeout=10)
-                    os._exit(3)
-
-                watchdog = threading.Timer(args.sharded_timeout, give_up)
-                watchdog.daemon = True
-                watchdog.start()
+            watchdog = start_watchdog(args.sharded_timeout, rank, out, dist)
             try:
                 sh = run_sharded(args, dist, dev, rank, world, args.sharded_n, args.sharded_steps, args.sharded_warmup)
             except Exception as exc:  # noqa: BLE001

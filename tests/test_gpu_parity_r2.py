@@ -451,3 +451,30 @@ def test_bench_line_contract(gpu_ctx):
     assert {"potrf", "trtri", "lauum"} <= stages
     # the stage events lie inside the step: their sum cannot exceed ms_per_step (5 % allowance for event resolution at this size)
     assert sum(rec["stages"]["ms"].values()) <= 1.05 * rec["ms_per_step"]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_through_both_legs_on_one_gpu():
+    """``bench.py --gpus 2 --share-gpu`` (test mode: both ranks on cuda:0 over gloo, small sizes): the N > 1 code path of the
+    benchmark — self-launch, the replica leg with its barrier / MAX timing, the sharded leg, ONE line carrying both — runs on
+    the 1-GPU box before a multi-GPU node ever sees it."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1",
+                        "--n", "4096", "--sharded-n", "3000", "--nb", "256", "--sharded-steps", "1", "--sharded-warmup", "1",
+                        "--sharded-timeout", "300"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["config"]["N"] == 4096
+    assert abs(rec["value"] - 2 * 1e3 / rec["ms_per_step"]) <= 1e-6 * rec["value"]  # whole-job rate: both replicas
+    sh = rec["sharded"]
+    assert "error" not in sh, sh
+    assert sh["n_gpus"] == 2 and sh["scaling"] == "strong" and sh["config"]["N"] == 3000 and sh["config"]["backend"] == "gloo"
+    assert {"shard_factor", "shard_inverse", "shard_backsolve"} <= set(sh["stages"]["ms"])
+    assert "cpu_baseline" not in rec  # rank 0 at N = 1 only

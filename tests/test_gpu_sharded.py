@@ -68,6 +68,18 @@ def test_sharded_rccl_branch_with_one_rank(N, D, nb, kind, S, dU):
 
 
 @pytest.mark.gpu
+def test_sharded_jitter_retries_and_failure_are_collective():
+    """A covariance that is indefinite at first (duplicated rows, slightly negative noise): every rank learns the failure from the
+    all-reduced status word, retries with the same jitter (gpytorch's schedule) and ends on the single-GPU path's values — or, when
+    no jitter suffices, EVERY rank raises NotPSDError instead of one of them hanging in a collective the others never enter."""
+    out = _run([1024, 5, 256, 0, 1, 0, "jitter"], world=2, port=29610)
+    for name, e in out["err"].items():
+        assert e < 1e-4, (name, e, out)  # (a matrix lifted by 5e-8: condition ~1e7, both paths round differently)
+    out = _run([1024, 5, 256, 0, 1, 0, "notpsd"], world=3, port=29611)
+    assert out["raised"] == {"sharded": "NotPSDError", "single": "NotPSDError"}, out
+
+
+@pytest.mark.gpu
 def test_sharded_through_gp_plus_api():
     """settings.sharded_evaluation routes GP_Plus's own loss through the cooperative evaluation (mixed-input model)."""
     out = _run([700, 8, 256, 0, 1, 2, "model"], port=29547)

@@ -208,3 +208,26 @@ def test_bench_self_launches_its_ranks_dry_run():
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "64"], capture_output=True, text=True,
                        timeout=300, env=env)
     assert p.returncode != 0 and "GPU" in p.stderr
+
+
+def test_bench_watchdog_ends_a_hung_second_leg_on_every_rank():
+    """``--dry-run --fake-hang``: rank 1 never returns from the (fake) sharded leg.  After ``--sharded-timeout`` seconds rank 0 prints
+    the line with the failure recorded, EVERY rank leaves with a non-zero status, and the self-launcher still returns 0 because
+    the line was relayed — within seconds, not after a process-group timeout."""
+    import json
+    import subprocess
+    import time
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--dry-run", "--fake-hang", "--sharded-timeout", "5"], capture_output=True, text=True, timeout=300, env=env)
+    took = time.time() - t0
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert len(lines) == 1, p.stdout
+    rec = json.loads(lines[0])
+    assert "hang" in rec["sharded"]["error"] and rec["n_gpus"] == 2
+    assert took < 120, took
+    assert "exitcode  : 3" in p.stderr or "exitcode: 3" in p.stderr or "(exitcode: 3)" in p.stderr, p.stderr[-1500:]

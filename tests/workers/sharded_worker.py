@@ -123,23 +123,44 @@ def main():
     U = torch.rand(N, D, generator=g, dtype=torch.float64)
     y = torch.sin(3.0 * U[:, 0]) + U[:, 1] ** 2 + 0.05 * torch.randn(N, generator=g, dtype=torch.float64)
     grp = (torch.arange(N) % S).to(torch.int32) if S > 1 else None
+    variant = sys.argv[7] if len(sys.argv) > 7 else ""
+    tau0 = 2e-3
+    if variant in ("jitter", "notpsd"):
+        # every other row duplicated and a slightly NEGATIVE noise: K + tau I is indefinite until the jitter schedule
+        # (1e-8, 1e-7, 1e-6) lifts it ("jitter": from 1e-7 on) or never ("notpsd"): every rank must retry / give up together
+        U[1::2] = U[0:2 * (N // 2):2]
+        tau0 = -5e-8 if variant == "jitter" else -1e-6
     res = {}
+    raised = {}
+    import warnings
+    warnings.simplefilter("ignore", RuntimeWarning)
     for mode in ("sharded", "single"):
         if mode == "single" and rank != 0:
             continue
         Ud = U.to(dev).requires_grad_(dU > 0)
         w = torch.full((D,), 2.5, dtype=torch.float64, device=dev).requires_grad_(True)
         sf2 = torch.tensor(0.8, dtype=torch.float64, device=dev).requires_grad_(True)
-        tau = torch.full((S,), 2e-3, dtype=torch.float64, device=dev)
+        tau = torch.full((S,), tau0, dtype=torch.float64, device=dev)
         tau = (tau * (1.0 + torch.arange(S, device=dev, dtype=torch.float64))).requires_grad_(True)
         mean = torch.full((N,), 0.1, dtype=torch.float64, device=dev).requires_grad_(True)
         spec = KernelSpec(w=w, sf2=sf2, kind=kind, d_split=2 if kind else 0)
         cfg = {"group": None, "nb": nb} if mode == "sharded" else None
-        with settings.sharded_evaluation(cfg):
-            mll = exact_mll(Ud, spec, tau, mean, y.to(dev), grp=None if grp is None else grp.to(dev), n_grad_dims=dU)
+        try:
+            with settings.sharded_evaluation(cfg):
+                mll = exact_mll(Ud, spec, tau, mean, y.to(dev), grp=None if grp is None else grp.to(dev), n_grad_dims=dU)
+        except Exception as exc:  # noqa: BLE001
+            raised[mode] = type(exc).__name__
+            continue
         mll.backward()
         res[mode] = [mll.detach().cpu().reshape(1), w.grad.cpu(), sf2.grad.cpu().reshape(1), tau.grad.cpu(),
                      mean.grad.cpu()] + ([Ud.grad.cpu()[:, :dU].reshape(-1)] if dU > 0 else [])
+    if variant == "notpsd":
+        if rank == 0:
+            emit("RESULT " + json.dumps({"raised": raised, "backend": dist.get_backend()}))
+        emit(f"RANK{rank} same_as_rank0={raised.get('sharded') == 'NotPSDError'}")
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # every rank must hold the same sharded result
     same = same_as_rank0(torch.cat([t.reshape(-1) for t in res["sharded"]]), dev)
     if rank == 0:
