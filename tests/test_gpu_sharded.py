@@ -86,30 +86,65 @@ def test_sharded_through_gp_plus_api():
     assert out["err"]["loss_and_grads"] < 1e-8, out
 
 
-@pytest.mark.gpu
-def test_sharded_c5_size_two_ranks():
-    """BASELINE config C5 at FULL size (N = 60 000, d = 16: 59 block rows of 1024) through GP_Plus, sharded over two ranks
-    (one GPU, gloo: 2 x 87 GB) against the single-GPU path run on its own beforehand (86 GB): loss and every gradient."""
+def _config_values(name, nb, world, n=None, nograd=False, port=29977, timeout=1500):
+    """Loss and gradients of a BASELINE config through GP_Plus: (single-GPU path, sharded over ``world`` ranks)."""
     import re
-    import torch
 
-    if torch.cuda.get_device_properties(0).total_memory < 200 * 2 ** 30:
-        pytest.skip("needs ~175 GiB of device memory")
     worker = os.path.join(ROOT, "tests", "workers", "sharded_worker.py")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    extra = ([str(n)] if n else []) + (["nograd"] if nograd else [])
+    if nograd and not n:
+        extra = ["0", "nograd"]
 
     def values(cmd):
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
         assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
         res = [json.JSONDecoder().raw_decode(p.stdout, m.end())[0] for m in re.finditer(r"RESULT (?=\{)", p.stdout)]
         assert len(res) == 1, p.stdout[-3000:]
+        same = re.findall(r"same_as_rank0=(True|False)", p.stdout)
+        assert all(v == "True" for v in same), same
         return res[0]["values"]
 
-    single = values([sys.executable, worker, "config", "C5", "single", "1024"])
-    shard = values([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                    "--master-port", "29977", worker, "config", "C5", "sharded", "1024"])
+    single = values([sys.executable, worker, "config", name, "single", str(nb)] + extra)
+    shard = values([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+                    "127.0.0.1", "--master-port", str(port), worker, "config", name, "sharded", str(nb)] + extra)
+    return single, shard
+
+
+def _assert_close_values(single, shard, tol):
     assert set(single) == set(shard)
     for k, ref in single.items():
         a, b = (shard[k], ref) if isinstance(ref, list) else ([shard[k]], [ref])
         scale = max(max(abs(v) for v in b), 1e-300)
-        assert max(abs(x - y) for x, y in zip(a, b)) <= 1e-8 * scale, (k, a, b)
+        assert max(abs(x - y) for x, y in zip(a, b)) <= tol * scale, (k, a, b)
+
+
+@pytest.mark.gpu
+def test_sharded_multifidelity_model_through_gp_plus():
+    """BASELINE config C4's model (three sources: per-source noise levels, per-source means, the source column manifold-encoded)
+    at N = 1500 on three ranks, block height 256: loss and every gradient — latent map, three noises, two means, lengthscales —
+    against the single-GPU path."""
+    single, shard = _config_values("C4", 256, 3, n=1500, port=29655)
+    assert any("raw_noise" in k for k in single) and any(k.startswith("latent") for k in single)
+    _assert_close_values(single, shard, 1e-8)
+
+
+@pytest.mark.gpu
+def test_sharded_evaluation_without_gradient():
+    """A gradient-free evaluation (``torch.no_grad()``: validation loss) skips the back-substitution and alpha; the value is the
+    same."""
+    single, shard = _config_values("C3", 256, 2, n=1200, nograd=True, port=29656)
+    assert list(single) == ["loss"]
+    _assert_close_values(single, shard, 1e-9)
+
+
+@pytest.mark.gpu
+def test_sharded_c5_size_two_ranks():
+    """BASELINE config C5 at FULL size (N = 60 000, d = 16: 59 block rows of 1024) through GP_Plus, sharded over two ranks
+    (one GPU, gloo: 2 x 87 GB) against the single-GPU path run on its own beforehand (86 GB): loss and every gradient."""
+    import torch
+
+    if torch.cuda.get_device_properties(0).total_memory < 200 * 2 ** 30:
+        pytest.skip("needs ~175 GiB of device memory")
+    single, shard = _config_values("C5", 1024, 2, port=29977)
+    _assert_close_values(single, shard, 1e-8)

@@ -77,9 +77,10 @@ def model_case(rank, world, dev, N, nb):
     dist.destroy_process_group()
 
 
-def config_case(name, sharded, nb):
-    """A BASELINE config at FULL size through GP_Plus (baseline_configs.make_config), sharded over the ranks or — one process,
-    no process group — on the single-GPU path; rank 0 prints loss and gradients."""
+def config_case(name, sharded, nb, n=None, nograd=False):
+    """A BASELINE config (FULL size unless ``n`` is given) through GP_Plus (baseline_configs.make_config), sharded over the ranks
+    or — one process, no process group — on the single-GPU path; rank 0 prints loss and gradients (``nograd``: the loss of a
+    gradient-free evaluation, which skips the back-substitution)."""
     from gpplus_amd.models import GP_Plus
     from gpplus_amd.gpcore import ExactMarginalLogLikelihood
     from gpplus_amd.test_functions.baseline_configs import apply_theta, make_config
@@ -89,15 +90,19 @@ def config_case(name, sharded, nb):
     else:
         dev = torch.device("cuda", 0)
         torch.cuda.set_device(dev)
-    X, y, kw, theta = make_config(name)
+    X, y, kw, theta = make_config(name, n)
     torch.manual_seed(0)
     m = GP_Plus(X, y, dtype=torch.float64, device=str(dev), **kw)
     apply_theta(m, theta)
     m.train()
     mll = ExactMarginalLogLikelihood(m.likelihood, m)
     with settings.sharded_evaluation({"group": None, "nb": nb} if sharded else None):
-        loss = -mll(m(*m.train_inputs), m.train_targets)
-        loss.backward()
+        if nograd:
+            with torch.no_grad():
+                loss = -mll(m(*m.train_inputs), m.train_targets)
+        else:
+            loss = -mll(m(*m.train_inputs), m.train_targets)
+            loss.backward()
     if rank == 0:
         vals = {"loss": float(loss)}
         for n, p in m.named_parameters():
@@ -113,7 +118,8 @@ def config_case(name, sharded, nb):
 
 def main():
     if len(sys.argv) > 2 and sys.argv[1] == "config":
-        return config_case(sys.argv[2], sys.argv[3] == "sharded", int(sys.argv[4]))
+        return config_case(sys.argv[2], sys.argv[3] == "sharded", int(sys.argv[4]), (int(sys.argv[5]) or None) if len(sys.argv) > 5 else None,
+                           len(sys.argv) > 6 and sys.argv[6] == "nograd")
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = pick_device_and_backend()
     N, D, nb, kind, S, dU = (int(a) for a in sys.argv[1:7])
