@@ -148,3 +148,17 @@ def test_sharded_c5_size_two_ranks():
         pytest.skip("needs ~175 GiB of device memory")
     single, shard = _config_values("C5", 1024, 2, port=29977)
     _assert_close_values(single, shard, 1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("backend,force", [("gloo", "0"), ("nccl", "1")])
+def test_sharded_choreography_is_bitwise_repeatable(backend, force):
+    """The sharded evaluation enqueues on five streams (panel, throughput, bulk, collectives, the caller's) tied by events; every
+    kernel is deterministic, so repeating one evaluation must reproduce loss and gradients BIT FOR BIT — any difference is a race
+    (tools/stress_sharded.py; 17 block rows, per-group noise, manifold gradients, 20 repetitions)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPP_SHARDED_FORCE_COLLECTIVES=force,
+               MASTER_PORT=str(29720 + (backend == "nccl")))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_sharded.py"), "4300", "256", "20", backend],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "20 repetitions, 0 differ" in p.stdout, p.stdout[-1000:]
