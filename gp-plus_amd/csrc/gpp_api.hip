@@ -276,7 +276,20 @@ hipError_t ensure_streams(gpp_handle_s* h) {
     }
   }
   if (!h->full_stream) {
-    hipError_t e = hipStreamCreateWithFlags(&h->full_stream, hipStreamNonBlocking);
+    // LOWEST priority for the stream without a CU mask: the bulk of a trailing update overlaps the start of the panel after next,
+    // and its work-groups also run on the panel's CUs; with equal priorities the panel's small launches queued for slots behind
+    // the bulk's thousands of tiles (traced: a 28-work-group panel solve took 1.57 ms).  Measured A/B, twice each: potrf 52.26 /
+    // 52.07 -> 51.73 / 51.48 ms at N = 20000; no change at 30000.  GPP_FULL_PRIO=0 restores the default priority.
+    static const int prio = getenv("GPP_FULL_PRIO") ? atoi(getenv("GPP_FULL_PRIO")) : 1;  // experiment knob
+    hipError_t e;
+    if (prio) {
+      int lo = 0, hi = 0;
+      e = hipDeviceGetStreamPriorityRange(&lo, &hi);
+      if (e != hipSuccess) return e;
+      e = hipStreamCreateWithPriority(&h->full_stream, hipStreamNonBlocking, lo);
+    } else {
+      e = hipStreamCreateWithFlags(&h->full_stream, hipStreamNonBlocking);
+    }
     if (e != hipSuccess) return e;
   }
   while (h->n_events < 16) {
