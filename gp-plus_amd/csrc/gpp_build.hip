@@ -14,6 +14,8 @@
 // stores 4 consecutive doubles per row: 16 lanes x 32 B = 512 B contiguous per row segment.
 #include "gpp_internal.h"
 
+#include <atomic>
+
 namespace {
 
 constexpr int TB = 64;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void gpp_cov_tile(const double* __restrict__ U
 // more than 48 KiB of dynamic LDS (D > 48 features) needs the opt-in, once per device
 static hipError_t cov_lds_optin(int D) {
   if ((size_t)2 * D * TB * sizeof(double) <= 48 * 1024) return hipSuccess;
-  static bool done[64] = {false};
+  static std::atomic<bool> done[64];  // (per device; handles of different host threads may get here together)
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return e;

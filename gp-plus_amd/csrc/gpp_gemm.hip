@@ -20,6 +20,7 @@
 #include "gpp_internal.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -458,7 +459,7 @@ hipError_t launch_inst(hipStream_t s, dim3 grid, const GemmArgs& a) {
   constexpr size_t bytes = gemm_lds_bytes(VAR, 2 * WTM, 2 * WTN, BK, NBUF);
   auto* fn = gpp_gemm_f64<VAR, WTM, WTN, TAG, BK, NBUF>;
   if (bytes > 48 * 1024) {
-    static bool attr_set[64] = {false};  // per instantiation and device (function attributes are per device)
+    static std::atomic<bool> attr_set[64];  // per instantiation and device (function attributes are per device)
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;

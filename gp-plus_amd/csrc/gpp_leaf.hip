@@ -21,6 +21,7 @@
 // Then the 8 diagonal tiles are inverted in parallel (2 per wave, lane per column) and the inverse is assembled by
 // pair merging at tile level (sizes 16, 32, 64): X21 = -X22 (L21 X11), MFMA again.
 #include "gpp_internal.h"
+#include <atomic>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -419,7 +420,7 @@ hipError_t gpp_launch_leaf(hipStream_t s, double* A, int64_t lda, double* Linv, 
                            int row_offset, int batch, int64_t sA, int64_t sLi) {
   if (n <= 0 || batch <= 0) return hipSuccess;
   if (n > NB) return hipErrorInvalidValue;
-  static bool attr_set[64] = {false};  // per device (function attributes are per device)
+  static std::atomic<bool> attr_set[64];  // per device (function attributes are per device)
   const size_t shmem = (size_t)NT * TSZ * sizeof(double);
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
