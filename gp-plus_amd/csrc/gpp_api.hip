@@ -276,11 +276,13 @@ hipError_t ensure_streams(gpp_handle_s* h) {
     }
   }
   if (!h->full_stream) {
-    // LOWEST priority for the stream without a CU mask: the bulk of a trailing update overlaps the start of the panel after next,
-    // and its work-groups also run on the panel's CUs; with equal priorities the panel's small launches queued for slots behind
-    // the bulk's thousands of tiles (traced: a 28-work-group panel solve took 1.57 ms).  Measured A/B, twice each: potrf 52.26 /
-    // 52.07 -> 51.73 / 51.48 ms at N = 20000; no change at 30000.  GPP_FULL_PRIO=0 restores the default priority.
-    static const int prio = getenv("GPP_FULL_PRIO") ? atoi(getenv("GPP_FULL_PRIO")) : 1;  // experiment knob
+    // Experiment knob GPP_FULL_PRIO=1: LOWEST priority for the stream without a CU mask.  The bulk of a trailing update overlaps
+    // the start of the panel after next, and its work-groups also run on the panel's CUs; with equal priorities the panel's small
+    // launches queue for slots behind the bulk's thousands of tiles (traced: a 28-work-group panel solve took 1.57 ms).  Measured
+    // A/B, twice each: potrf 52.26 / 52.07 -> 51.73 / 51.48 ms at N = 20000; no change at 30000.  NOT the default: with the
+    // priority stream `rocprofv3 --kernel-trace --stats -- python3 bench.py` never returned on this stack (ROCm 7.2.0; the plain
+    // run is fine) — a 0.4 % gain is not worth a benchmark that cannot be profiled.
+    static const int prio = getenv("GPP_FULL_PRIO") ? atoi(getenv("GPP_FULL_PRIO")) : 0;
     hipError_t e;
     if (prio) {
       int lo = 0, hi = 0;

@@ -8,7 +8,8 @@ df['dur'] = (df.End_Timestamp - df.Start_Timestamp) / 1e3
 df = df.sort_values('Start_Timestamp').reset_index(drop=True)
 cov = df.index[df.Kernel_Name.str.contains('gpp_cov_tile')]
 start = cov[-1]
-end = df.index[(df.index > start) & df.Kernel_Name.str.contains('gpp_trmv_lower')][0]
+_after = df.index[(df.index > start) & df.Kernel_Name.str.contains('gpp_trmv_lower')]
+end = _after[0] if len(_after) else len(df)  # (a factorisation-only trace, STAGES_ONLY=build,potrf, has no later stage)
 ev = df.iloc[start + 1:end]
 lastleaf = ev.index[ev.Kernel_Name.str.contains('leaf')][-1]
 pot = df.iloc[start + 1:lastleaf + 1].copy()
