@@ -34,25 +34,41 @@ struct gpp_handle_s {
 // positive / huge arguments, constants re-materialised per call) of the general-purpose library exp, which made the N^2
 // kernels VALU-bound instead of HBM-bound.  Max error 2 ulp on [-745, 0] (tools/exp_check.py); NaN propagates; x < -800 -> 0.
 #ifdef __HIPCC__
-__device__ __forceinline__ double gpp_exp_nonpos(double x) {
+// The constants live in SGPRs for the whole kernel (wave-uniform; one constant-bus operand per v_fma_f64): left to itself the
+// compiler re-materialises each coefficient in a VGPR pair per use (two v_mov_b32 in front of every v_fmac_f64, ~26 per call —
+// as many issue slots as the arithmetic).  The empty asm makes them opaque, i.e. not re-materialisable.
+struct GppExpConsts {
+  double log2e, ln2_hi, ln2_lo, c[11];
+};
+__device__ __forceinline__ GppExpConsts gpp_exp_consts() {
+  GppExpConsts k = {1.44269504088896338700e+00, 6.93147180369123816490e-01, 1.90821492927058770002e-10,
+                    {2.08767569878680989792e-09,    // 1/12!
+                     2.50521083854417187751e-08,    // 1/11!
+                     2.75573192239858906526e-07,    // 1/10!
+                     2.75573192239858906526e-06,    // 1/9!
+                     2.48015873015873015873e-05,    // 1/8!
+                     1.98412698412698412698e-04,    // 1/7!
+                     1.38888888888888888889e-03,    // 1/6!
+                     8.33333333333333333333e-03,    // 1/5!
+                     4.16666666666666666667e-02,    // 1/4!
+                     1.66666666666666666667e-01,    // 1/3!
+                     0.5}};
+  asm volatile("" : "+s"(k.log2e), "+s"(k.ln2_hi), "+s"(k.ln2_lo));
+#pragma unroll
+  for (int i = 0; i < 10; ++i) asm volatile("" : "+s"(k.c[i]));
+  return k;
+}
+__device__ __forceinline__ double gpp_exp_nonpos(double x, const GppExpConsts& k) {
   x = (x < -800.0) ? -800.0 : x;  // (a select, not a max: NaN stays NaN)
-  const double k = __builtin_rint(x * 1.44269504088896338700e+00);
-  double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
-  r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
-  double p = 2.08767569878680989792e-09;                 // 1/12!
-  p = __builtin_fma(p, r, 2.50521083854417187751e-08);   // 1/11!
-  p = __builtin_fma(p, r, 2.75573192239858906526e-07);   // 1/10!
-  p = __builtin_fma(p, r, 2.75573192239858906526e-06);   // 1/9!
-  p = __builtin_fma(p, r, 2.48015873015873015873e-05);   // 1/8!
-  p = __builtin_fma(p, r, 1.98412698412698412698e-04);   // 1/7!
-  p = __builtin_fma(p, r, 1.38888888888888888889e-03);   // 1/6!
-  p = __builtin_fma(p, r, 8.33333333333333333333e-03);   // 1/5!
-  p = __builtin_fma(p, r, 4.16666666666666666667e-02);   // 1/4!
-  p = __builtin_fma(p, r, 1.66666666666666666667e-01);   // 1/3!
-  p = __builtin_fma(p, r, 0.5);
+  const double n = __builtin_rint(x * k.log2e);
+  double r = __builtin_fma(-n, k.ln2_hi, x);
+  r = __builtin_fma(-n, k.ln2_lo, r);
+  double p = k.c[0];
+#pragma unroll
+  for (int i = 1; i < 11; ++i) p = __builtin_fma(p, r, k.c[i]);
   p = __builtin_fma(p, r, 1.0);
   p = __builtin_fma(p, r, 1.0);
-  return __builtin_ldexp(p, (int)k);
+  return __builtin_ldexp(p, (int)n);
 }
 #endif
 

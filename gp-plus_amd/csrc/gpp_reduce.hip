@@ -228,6 +228,7 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
   const int tid = threadIdx.x;
   const int ty = tid >> 4, tx = tid & 15;
   const double sf2 = *sf2p;
+  const GppExpConsts ec = gpp_exp_consts();
   if (tid < DT) sw[tid] = (tid < D) ? w[tid] : 0.0;
 
   double my_sf2 = 0.0;
@@ -313,14 +314,14 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
           const int64_t j = j0 + 4 * tx + b;
           double g = 0.0, gm = 0.0;
           if (i < N && j <= i) {
-            const double er = gpp_exp_nonpos(-r2[a][b]);
+            const double er = gpp_exp_nonpos(-r2[a][b], ec);
             double kv = er, kd = 0.0;
             if (MAT && kind == 1) {
-              const double aa = sqrt(6.0 * r2m[a][b]), ea = gpp_exp_nonpos(-aa);
+              const double aa = sqrt(6.0 * r2m[a][b]), ea = gpp_exp_nonpos(-aa, ec);
               kv = er * (1.0 + aa) * ea;
               kd = er * 3.0 * ea;
             } else if (MAT && kind == 2) {
-              const double aa = sqrt(10.0 * r2m[a][b]), ea = gpp_exp_nonpos(-aa);
+              const double aa = sqrt(10.0 * r2m[a][b]), ea = gpp_exp_nonpos(-aa, ec);
               kv = er * (1.0 + aa + aa * aa * (1.0 / 3.0)) * ea;
               kd = er * (5.0 / 3.0) * (1.0 + aa) * ea;
             }
