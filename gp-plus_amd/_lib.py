@@ -57,6 +57,8 @@ _SIGNATURES = {
                                      c_void_p]),
     "gpp_predict": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
                             c_void_p, c_int64, c_void_p, c_void_p]),
+    "gpp_predict_tn": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int64, c_void_p,
+                               c_void_p, c_int64, c_void_p, c_void_p]),
     "gpp_gemm": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, c_void_p,
                          c_int64, c_double, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int]),
     "gpp_gemm_batched": (c_int, [c_void_p, c_int, c_int, c_int64, c_int64, c_int64, c_double, c_void_p, c_int64, c_int64,

@@ -307,6 +307,14 @@ class GppContext:
                                    mean_out.data_ptr(), _ptr(var_out)), "gpp_predict")
 
     @_on_own_device
+    def predict_tn(self, Linv, z, Kns, kss, V, mean_out, var_out):
+        """Prediction from the transposed cross block Kns (N x M) and z = Linv r: mean, variance and V = Kns^T Linv^T."""
+        self._stream()
+        check(self.lib.gpp_predict_tn(self.h, Linv.data_ptr(), _ld(Linv), Linv.shape[0], z.data_ptr(), Kns.data_ptr(), _ld(Kns),
+                                      Kns.shape[1], kss.data_ptr(), V.data_ptr(), _ld(V), mean_out.data_ptr(), var_out.data_ptr()),
+              "gpp_predict_tn")
+
+    @_on_own_device
     def gemm(self, transA, transB, M, N, K, alpha, A, B, beta, C, *, a_mask=0, b_mask=0, klo_mode=0, khi_mode=0,
              c_tri=0):
         self._stream()

@@ -946,6 +946,29 @@ int gpp_predict(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, cons
   return 0;
 }
 
+int gpp_predict_tn(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, const double* z, const double* Kns, int64_t ldk,
+                   int64_t M, const double* kss, double* V, int64_t ldv, double* mean_out, double* var_out) {
+  if (!h) return -1;
+  if (N < 0) return -4;
+  if (int q = check_mat(Linv, ldi, N, 2)) return q;
+  if (!z || !aligned16(z)) return -5;
+  if (!Kns || !aligned16(Kns) || (ldk & 1) || ldk < M) return -6;
+  if (M < 0) return -8;
+  if (!kss) return -9;
+  if (!V || !aligned16(V) || (ldv & 1) || ldv < N) return -10;
+  if (!mean_out) return -12;
+  if (!var_out) return -13;
+  // V = Kns^T W with W = L^-T, the mirror in the upper triangle of the Linv buffer (keep k <= n): the row-contiguous TN product
+  // of every other O(N^3) stage, where the [test][train] layout of gpp_predict needs the k-contiguous NT variant (1 work-group
+  // per CU, no lean staging: 34 TFLOP/s on M N^2 against ~60 here)
+  GemmArgs g = mk(Kns, ldk, Linv, ldi, V, ldv, M, N, N, 1.0, 0.0);
+  g.b_mask = 1; g.khi_mode = 2;
+  GPP_TRY(gpp_launch_gemm(h->stream, 2, g, 1));
+  // mean_a = sum_j V[a][j] z_j (= K_*N alpha, alpha = L^-T z), var_a = kss_a - sum_j V[a][j]^2: one pass over V
+  GPP_TRY(gpp_launch_predict_reduce(h->stream, V, ldv, V, ldv, M, N, z, kss, mean_out, var_out));
+  return 0;
+}
+
 int gpp_gemm(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64_t K, double alpha, const double* A,
              int64_t lda, const double* B, int64_t ldb, double beta, double* C, int64_t ldc, int a_mask, int b_mask,
              int klo_mode, int khi_mode, int c_tri) {

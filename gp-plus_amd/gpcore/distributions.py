@@ -18,21 +18,29 @@ from .kernels import DiagNoise, LazyKernelMatrix
 class DenseCovariance:
     """Dense (M x M) covariance produced lazily by a builder, with a cheap diagonal; used for predictive MVNs."""
 
-    def __init__(self, diag: torch.Tensor, builder=None, added_diag: Optional[torch.Tensor] = None):
+    def __init__(self, diag, builder=None, added_diag: Optional[torch.Tensor] = None, n: Optional[int] = None):
+        # ``diag``: the diagonal, or a callable producing it on first use (a prediction asked for its mean only never pays the
+        # O(M N^2) product behind the variance); ``n``: the size, needed while the diagonal does not exist yet
         self._diag, self._builder, self._added = diag, builder, added_diag
+        self._n = n if n is not None else diag.shape[0]
         self._dense = None
 
     @property
     def shape(self):
-        n = self._diag.shape[0]
-        return torch.Size([n, n])
+        return torch.Size([self._n, self._n])
+
+    def _diagonal(self) -> torch.Tensor:
+        if callable(self._diag):
+            self._diag = self._diag()
+        return self._diag
 
     def diag(self):
-        return self._diag if self._added is None else self._diag + self._added
+        d = self._diagonal()
+        return d if self._added is None else d + self._added
 
     def add_diag_vector(self, v: torch.Tensor) -> "DenseCovariance":
         added = v if self._added is None else self._added + v
-        out = DenseCovariance(self._diag, self._builder, added)
+        out = DenseCovariance(self._diagonal(), self._builder, added, n=self._n)
         out._dense = self._dense
         return out
 

@@ -82,16 +82,27 @@ class ExactGP(GP):
             test_out = Module.__call__(self, *inputs, **kwargs)
             tcov = test_out.lazy_covariance_matrix
             Us = tcov.U1.to(torch.float64).contiguous()
-            mean_c, var, V = predict_from_cache(cache, Us, need_var=True, need_V=True)
+            # the mean is O(M N) and computed now; the variance needs V = K_*N L^-T (M N^2 flops) and is computed when — if —
+            # somebody asks for it (predict(return_std=False), the acquisition means of a BO loop and Sobol's p + 2 batches do not)
+            mean_c, _, _ = predict_from_cache(cache, Us, need_var=False)
             pred_mean = test_out.mean.to(torch.float64) + mean_c
+            lazy = {}
 
-            def full_cov(Us=Us, V=V, spec=cache.spec, gctx=cache.gctx):
-                from ..backend import square_buffer
+            def var_and_v(cache=cache, Us=Us):
+                if "V" not in lazy:
+                    if cache.stale():
+                        raise RuntimeError("the prediction workspace was reused by another model before the variance of this "
+                                           "prediction was evaluated; read .variance / .stddev right after the call")
+                    with torch.no_grad():
+                        _, lazy["var"], lazy["V"] = predict_from_cache(cache, Us, need_var=True, need_V=True)
+                return lazy["var"], lazy["V"]
 
+            def full_cov(Us=Us, spec=cache.spec, gctx=cache.gctx):
                 M = Us.shape[0]
+                V = var_and_v()[1]
                 Kss = LazyKernelMatrix(Us, None, spec).evaluate()
                 # Kss - V V^T through the MFMA GEMM (NT, lower + mirrored by symmetry)
                 gctx.gemm(0, 1, M, M, V.shape[1], -1.0, V, V, 1.0, Kss)
                 return Kss
 
-            return MultivariateNormal(pred_mean, DenseCovariance(var, full_cov))
+            return MultivariateNormal(pred_mean, DenseCovariance(lambda: var_and_v()[0], full_cov, n=Us.shape[0]))

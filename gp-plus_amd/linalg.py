@@ -297,8 +297,9 @@ class FactorCache:
     """Cholesky factor, its inverse and alpha = Ky^-1 (y - m) of the training covariance: the analogue of gpytorch's
     prediction strategy caches (mean_cache / covar_cache) used by models/gpregression.py:122-149."""
 
-    def __init__(self, gctx, L, Linv, alpha, U, spec, jitter, ws=None):
+    def __init__(self, gctx, L, Linv, alpha, U, spec, jitter, ws=None, z=None):
         self.gctx, self.L, self.Linv, self.alpha, self.U, self.spec, self.jitter = gctx, L, Linv, alpha, U, spec, jitter
+        self.z = z  # Linv (y - m): the mean of a prediction that also wants the variance is V z
         # L and Linv live in the shared prediction workspace: another model's factorisation of the same size overwrites
         # them.  ``stale()`` tells the owner to factor again instead of predicting from someone else's matrices.
         self._ws, self._epoch = ws, (ws.epoch if ws is not None else 0)
@@ -329,26 +330,29 @@ def _factorize(U, spec: KernelSpec, tau, grp, mean, y) -> FactorCache:
     torch.sub(_as_f64(y, dev), _as_f64(mean, dev), out=ws.r)
     gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
     gctx.alpha(ws.Li, ws.z, ws.alpha)
-    return FactorCache(gctx, ws.A, ws.Li, ws.alpha.clone(), Ud, KernelSpec(wd, sd.reshape(()), spec.kind, spec.d_split), jit, ws)
+    return FactorCache(gctx, ws.A, ws.Li, ws.alpha.clone(), Ud, KernelSpec(wd, sd.reshape(()), spec.kind, spec.d_split), jit, ws,
+                       z=ws.z.clone())
 
 
 @torch.no_grad()
 def predict_from_cache(cache: FactorCache, Us: torch.Tensor, need_var: bool = True, need_V: bool = False):
-    """K8: mean contribution K_*N alpha and prior-minus-explained variance; optionally V = K_*N Linv^T."""
+    """K8: mean contribution K_*N alpha and prior-minus-explained variance; optionally V = K_*N Linv^T.
+    Mean only: the [test][train] cross block and one row reduction, O(M N).  With the variance: the TRANSPOSED cross block, so that
+    V = Kns^T Linv^T is the row-contiguous TN product (gpp_predict_tn), and both outputs come from one pass over V."""
     dev = Us.device
     gctx = cache.gctx
-    Ksn = cross_kernel(Us, cache.U, cache.spec)
-    M, N = Ksn.shape
+    M, N = Us.shape[0], cache.U.shape[0]
     mean = torch.empty(M, dtype=torch.float64, device=dev)
-    var = torch.empty(M, dtype=torch.float64, device=dev) if need_var else None
-    V = None
-    kss = None
-    if need_var or need_V:
-        V = torch.empty((M, Ksn.stride(0)), dtype=torch.float64, device=dev)[:, :N]
-        kss = cache.spec.sf2.reshape(1).expand(M).contiguous()
-        if var is None:
-            var = torch.empty(M, dtype=torch.float64, device=dev)
-    gctx.predict(cache.Linv, cache.alpha, Ksn, kss, V, mean, var)
+    if not (need_var or need_V):
+        Ksn = cross_kernel(Us, cache.U, cache.spec)
+        gctx.predict(cache.Linv, cache.alpha, Ksn, None, None, mean, None)
+        return mean, None, None
+    Kns = cross_kernel(cache.U, Us, cache.spec)  # N x M
+    ldv = max(16, (N + 15) // 16 * 16)
+    V = torch.empty((M, ldv), dtype=torch.float64, device=dev)[:, :N]
+    kss = cache.spec.sf2.reshape(1).expand(M).contiguous()
+    var = torch.empty(M, dtype=torch.float64, device=dev)
+    gctx.predict_tn(cache.Linv, cache.z, Kns, kss, V, mean, var)
     return mean, var, V
 
 

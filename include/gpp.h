@@ -197,6 +197,13 @@ int gpp_grad_reduce_cols(gpp_handle_t h, const double* U, int64_t N, int D, cons
 int gpp_predict(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, const double* alpha, const double* Ksn,
                 int64_t lds, int64_t M, const double* kss, double* V, int64_t ldv, double* mean_out, double* var_out);
 
+/* The same prediction from the TRANSPOSED cross block Kns (N x M: gpp_cross_kernel with the training points as rows) and
+ * z = Linv r (gpp_mll_reduce):  V = Kns^T Linv^T as a row-contiguous TN product against the mirror in Linv's upper triangle,
+ * mean_out[a] = sum_j V[a,j] z[j],  var_out[a] = kss[a] - sum_j V[a,j]^2.  The form to use when the variance is wanted (the product
+ * is ~1.7x faster than gpp_predict's); for the mean alone gpp_predict with V = NULL is O(M N).  (models/gpregression.py:122-149) */
+int gpp_predict_tn(gpp_handle_t h, const double* Linv, int64_t ldi, int64_t N, const double* z, const double* Kns, int64_t ldk,
+                   int64_t M, const double* kss, double* V, int64_t ldv, double* mean_out, double* var_out);
+
 /*
  * The fp64 MFMA GEMM behind all of the above, exported for the parity tests:
  *   C = beta*C + alpha*op(A)*op(B),  op(A): M x K, op(B): K x N, all row-major.

@@ -226,3 +226,52 @@ def test_exp_for_nonpositive_arguments_is_accurate_to_a_few_ulp(gpu_ctx):
     rel, ulp, den = mod.max_rel_err(400_000)
     assert ulp <= 4.0 and rel < 1e-15, (rel, ulp)
     assert den < 1e-307
+
+
+@pytest.mark.parametrize("n,m", [(600, 130), (1000, 1), (257, 700)])
+def test_predict_tn_matches_scipy_and_the_nt_form(gpu_ctx, n, m):
+    """gpp_predict_tn (transposed cross block, V = Kns^T L^-T as a TN product against the mirror, mean = V z) against scipy and
+    against gpp_predict on the same factor; the mean-only form of gpp_predict (V = NULL) as well."""
+    import scipy.linalg as sla
+
+    d = 7
+    rng = np.random.default_rng(n + m)
+    U = rng.standard_normal((n, d))
+    w = rng.uniform(0.05, 0.5, d)
+    K = 0.8 * np.exp(-((U[:, None, :] - U[None, :, :]) ** 2 * w).sum(-1)) + 1e-3 * np.eye(n)
+    Us = rng.standard_normal((m, d))
+    r = rng.standard_normal(n)
+    Ks = 0.8 * np.exp(-((Us[:, None, :] - U[None, :, :]) ** 2 * w).sum(-1))
+    cf = sla.cho_factor(K, lower=True)
+    alpha = sla.cho_solve(cf, r)
+    mean = Ks @ alpha
+    Vref = sla.solve_triangular(cf[0], Ks.T, lower=True).T  # m x n
+    var = 0.8 - (Vref ** 2).sum(1)
+    A, Li, T = _sq(n), _sq(n), _sq(n)
+    A.copy_(_dev(K))
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gpu_ctx.potrf(A, Li, info)
+    gpu_ctx.trtri(A, Li, T)
+    z = torch.empty(n, dtype=torch.float64, device="cuda")
+    out3 = torch.empty(3, dtype=torch.float64, device="cuda")
+    gpu_ctx.mll_reduce(A, Li, _dev(r), z, out3)
+    ld = lambda k: max(16, (k + 15) // 16 * 16)
+    Kns = torch.empty(n, ld(m), dtype=torch.float64, device="cuda")[:, :m]
+    Kns.copy_(_dev(Ks.T))
+    V = torch.full((m, ld(n)), float("nan"), dtype=torch.float64, device="cuda")[:, :n]
+    mo = torch.empty(m, dtype=torch.float64, device="cuda")
+    vo = torch.empty(m, dtype=torch.float64, device="cuda")
+    kss = torch.full((m,), 0.8, dtype=torch.float64, device="cuda")
+    gpu_ctx.predict_tn(Li, z, Kns, kss, V, mo, vo)
+    sc = 1e-9 * np.abs(mean).max() + 1e-12
+    np.testing.assert_allclose(mo.cpu().numpy(), mean, rtol=1e-8, atol=sc)
+    np.testing.assert_allclose(vo.cpu().numpy(), var, rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(V.cpu().numpy(), Vref, rtol=1e-7, atol=1e-9)
+    # the [test][train] form, with and without the variance
+    Ksn = torch.empty(m, ld(n), dtype=torch.float64, device="cuda")[:, :n]
+    Ksn.copy_(_dev(Ks))
+    al = torch.empty(n, dtype=torch.float64, device="cuda")
+    gpu_ctx.alpha(Li, z, al)
+    m2 = torch.empty(m, dtype=torch.float64, device="cuda")
+    gpu_ctx.predict(Li, al, Ksn, None, None, m2, None)
+    np.testing.assert_allclose(m2.cpu().numpy(), mean, rtol=1e-8, atol=sc)
