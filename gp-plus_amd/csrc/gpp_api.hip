@@ -702,7 +702,7 @@ int gpp_lauum(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double
   // 0.278, 4096 0.742 / 0.502 / 0.610, 6144 1.38 / 1.55 / 1.94)
   static const int lt = getenv("GPP_LAUUM_TILE") ? atoi(getenv("GPP_LAUUM_TILE")) : 0;  // experiment knob (0: by size)
   const int t = lt ? lt : (N <= 2560 ? 32 : N <= 5120 ? 64 : NBLK);
-  GPP_TRY(gpp_launch_gemm(h->stream, 2, g, 1, t, t));
+  GPP_TRY(gpp_launch_gemm(h->stream, 2, g, 1, t, t == 256 ? 128 : t));  // (256: the tall 256 x 128 tile, 8 waves — experiment)
   return 0;
 }
 

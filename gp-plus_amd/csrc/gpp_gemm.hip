@@ -86,15 +86,15 @@ __device__ __forceinline__ void store_kc(double* __restrict__ s, int tid, const 
 }
 
 // Operand stored [k][row] (row contiguous): BK k x T rows per chunk, BK * T / 512 16-byte vectors per thread.
-template <int T, int BK>
+template <int T, int BK, int NTH = 256>
 __device__ __forceinline__ unsigned load_mc(const double* __restrict__ P, int64_t ld, int R, int r0, int kb, int kend,
-                                            int mask, int tid, v2d (&reg)[BK * T / 512]) {
-  constexpr int NV = BK * T / 512;
+                                            int mask, int tid, v2d (&reg)[BK * T / (2 * NTH)]) {
+  constexpr int NV = BK * T / (2 * NTH);
   unsigned keep = 0;
   const double* ptr[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int v = tid + 256 * i;
+    const int v = tid + NTH * i;
     const int gk = kb + v / (T / 2);
     const int gr = r0 + ((v % (T / 2)) << 1);
     const bool v0 = (gk < kend) & (gr < R);
@@ -108,11 +108,11 @@ __device__ __forceinline__ unsigned load_mc(const double* __restrict__ P, int64_
   for (int i = 0; i < NV; ++i) reg[i] = *reinterpret_cast<const v2d*>(ptr[i]);  // all requests back to back
   return keep;
 }
-template <int T, int BK, bool SEL>
-__device__ __forceinline__ void store_mc(double* __restrict__ s, int tid, const v2d (&reg)[BK * T / 512], unsigned keep) {
+template <int T, int BK, bool SEL, int NTH = 256>
+__device__ __forceinline__ void store_mc(double* __restrict__ s, int tid, const v2d (&reg)[BK * T / (2 * NTH)], unsigned keep) {
 #pragma unroll
-  for (int i = 0; i < BK * T / 512; ++i) {
-    const int v = tid + 256 * i;
+  for (int i = 0; i < BK * T / (2 * NTH); ++i) {
+    const int v = tid + NTH * i;
     v2d t = reg[i];
     if (SEL) {
       t.x = ((keep >> (2 * i)) & 1u) ? t.x : 0.0;
@@ -140,12 +140,12 @@ template <int T, int BK>
 __device__ __forceinline__ bool chunk_in_range(int r0, int R, int kb, int kend) {
   return r0 + T <= R && kb + BK <= kend;
 }
-template <int T, int BK>
+template <int T, int BK, int NTH = 256>
 __device__ __forceinline__ unsigned mask_bits_mc(int r0, int kb, int mask, int tid) {
   unsigned keep = 0;
 #pragma unroll
-  for (int i = 0; i < BK * T / 512; ++i) {
-    const int v = tid + 256 * i;
+  for (int i = 0; i < BK * T / (2 * NTH); ++i) {
+    const int v = tid + NTH * i;
     const int gk = kb + v / (T / 2);
     const int gr = r0 + ((v % (T / 2)) << 1);
     keep |= (keep_elem(mask, gk, gr) ? 1u : 0u) << (2 * i);
@@ -153,11 +153,11 @@ __device__ __forceinline__ unsigned mask_bits_mc(int r0, int kb, int mask, int t
   }
   return keep;
 }
-template <int T, bool KC, int BK>
-__device__ __forceinline__ void thread_offsets(int64_t ld, int tid, unsigned (&off)[BK * T / 512]) {
+template <int T, bool KC, int BK, int NTH = 256>
+__device__ __forceinline__ void thread_offsets(int64_t ld, int tid, unsigned (&off)[BK * T / (2 * NTH)]) {
 #pragma unroll
-  for (int i = 0; i < BK * T / 512; ++i) {
-    const int v = tid + 256 * i;
+  for (int i = 0; i < BK * T / (2 * NTH); ++i) {
+    const int v = tid + NTH * i;
     if (KC) off[i] = (unsigned)(((int64_t)(v >> 3) * ld + ((v & 7) << 1)) * 8);
     else off[i] = (unsigned)(((int64_t)(v / (T / 2)) * ld + ((v % (T / 2)) << 1)) * 8);
   }
@@ -178,17 +178,23 @@ __device__ __forceinline__ void load_fast(const double* __restrict__ ubase, cons
 // leaves have almost no MFMA work per 16-wide chunk, so every chunk cost one full L2 round trip (~0.6 us: a K = 128
 // product took 8-20 us); they run (64, 1): four times fewer round trips, the next chunk's loads in flight in
 // registers during the MFMAs, two barriers per chunk.  (k-contiguous operands, VAR != 2, only exist with BK = 16.)
-template <int VAR, int WTM, int WTN, int TAG = 0, int BK = 16, int NBUF = 2>
-__global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM < 64) ? 2 : 1) void gpp_gemm_f64(GemmArgs p) {
+// WR = rows of waves in the work-group: 2 (256 threads, 2 x 2 waves: every instantiation of the evaluation) or 4 (512 threads, 4 x 2
+// waves, a 256 x 128 tile on ONE work-group per CU: the experiment of DESIGN.md section 3.5 — 25 % fewer operand bytes per flop).
+template <int VAR, int WTM, int WTN, int TAG = 0, int BK = 16, int NBUF = 2, int WR = 2>
+__global__ __launch_bounds__(128 * WR, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM < 64) ? 2 : 1) void gpp_gemm_f64(GemmArgs p) {
   static_assert(BK == 16 || VAR == 2, "wide K chunks are implemented for row-contiguous (TN) operands only");
   static_assert(BK % 16 == 0 && (NBUF == 1 || NBUF == 2), "bad staging parameters");
+  static_assert(WR == 2 || (WR == 4 && VAR == 2 && BK == 16 && NBUF == 2 && WTM == 64 && WTN == 64), "the tall tile is TN only");
+  constexpr int NTH = 128 * WR;
   constexpr bool A_KC = (VAR != 2);
   constexpr bool B_KC = (VAR == 0);
-  constexpr int TM = 2 * WTM, TN = 2 * WTN;  // work-group tile: TM rows x TN columns (2 x 2 waves)
+  constexpr int TM = WR * WTM, TN = 2 * WTN;  // work-group tile: TM rows x TN columns (WR x 2 waves)
   constexpr int LDA = ldt_mc(TM, BK), LDB = ldt_mc(TN, BK);  // strides of [k][row] chunks (MC operands)
   constexpr int TX = TM > TN ? TM : TN;
-  constexpr int OPSZ = (BK * ldt_mc(TX, BK) > TX * LDK) ? BK * ldt_mc(TX, BK) : TX * LDK;  // doubles per staged chunk
-  constexpr int NVA = BK * TM / 512, NVB = BK * TN / 512;  // 16-byte vectors per thread and chunk
+  // doubles per staged chunk: one size for both operands of the square tiles, the two true sizes for the tall one
+  constexpr int OPSZ = (BK * ldt_mc(TX, BK) > TX * LDK) ? BK * ldt_mc(TX, BK) : TX * LDK;
+  constexpr int OPA = (WR == 2) ? OPSZ : BK * LDA, OPB = (WR == 2) ? OPSZ : BK * LDB;
+  constexpr int NVA = BK * TM / (2 * NTH), NVB = BK * TN / (2 * NTH);  // 16-byte vectors per thread and chunk
   constexpr int RB = WTM / 4, CB = WTN / 16;
   extern __shared__ __attribute__((aligned(16))) double smem[];  // NBUF * 2 * OPSZ doubles (see gemm_lds_bytes)
 
@@ -216,6 +222,13 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
       while (S(i) > t) --i;
       tm = p.row_off + p.row_mod * i;
       tn = t - S(i);
+    } else if (p.c_lower == 1 && TM == 2 * TN) {
+      // tall tiles, lower triangle: tile row tm (TM rows) has the column tiles 0 .. 2 tm + 1; S(tm) = tm (tm + 1) tiles precede it
+      tm = (int)((sqrtf(4.f * (float)t + 1.f) - 1.f) * 0.5f);
+      while ((tm + 1) * (tm + 2) <= t) ++tm;
+      while (tm * (tm + 1) > t) --tm;
+      tn = t - tm * (tm + 1);
+      if (tn >= p.tiles_n) return;
     } else if (p.c_lower) {
       tm = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
       while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
@@ -274,8 +287,8 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
   v2d ra[NVA], rb[NVB];
   unsigned ka = 0, kb_ = 0;
   unsigned offa[NVA], offb[NVB];
-  thread_offsets<TM, A_KC, BK>(p.lda, tid, offa);
-  thread_offsets<TN, B_KC, BK>(p.ldb, tid, offb);
+  thread_offsets<TM, A_KC, BK, NTH>(p.lda, tid, offa);
+  thread_offsets<TN, B_KC, BK, NTH>(p.ldb, tid, offb);
   // uniform bases of the tile's first chunk row/column block; advanced by a scalar per chunk
   const double* __restrict__ ubaseA = A_KC ? A + (int64_t)row0 * p.lda : A + row0;
   const double* __restrict__ ubaseB = B_KC ? B + (int64_t)col0 * p.ldb : B + col0;
@@ -294,29 +307,29 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
     }
     if (pa) {
       load_fast<NVA>(ubaseA + (int64_t)kb * stepA, offa, ra);
-      if (pa == 2) ka = mask_bits_mc<TM, BK>(row0, kb, p.a_mask, tid);
+      if (pa == 2) ka = mask_bits_mc<TM, BK, NTH>(row0, kb, p.a_mask, tid);
     } else {
       if constexpr (A_KC) ka = load_kc<TM>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra);
-      else ka = load_mc<TM, BK>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra);
+      else ka = load_mc<TM, BK, NTH>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra);
     }
     if (pb) {
       load_fast<NVB>(ubaseB + (int64_t)kb * stepB, offb, rb);
-      if (pb == 2) kb_ = mask_bits_mc<TN, BK>(col0, kb, p.b_mask, tid);
+      if (pb == 2) kb_ = mask_bits_mc<TN, BK, NTH>(col0, kb, p.b_mask, tid);
     } else {
       if constexpr (B_KC) kb_ = load_kc<TN>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb);
-      else kb_ = load_mc<TN, BK>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb);
+      else kb_ = load_mc<TN, BK, NTH>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb);
     }
   };
   auto stage_store = [&](double* da, double* db) {
     if (pa == 1) {
-      if constexpr (A_KC) store_kc<TM, false>(da, tid, ra, 0); else store_mc<TM, BK, false>(da, tid, ra, 0);
+      if constexpr (A_KC) store_kc<TM, false>(da, tid, ra, 0); else store_mc<TM, BK, false, NTH>(da, tid, ra, 0);
     } else {
-      if constexpr (A_KC) store_kc<TM, true>(da, tid, ra, ka); else store_mc<TM, BK, true>(da, tid, ra, ka);
+      if constexpr (A_KC) store_kc<TM, true>(da, tid, ra, ka); else store_mc<TM, BK, true, NTH>(da, tid, ra, ka);
     }
     if (pb == 1) {
-      if constexpr (B_KC) store_kc<TN, false>(db, tid, rb, 0); else store_mc<TN, BK, false>(db, tid, rb, 0);
+      if constexpr (B_KC) store_kc<TN, false>(db, tid, rb, 0); else store_mc<TN, BK, false, NTH>(db, tid, rb, 0);
     } else {
-      if constexpr (B_KC) store_kc<TN, true>(db, tid, rb, kb_); else store_mc<TN, BK, true>(db, tid, rb, kb_);
+      if constexpr (B_KC) store_kc<TN, true>(db, tid, rb, kb_); else store_mc<TN, BK, true, NTH>(db, tid, rb, kb_);
     }
   };
 
@@ -326,15 +339,15 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
   auto kpos = [&](int c) { return p.k_reverse ? klo + (nch - 1 - c) * BK : klo + c * BK; };
   if (nch > 0) {
     stage_load(kpos(0));
-    stage_store(smem, smem + OPSZ);
+    stage_store(smem, smem + OPA);
   }
   __syncthreads();
 
   auto compute = [&](int cur) {
     // v_mfma_f64_16x16x4_f64: lane (i = l&15, k = l>>4) supplies A[row i][k] and B[k][col i]; one instruction yields a
     // 16 x 16 block of C.  Per k-step of 4 a 64 x 64 wave tile takes 4 + 4 fragment reads for 16 MFMAs.
-    const double* sa = smem + (cur * 2 + 0) * OPSZ + (A_KC ? (wm + li) * LDK + lk : wm + li + lk * LDA);
-    const double* sb = smem + (cur * 2 + 1) * OPSZ + (B_KC ? (wn + li) * LDK + lk : wn + li + lk * LDB);
+    const double* sa = smem + cur * (OPA + OPB) + (A_KC ? (wm + li) * LDK + lk : wm + li + lk * LDA);
+    const double* sb = smem + cur * (OPA + OPB) + OPA + (B_KC ? (wn + li) * LDK + lk : wn + li + lk * LDB);
 #pragma unroll
     for (int kk = 0; kk < BK / 4; ++kk) {
       double bf[CB], af[RB / 4];
@@ -384,7 +397,7 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
     if (NBUF == 1) __syncthreads();  // everyone has read this chunk: the single buffer may take the next one
     if (more) {
       const int nxt = (NBUF == 2) ? (cur ^ 1) : 0;
-      stage_store(smem + (nxt * 2 + 0) * OPSZ, smem + (nxt * 2 + 1) * OPSZ);
+      stage_store(smem + nxt * (OPA + OPB), smem + nxt * (OPA + OPB) + OPA);
     }
     __syncthreads();
   };
@@ -402,8 +415,8 @@ __global__ __launch_bounds__(256, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM 
       compute(cur);
       if constexpr (TAG == 1) __builtin_amdgcn_s_setprio(0);
       if (NBUF == 1) __syncthreads();
-      store_mc<TM, BK, false>(smem + (nxt * 2 + 0) * OPSZ, tid, ra, 0);
-      store_mc<TN, BK, false>(smem + (nxt * 2 + 1) * OPSZ, tid, rb, 0);
+      store_mc<TM, BK, false, NTH>(smem + nxt * (OPA + OPB), tid, ra, 0);
+      store_mc<TN, BK, false, NTH>(smem + nxt * (OPA + OPB) + OPA, tid, rb, 0);
       __syncthreads();
     }
   }
@@ -454,10 +467,11 @@ constexpr size_t gemm_lds_bytes(int var, int tm, int tn, int bk, int nbuf) {
   const int mc = bk * ldt_mc(tx, bk), kc = tx * LDK;
   return (size_t)nbuf * 2 * ((var != 2 && kc > mc) ? kc : mc) * sizeof(double);
 }
-template <int VAR, int WTM, int WTN, int TAG, int BK, int NBUF>
+template <int VAR, int WTM, int WTN, int TAG, int BK, int NBUF, int WR = 2>
 hipError_t launch_inst(hipStream_t s, dim3 grid, const GemmArgs& a) {
-  constexpr size_t bytes = gemm_lds_bytes(VAR, 2 * WTM, 2 * WTN, BK, NBUF);
-  auto* fn = gpp_gemm_f64<VAR, WTM, WTN, TAG, BK, NBUF>;
+  constexpr size_t bytes = (WR == 2) ? gemm_lds_bytes(VAR, 2 * WTM, 2 * WTN, BK, NBUF)
+                                     : (size_t)NBUF * BK * (ldt_mc(WR * WTM, BK) + ldt_mc(2 * WTN, BK)) * sizeof(double);
+  auto* fn = gpp_gemm_f64<VAR, WTM, WTN, TAG, BK, NBUF, WR>;
   if (bytes > 48 * 1024) {
     static std::atomic<bool> attr_set[64];  // per instantiation and device (function attributes are per device)
     int dev = 0;
@@ -469,7 +483,7 @@ hipError_t launch_inst(hipStream_t s, dim3 grid, const GemmArgs& a) {
       if (dev >= 0 && dev < 64) attr_set[dev] = true;
     }
   }
-  hipLaunchKernelGGL(fn, grid, dim3(256), bytes, s, a);
+  hipLaunchKernelGGL(fn, grid, dim3(128 * WR), bytes, s, a);
   return hipGetLastError();
 }
 // small tiles: wide K chunks for the row-contiguous variant, the classic staging otherwise
@@ -480,6 +494,9 @@ template <int VAR>
 hipError_t launch_var(hipStream_t s, int tm, int tn, dim3 grid, const GemmArgs& a) {
   constexpr int SBK = (VAR == 2) ? GPP_SMALL_BK : 16;
   constexpr int SNB = (VAR == 2 && GPP_SMALL_BK > 16) ? 1 : 2;
+  if constexpr (VAR == 2) {
+    if (tm == 256 && tn == 128) return launch_inst<2, 64, 64, 1, 16, 2, 4>(s, grid, a);  // (TAG 1: its own name in profiles)
+  }
   if (tm == 128 && tn == 128 && a.tag == 1 && VAR == 2) return launch_inst<2, 64, 64, 1, 16, 2>(s, grid, a);
   if (tm == 128 && tn == 128) return launch_inst<VAR, 64, 64, 0, 16, 2>(s, grid, a);
   if (tm == 64 && tn == 64) return launch_inst<VAR, 32, 32, 0, SBK, SNB>(s, grid, a);
@@ -509,10 +526,12 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int
     else tile_m = 32;
     tile_n = tile_m;
   }
-  if (a.c_lower && tile_m != tile_n) return hipErrorInvalidValue;
+  const bool tall = (tile_m == 256 && tile_n == 128);
+  if (a.c_lower && tile_m != tile_n && !(tall && a.c_lower == 1 && a.row_mod <= 1 && a.row_i1 == 0 && a.row_t1 == 0)) return hipErrorInvalidValue;
   a.tiles_m = (a.M + tile_m - 1) / tile_m;
   a.tiles_n = (a.N + tile_n - 1) / tile_n;
   int64_t nt = a.c_lower ? (int64_t)a.tiles_m * (a.tiles_m + 1) / 2 : (int64_t)a.tiles_m * a.tiles_n;
+  if (tall && a.c_lower == 1) nt = (int64_t)a.tiles_m * (a.tiles_m + 1);  // row tm: column tiles 0 .. 2 tm + 1 (those past N exit)
   a.tile_base = 0;
   if (a.c_lower == 1 && (a.row_mod > 1 || a.row_i1 > 0)) {
     if (a.row_mod < 1) { a.row_mod = 1; a.row_off = 0; }
