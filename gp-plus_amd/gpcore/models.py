@@ -70,7 +70,7 @@ class ExactGP(GP):
         if self.training:
             if self.train_inputs is None:
                 raise RuntimeError("train_inputs, train_targets cannot be None in training mode.")
-            if not all(torch.equal(ti, x) for ti, x in zip(self.train_inputs, inputs)):
+            if not all(ti is x or torch.equal(ti, x) for ti, x in zip(self.train_inputs, inputs)):  # (equal() waits for the GPU)
                 raise RuntimeError("You must train on the training inputs!")
             return Module.__call__(self, *inputs, **kwargs)
         # ---- posterior mode -----------------------------------------------------------------------

@@ -1,0 +1,89 @@
+"""Objective + gradient as ONE replayed HIP graph (hipGraph through ``torch.cuda.CUDAGraph``).
+
+At the sizes of the reference's examples (N = 100 ... 2000) one evaluation of ``optim/mll_scipy.py:37-60,101-127`` — model
+forward, ~40 library launches, priors, autograd backward, parameter transforms — is ~100 short kernels issued by ~2 ms of
+Python, and the L-BFGS loop of ``fit_model_scipy`` runs thousands of them one after the other.  The launches do not depend on
+the parameter VALUES, only on shapes: they are captured once, with the parameters read from one flat device vector, and every
+later evaluation is a copy of theta, one graph launch and one read-back of (objective, gradient, factorisation status).
+
+Nothing may wait for the host inside a capture, so the factorisation runs its no-jitter attempt only and leaves its status on the
+device (``linalg._factor``); a replay whose status is not zero — or whose objective is not finite — returns ``None`` and the caller
+evaluates that point eagerly (jitter retries, NotPSDError / NanError).  Limited to the single-stream factorisation (N < 3840):
+above that one evaluation is long enough to hide the host, and the look-ahead driver's internal streams do not belong in a graph.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .linalg import LOOKAHEAD_MIN_N, get_context, get_workspace
+
+__all__ = ["GraphedObjective"]
+
+
+class GraphedObjective:
+    """``closure()`` -> scalar objective of ``params``; ``evaluate(theta)`` -> (value, gradient) as numpy, or None."""
+
+    def __init__(self, closure: Callable[[], torch.Tensor], params: List[torch.nn.Parameter], n_points: int, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("graph replay needs a GPU device")
+        if n_points >= LOOKAHEAD_MIN_N:
+            raise RuntimeError(f"graph replay is limited to N < {LOOKAHEAD_MIN_N}")
+        self.params, self.device = params, device
+        self.sizes = [p.numel() for p in params]
+        n = sum(self.sizes)
+        self.n = n
+        self.theta = torch.zeros(n, dtype=torch.float64, device=device)            # static input of the graph
+        self.theta_host = torch.zeros(n, dtype=torch.float64).pin_memory()
+        self.out_host = torch.zeros(n + 2, dtype=torch.float64).pin_memory()
+        self.done = torch.cuda.Event()
+        # the evaluation workspace the captured launches write to: held here, because linalg.get_workspace drops a size when
+        # another one is asked for and a replay must never write into memory that has been handed to someone else
+        self.gctx = get_context(device)
+        self.ws = get_workspace(self.gctx, n_points)
+        self.status = self.ws.info
+
+        def body():
+            with torch.no_grad():  # scatter theta into the parameters (their storage is the graph's own input)
+                i = 0
+                for p, k in zip(params, self.sizes):
+                    p.copy_(self.theta[i:i + k].view(p.shape))
+                    i += k
+            value = closure()
+            grads = torch.autograd.grad(value, params)
+            return torch.cat([value.detach().reshape(1).double()] + [g.reshape(-1).double() for g in grads]
+                             + [self.status.reshape(1).double()])
+
+        with torch.no_grad():
+            self.theta.copy_(torch.cat([p.detach().reshape(-1).double() for p in params]))
+        # warm-up on a side stream (allocations, lazily created workspaces, one-time checks), then the capture
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                body()
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = body()
+        self._lib_scratch = self.gctx._ws  # (same reason: the library's scratch buffer is replaced when a larger one is needed)
+        self.replays = 0
+
+    def evaluate(self, theta: np.ndarray) -> Optional[Tuple[float, np.ndarray]]:
+        self.theta_host.copy_(torch.from_numpy(np.ascontiguousarray(theta, dtype=np.float64)))
+        self.theta.copy_(self.theta_host, non_blocking=True)
+        self.ws.epoch += 1  # the factors in the workspace are overwritten: prediction caches living there are stale
+        self.graph.replay()
+        self.out_host.copy_(self.out, non_blocking=True)
+        self.done.record(torch.cuda.current_stream(self.device))
+        self.done.synchronize()
+        self.replays += 1
+        res = self.out_host.numpy()
+        value, status = float(res[0]), res[-1]
+        if status != 0.0 or not np.isfinite(value) or not np.all(np.isfinite(res[1:-1])):
+            return None
+        return value, res[1:-1].copy()

@@ -126,6 +126,17 @@ def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_spl
     """Build Ky (upper) and factor it, with gpytorch's jitter-retry policy.  Returns the jitter that was needed.
     ``after()`` enqueues whatever follows the factorisation BEFORE ``info`` is read back, so the GPU keeps working while
     the host waits (and afterwards runs the Python between forward and backward); a failed attempt just repeats it."""
+    if torch.cuda.is_current_stream_capturing():
+        # Inside a HIP-graph capture (gp-plus_amd/graphed.py) nothing may wait for the host: ONE attempt without jitter, the
+        # status stays on the device in ``ws.info`` — the owner of the graph reads it with the result of every replay and
+        # falls back to this eager path (jitter retries, exceptions) when it is not zero.
+        if ws.N >= LOOKAHEAD_MIN_N:
+            raise RuntimeError("graph capture of the evaluation is limited to the single-stream factorisation (N < 3840)")
+        ctx.kernel_build(U, w, sf2, tau, grp, ws.A, jitter=0.0, kind=kind, d_split=d_split, uplo=UPLO_UPPER)
+        ctx.potrf(ws.A, ws.Li, ws.info, ws.Ki)
+        if after is not None:
+            after()
+        return 0.0
     jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
     for jit in jitters:
         # The factorisation's launches (a DAG over the library's internal streams, ~1000 launches at N = 20000) run fastest

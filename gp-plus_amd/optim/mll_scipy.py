@@ -64,7 +64,37 @@ class MLLObjective:
     def pack_grads(self) -> np.ndarray:
         return np.concatenate([p.grad.detach().cpu().double().numpy().ravel() for p in self._params().values()]).astype(np.float64)
 
+    def _graphed(self):
+        """The replayed form of ``fun`` (gp-plus_amd/graphed.py), built on first use; None when it does not apply."""
+        if getattr(self, "_graph", None) is None and not getattr(self, "_graph_failed", False):
+            from .. import settings
+            from ..graphed import GraphedObjective
+            from ..linalg import LOOKAHEAD_MIN_N
+
+            params = list(self._params().values())
+            dev = params[0].device if params else torch.device("cpu")
+            n_points = self.model.train_inputs[0].shape[0]
+            ok = (settings.graphed_objective.value() and dev.type == "cuda" and n_points < LOOKAHEAD_MIN_N
+                  and settings.sharded_evaluation.value() is None and not getattr(self.model, "interval_score", False))
+            if not ok:
+                self._graph_failed = True
+                return None
+            try:
+                self._graph = GraphedObjective(
+                    lambda: -marginal_log_likelihood(self.model, self.add_prior, self.regularization_parameter), params,
+                    n_points, dev)
+            except (NotPSDError, NanError, RuntimeError):  # (an indefinite warm-up point, or a capture the stack refuses)
+                self._graph_failed = True
+                return None
+        return getattr(self, "_graph", None)
+
     def fun(self, x: np.ndarray, return_grad=True) -> Union[float, Tuple[float, np.ndarray]]:
+        g = self._graphed() if return_grad else None
+        if g is not None:
+            res = g.evaluate(x)
+            if res is not None:
+                return res
+            # the factorisation failed without jitter (or the objective is not finite): this point goes the eager way
         old = self.model.state_dict()
         old.update(self.unpack_parameters(x))
         self.model.load_state_dict(old)

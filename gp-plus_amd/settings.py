@@ -32,6 +32,12 @@ min_variance = _Value(1e-10)        # gpytorch.settings.min_variance (double)
 batched_restarts = _Value(True)
 
 
+# Graph replay of the L-BFGS objective (optim/mll_scipy.py): for small problems, where one evaluation is a chain of ~100 short
+# launches issued by ~2 ms of Python, ``fit_model_scipy`` captures objective + gradient once as a HIP graph and replays it per
+# evaluation (gp-plus_amd/graphed.py).  ``with settings.graphed_objective(False):`` evaluates eagerly, as the reference does.
+graphed_objective = _Value(True)
+
+
 # Sharded single evaluation (gp-plus_amd/sharded.py): ``with settings.sharded_evaluation({"group": None, "nb": 1024}):``
 # makes every exact-GP log-likelihood inside the block a cooperative evaluation by all ranks of the process group
 # (None = the default group).  Every rank must run the same model code with the same parameters.

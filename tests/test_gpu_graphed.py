@@ -1,0 +1,164 @@
+"""The replayed L-BFGS objective (gp-plus_amd/graphed.py) against the eager evaluation it was captured from:
+same value and gradient at every point, the eager path for the points the replay cannot serve (an indefinite Ky, NaN), the same
+fit from ``fit_model_scipy`` with the replay on and off — and a prediction cache that notices its factors were overwritten."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+pytestmark = pytest.mark.gpu
+
+
+def load(name):
+    return dict(np.load(os.path.join(GOLD, name)))
+
+
+def _model(kind, n=None, **extra):
+    from gpplus_amd.models import GP_Plus
+
+    if kind == "plain":
+        fx = load("c1_borehole_n500.npz")
+        X, y, kw = fx["Xtrain"], fx["ytrain"], {}
+    elif kind == "mixed":
+        fx = load("c3_borehole_mixed_n100.npz")
+        X, y, kw = fx["Utrain"], fx["ytrain"], dict(qual_dict={0: 5, 5: 5})
+    else:
+        fx = load("c4_wing_mf_n300.npz")
+        X, y, kw = fx["Xtrain"], fx["ytrain"], dict(qual_dict={10: 3}, multiple_noise=True, m_gp="multiple_constant")
+    if n is not None:
+        X, y = X[:n], y[:n]
+    kw.update(extra)
+    return GP_Plus(torch.tensor(X), torch.tensor(y), dtype=torch.float64, device=torch.device("cuda:0"), **kw)
+
+
+def _objective(model):
+    from gpplus_amd.optim.mll_scipy import MLLObjective
+
+    model.train()
+    return MLLObjective(model, True, [0, 0])
+
+
+@pytest.mark.parametrize("kind", ["plain", "mixed", "multifidelity"])
+def test_replay_equals_eager_evaluation(kind):
+    from gpplus_amd import settings
+
+    m = _model(kind)
+    obj = _objective(m)
+    x0 = obj.pack_parameters()
+    rng = np.random.default_rng(0)
+    points = [x0] + [x0 + 0.3 * rng.standard_normal(x0.shape) for _ in range(6)]
+    with settings.graphed_objective(False):
+        eager = [_objective(m).fun(x) for x in points]
+    got = [obj.fun(x) for x in points]
+    assert obj._graph is not None and obj._graph.replays == len(points)
+    for (fe, ge), (fg, gg) in zip(eager, got):
+        # the same launches on the same data in the same order
+        assert fg == pytest.approx(fe, rel=1e-13, abs=0)
+        np.testing.assert_allclose(gg, ge, rtol=1e-11, atol=1e-13)
+    # the replay leaves the evaluated point in the model, as load_state_dict does on the eager path
+    np.testing.assert_array_equal(obj.pack_parameters(), points[-1])
+    # visiting the points again in another order gives the same numbers again (nothing carried over between replays)
+    again = [obj.fun(x) for x in reversed(points)]
+    for (f1, g1), (f2, g2) in zip(reversed(got), again):
+        assert f1 == f2 and np.array_equal(g1, g2)
+
+
+def test_points_the_replay_cannot_serve_take_the_eager_path():
+    from gpplus_amd import settings
+    from gpplus_amd.errors import NanError
+
+    # 300 points on a line, a very long lengthscale and (almost) no noise: Ky is numerically singular, the factorisation
+    # without jitter fails and the answer has to come from the eager path's jitter retries
+    from gpplus_amd.models import GP_Plus
+
+    x = torch.linspace(0, 1, 300, dtype=torch.float64).reshape(-1, 1)
+    y = torch.sin(6 * x[:, 0])
+    m = GP_Plus(x, y, dtype=torch.float64, device=torch.device("cuda:0"), lb_noise=1e-14)
+    obj = _objective(m)
+    names = list(obj.param_shapes)
+    x0 = obj.pack_parameters()
+    good = obj.fun(x0)
+    assert obj._graph is not None and obj._graph.replays == 1
+    bad = x0.copy()
+    for i, n in enumerate(names):
+        if "raw_lengthscale" in n:
+            bad[i] = -9.0   # omega = 10^-9: a constant kernel
+        if "raw_noise" in n:
+            bad[i] = -40.0
+    assert obj._graph.evaluate(bad) is None
+    with warnings.catch_warnings(record=True) as w1:
+        warnings.simplefilter("always")
+        f_g, g_g = obj.fun(bad)
+    with settings.graphed_objective(False), warnings.catch_warnings(record=True) as w2:
+        warnings.simplefilter("always")
+        f_e, g_e = _objective(m).fun(bad)
+    assert any("jitter" in str(w.message) for w in w1) and any("jitter" in str(w.message) for w in w2)
+    assert f_g == f_e and np.array_equal(g_g, g_e)
+    # the graph is still good for the next point
+    f2, g2 = obj.fun(x0)
+    assert f2 == good[0] and np.array_equal(g2, good[1])
+    # NaN in theta: NanError from the eager path, as without the replay
+    nan = x0.copy()
+    nan[0] = np.nan
+    with pytest.raises(NanError):
+        obj.fun(nan)
+
+
+def test_fit_model_scipy_is_the_same_fit_with_and_without_replay():
+    from gpplus_amd import settings
+    from gpplus_amd.optim.mll_scipy import fit_model_scipy
+
+    out = {}
+    for on in (True, False):
+        m = _model("mixed")
+        torch.manual_seed(4)
+        with settings.graphed_objective(on):
+            res, nll = fit_model_scipy(m, num_restarts=2, options={"maxfun": 300})
+        out[on] = (nll, [r.nfev for r in res], m.state_dict())
+    assert out[True][0] == pytest.approx(out[False][0], rel=1e-10)
+    assert out[True][1] == out[False][1]
+    for k, v in out[False][2].items():
+        torch.testing.assert_close(out[True][2][k], v, rtol=1e-8, atol=1e-10)
+
+
+def test_prediction_cache_sees_the_replays():
+    m = _model("plain", n=200)
+    fx = load("c1_borehole_n500.npz")
+    Xt = torch.tensor(fx["Xtrain"][200:260], device="cuda:0")
+    m.eval()
+    with torch.no_grad():
+        before = m(Xt).mean.clone()
+    cache = m.prediction_strategy
+    assert cache is not None and not cache.stale()
+    other = _model("plain", n=200)  # same N: same evaluation workspace
+    obj = _objective(other)
+    x0 = obj.pack_parameters()
+    obj.fun(x0)
+    obj.fun(x0 + 0.1)
+    assert obj._graph.replays == 2
+    if cache._ws is obj._graph.ws:
+        assert cache.stale()
+    with torch.no_grad():
+        after = m(Xt).mean
+    torch.testing.assert_close(after, before, rtol=1e-12, atol=1e-12)
+
+
+def test_large_problems_and_the_switch_leave_the_objective_eager():
+    from gpplus_amd import settings
+
+    m = _model("plain", n=100)
+    with settings.graphed_objective(False):
+        obj = _objective(m)
+        obj.fun(obj.pack_parameters())
+        assert obj._graphed() is None
+    from gpplus_amd.graphed import GraphedObjective
+
+    with pytest.raises(RuntimeError, match="N <"):
+        GraphedObjective(lambda: None, [], 5000, torch.device("cuda:0"))
