@@ -153,6 +153,23 @@ hipError_t potrf_rec(const Ctx& c, int64_t o, int64_t n) {
   return potrf_rec(c, o + n1, n2);
 }
 
+// Cooperative panel (gpp_leaf.hip): the block [o, o+n) factored AND inverted by one launch — used for the look-ahead's diagonal
+// blocks and for a whole small matrix.  GPP_COOP_PANEL=0 restores the chain of leaf-step launches + pair merges (experiment knob).
+constexpr int64_t PANEL_MAX_N = 1024;
+inline bool panel_enabled() {
+  static const bool on = !(getenv("GPP_COOP_PANEL") && atoi(getenv("GPP_COOP_PANEL")) == 0);
+  return on;
+}
+inline bool panel_fits(const gpp_handle_s* h, int64_t n) {
+  static const int64_t nmax = getenv("GPP_PANEL_MAX_N") ? atol(getenv("GPP_PANEL_MAX_N")) : PANEL_MAX_N;  // experiment knob
+  return panel_enabled() && h->panel_flags && n > NBLK && n % NBLK == 0 && n <= nmax && n / NBLK <= gpp_panel_max_leaves();
+}
+hipError_t launch_panel(gpp_handle_s* h, const Ctx& c, int64_t o, int64_t n, int max_wgs) {
+  int* fl = reinterpret_cast<int*>(h->panel_flags + (size_t)(h->panel_next % GPP_PANEL_RING) * gpp_panel_flag_bytes());
+  ++h->panel_next;
+  return gpp_launch_panel(c.s, c.A + o * c.ld + o, c.ld, c.Li + o * c.ldi + o, c.ldi, (int)n, c.info, (int)o, fl, max_wgs);
+}
+
 // ---- triangular inverse by pair merging -------------------------------------------------------------------------
 // One level: for the pairs of s-blocks [b, b+s), [b+s, min(b+2s, base+n)) of the range [base, base+n):
 //     T21 = U12^T Linv11 ;  Linv21 = -W22^T T21 (+ mirror).  ``skip(b)`` drops pairs that are already merged.
@@ -367,8 +384,19 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
     const int64_t want = (N - o >= nb_thresh) ? nb_big : nb_small;
     nb = std::min(want, N - o);
     const int64_t rem = N - o - nb;
-    HIP_TRY(potrf_rec(cp, o, nb));
-    if (T) {
+    const bool coop = T != nullptr && panel_fits(h, nb);
+    if (coop) {
+      // factor + complete inverse of the diagonal block in ONE cooperative launch on the panel's CUs
+      HIP_TRY(launch_panel(h, cp, o, nb, h->cu_split == 1 ? h->panel_cus : 64));
+      if (h->inv_nblocks < 128) {
+        h->inv_o[h->inv_nblocks] = o;
+        h->inv_n[h->inv_nblocks] = nb;
+        ++h->inv_nblocks;
+      }
+    } else {
+      HIP_TRY(potrf_rec(cp, o, nb));
+    }
+    if (T && !coop) {
       // complete inverse of this diagonal block, still on the panel stream (hidden behind the trailing update): it turns
       // the wide trsm below into ONE GEMM and is exactly the low levels of gpp_trtri, which will skip them
       for (int64_t s = NBLK; s < nb; s *= 2)
@@ -480,7 +508,19 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
         HIP_TRY(gpp_launch_gemm(cu.s, 2, a2, 1, NBLK, NBLK));
         GemmArgs a1 = g3;  // upper triangle of the leading rA x rA block (minus the next diagonal block): a few hundred
         a1.M = a1.N = (int)rA;  // tiles, issued last so that they run beside the unmasked part instead of on an emptying chip
-        HIP_TRY(gpp_launch_gemm(cu.s, 2, a1, 1, NBLK, NBLK));
+        // (measured A/B twice: potrf 26.8 -> 25.9 ms at N = 15000, 52.9 -> 52.3 at 20000, 16.2 -> 16.0 at 12288, even at 30000)
+        static const bool a1_fill = !(getenv("GPP_A1_FILL") && atoi(getenv("GPP_A1_FILL")) == 0);  // experiment knob
+        if (a1_fill) {
+          // on the second masked stream, beside the rectangle above: the two launches share ONE ragged last wave of work-groups
+          // instead of each ending on its own (a K = 1024 tile runs ~240 us; 990 tiles on 448 slots are 2.2 waves)
+          HIP_TRY(hipStreamWaitEvent(cf, pend.rows_ready, 0));
+          HIP_TRY(gpp_launch_gemm(cf, 2, a1, 1, NBLK, NBLK));
+          hipEvent_t A1 = next_event(h);
+          HIP_TRY(hipEventRecord(A1, cf));
+          HIP_TRY(hipStreamWaitEvent(cu.s, A1, 0));
+        } else {
+          HIP_TRY(gpp_launch_gemm(cu.s, 2, a1, 1, NBLK, NBLK));
+        }
         pend.g = mk(Urow + (o + nb + rA), cm.ld, Urow + (o + nb + rA), cm.ld, cm.A + (o + nb + rA) * cm.ld + (o + nb + rA),
                     cm.ld, rem - rA, rem - rA, nb, -1.0, 1.0);
         pend.g.c_lower = 2;
@@ -551,6 +591,13 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->ev_next = 0;
   h->inv_N = 0;
   h->inv_nblocks = 0;
+  h->panel_flags = nullptr;
+  h->panel_next = 0;
+  // (allocated here, not lazily: a first use inside a stream capture could not allocate)
+  if (hipMalloc(reinterpret_cast<void**>(&h->panel_flags), GPP_PANEL_RING * gpp_panel_flag_bytes()) != hipSuccess) {
+    (void)hipGetLastError();
+    h->panel_flags = nullptr;  // the leaf-step chain is used instead
+  }
   *out = h;
   return 0;
 }
@@ -562,6 +609,7 @@ int gpp_destroy(gpp_handle_t h) {
   if (h->fill_stream) (void)hipStreamDestroy(h->fill_stream);
   if (h->full_stream) (void)hipStreamDestroy(h->full_stream);
   for (int i = 0; i < h->n_events; ++i) (void)hipEventDestroy(h->events[i]);
+  if (h->panel_flags) (void)hipFree(h->panel_flags);
   delete h;
   return 0;
 }
@@ -656,8 +704,17 @@ int gpp_potrf_ws(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv,
   // (measured: the leaf-step factorisation on one stream wins up to ~6000 rows — 2.99 vs 3.46 ms at 4096, 4.25 vs 4.53 at
   //  5120, a tie at 6144; the look-ahead wins from there: 8.6 vs 10.1 ms at 8192)
   static const int64_t la_min_b = getenv("GPP_BORDER_MIN") ? atol(getenv("GPP_BORDER_MIN")) : BORDER_MIN_N;  // knob
-  if (N >= (T ? std::min(la_min, la_min_b) : la_min)) GPP_TRY(potrf_lookahead(h, c, N, LOOKAHEAD_NB, T, ldt));
-  else GPP_TRY(potrf_rec(c, 0, N));
+  if (N >= (T ? std::min(la_min, la_min_b) : la_min)) {
+    GPP_TRY(potrf_lookahead(h, c, N, LOOKAHEAD_NB, T, ldt));
+  } else if (panel_fits(h, N)) {
+    // a small matrix: factor and inverse by one cooperative launch on the caller's stream; gpp_trtri finds the inverse complete
+    GPP_TRY(launch_panel(h, c, 0, N, 256));
+    h->inv_nblocks = 1;
+    h->inv_o[0] = 0;
+    h->inv_n[0] = N;
+  } else {
+    GPP_TRY(potrf_rec(c, 0, N));
+  }
   return 0;
 }
 

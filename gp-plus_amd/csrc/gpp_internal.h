@@ -25,7 +25,12 @@ struct gpp_handle_s {
   int64_t inv_N;             // N of that factorisation (0: nothing recorded)
   int inv_nblocks;
   int64_t inv_o[128], inv_n[128];
+  // flag blocks of the cooperative panel launches (gpp_leaf.hip), used round-robin: a block is zeroed in stream order right
+  // before its launch, and no more than PANEL_RING panels are ever in flight on one handle
+  char* panel_flags;
+  int panel_next;
 };
+constexpr int GPP_PANEL_RING = 8;
 
 // ---- exp for the covariance kernels --------------------------------------------------------------
 // exp(x) for x <= 0 (every argument of the path is -r^2 or -sqrt(.)): k = rint(x log2 e), r = x - k ln 2 in two parts (Cody-Waite,
@@ -122,6 +127,11 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a, int ba
 // A holds the UPPER factor (A = U^T U, i.e. L = U^T read/written with swapped indices); the n x n diagonal block of
 // Linv receives inv(L) in its lower triangle and the mirror image inv(L)^T in its strict upper triangle.
 // batch > 1: independent blocks at A + b*sA, Linv + b*sLi, info + b (one work-group each).
+// cooperative panel (gpp_leaf.hip): factor AND invert a diagonal block of n = 128 C rows in one launch
+size_t gpp_panel_flag_bytes();
+int gpp_panel_max_leaves();
+hipError_t gpp_launch_panel(hipStream_t s, double* A, int64_t lda, double* Linv, int64_t ldi, int n, int32_t* info, int row_offset,
+                            int* flags, int max_wgs);
 hipError_t gpp_launch_leaf(hipStream_t s, double* A, int64_t lda, double* Linv, int64_t ldi, int n, int32_t* info,
                            int row_offset, int batch = 1, int64_t sA = 0, int64_t sLi = 0);
 

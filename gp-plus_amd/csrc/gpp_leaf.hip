@@ -21,7 +21,9 @@
 // Then the 8 diagonal tiles are inverted in parallel (2 per wave, lane per column) and the inverse is assembled by
 // pair merging at tile level (sizes 16, 32, 64): X21 = -X22 (L21 X11), MFMA again.
 #include "gpp_internal.h"
+#include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
@@ -255,12 +257,9 @@ __device__ __forceinline__ void write_linv_block(double* __restrict__ Linv, int6
   }
 }
 
-__global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
-                                                          int64_t ldi, int n, int32_t* info, int row_offset, int64_t sA,
-                                                          int64_t sLi) {
-  A += (int64_t)blockIdx.x * sA;  // batch element: an independent block
-  Linv += (int64_t)blockIdx.x * sLi;
-  info += blockIdx.x;
+// The whole leaf, called by all 256 threads of a work-group (the leaf kernel below, and the chain work-group of gpp_panel_potrf_inv).
+__device__ __forceinline__ void leaf_body(double* __restrict__ A, int64_t lda, double* __restrict__ Linv, int64_t ldi, int n,
+                                          int32_t* info, int row_offset) {
   // ONE 36-tile image of exactly 72 KiB: LDS is allocated contiguously, so on the look-ahead stream the leaf can only
   // start beside a running GEMM work-group if it fits the 72.5 KiB slot a finished GEMM work-group leaves behind.
   // Slot (i,j) holds, in turn: the parked raw tile; L(i,j) (off-diagonal) or L_jj with its diagonal replaced by the
@@ -414,7 +413,370 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
   STAMP(43);
 }
 
+__global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
+                                                          int64_t ldi, int n, int32_t* info, int row_offset, int64_t sA,
+                                                          int64_t sLi) {
+  // batch element: an independent block
+  leaf_body(A + (int64_t)blockIdx.x * sA, lda, Linv + (int64_t)blockIdx.x * sLi, ldi, n, info + blockIdx.x, row_offset);
+}
+
+// ---- cooperative panel: a whole diagonal block (C leaves of 128 rows) factored AND inverted by ONE launch -----------------------
+// The leaf-step factorisation of a diagonal block (potrf_blk in gpp_api.hip) is a chain of 3 launches per 128 rows — leaf, panel
+// solve, rank-128 update — followed by the pair merges of the block's inverse: at 1024 rows 8 x (45 + ~32) us + ~200 us, of which
+// only the leaves are inherently serial.  Here ONE work-group runs the leaves back to back and the others do everything else in
+// 128 x 32 strips, handing results over through flags in device memory (release / acquire at agent scope: tools/flag_probe.hip
+// measures 0.8 us per hand-off on an idle chip, ~4 us beside a kernel that saturates the memory system — a launch gap is 3-12):
+//   chain work-group : for j = 0 .. C-1:  wait until tile (j,j) has its update from row j-1;  leaf(j) -> U_jj, inv(L_jj);  publish
+//   factor strip (c,q), c = 1 .. C-1, q = 0 .. 3 (columns 32 q .. 32 q + 31 of tile column c), for j = 0 .. c-1:
+//         S : U[j,c]_q = inv(L_jj) A[j,c]_q            (needs leaf j)
+//         U : A[r,c]_q -= U[j,r]^T U[j,c]_q, r = j+1..c (needs all four strips of U[j,r]); after (r = c, j = c-1) tile (c,c) is ready
+//   inverse strip (i,q), i = 0 .. C-2, for j = i+1 .. C-1 (bordering, one leaf row at a time, one step BEHIND the factor strips so
+//         that it never delays them):  Linv[j,i]_q = -inv(L_jj) sum_{m=i}^{j-1} U[m,j]^T Linv[m,i]_q   (+ its mirror)
+// Every strip belongs to one work-group for the whole launch, so each entry is produced by the same sequence of operations
+// whatever the timing (bitwise repeatable), a strip's read-modify-write needs no lock, and the only waits are on EARLIER tasks
+// of a fixed global order (step j: S, then U, then the inverse row j-1) — no cycles, provided every work-group of the launch
+// gets onto the chip at some point: the grid never exceeds what the stream's CUs hold at one work-group each (72 KiB of LDS, ~350
+// registers per lane).
+// A wait gives up after ~1 s (then *info = 1 << 30 and every work-group leaves): a logic error must not hang the GPU.
+constexpr int PMAXC = 32;                         // leaves per launch the flag block is laid out for
+constexpr int PF_ABORT = 0, PF_LEAF = 1, PF_DIAG = 1 + PMAXC, PF_SOLVED = 1 + 2 * PMAXC;  // offsets (ints) in a flag block
+constexpr int PF_INTS = PF_SOLVED + PMAXC * PMAXC;
+constexpr int PBK = 16;                           // k rows per staged chunk
+constexpr int PLDA = 128 + 16, PLDB = 32 + 16;    // LDS row strides (doubles): two consecutive k rows fall in different bank halves
+constexpr int P_BUF = PBK * (PLDA + PLDB);        // one staged chunk of both operands; two of them: 48 KiB, less than the leaf's image
+
+// Phase stamps of the chain and of the strip that feeds the next leaf (tools/panel_stamps.py; a probe build only).
+#ifdef GPP_PANEL_STAMP
+__device__ unsigned long long g_panel_stamps[512];
+#define PSTAMP(i)                                                                   \
+  do {                                                                              \
+    if (threadIdx.x == 0) g_panel_stamps[(i)] = __builtin_amdgcn_s_memtime();       \
+  } while (0)
+#else
+#define PSTAMP(i) \
+  do {            \
+  } while (0)
+#endif
+
+// One 128 x 32 strip product  acc += A^T B  over K = 128 on a work-group of four waves.  Both operands are fetched WHOLE into
+// registers first (A: 128 k x 128 m, 32 16-byte vectors per thread; B: 128 k x 32 n, 8 vectors) — one memory round trip per
+// product instead of one per chunk, and the fetch can be issued before the flag the product waits for when the operand is the
+// work-group's own data — and then fed through two LDS chunk buffers of 16 k, one barrier per chunk.
+// Wave w owns the 16-row blocks w and 7 - w: with the triangular A of a leaf inverse (AMASK: keep k <= m) chunk c only matters for
+// row blocks >= c, and this deal gives every wave the same 72 of 128 MFMAs.
+struct StripAcc {
+  v4d c[2][2];  // [a][b] element v: row 16 rb(a) + 4 v + (lane >> 4), rb(0) = wave, rb(1) = 7 - wave; column 16 b + (lane & 15)
+};
+struct StripA { v2d r[32]; };
+struct StripB { v2d r[8]; };
+// (addresses = work-group-uniform row base + ONE per-thread 32-bit byte offset: no address registers per load)
+__device__ __forceinline__ void strip_load_a(StripA& o, const double* __restrict__ Ag, int64_t lda, int tid) {
+  const unsigned off = (unsigned)(((int64_t)(tid >> 6) * lda + ((tid & 63) << 1)) * 8);
+#pragma unroll
+  for (int i = 0; i < 32; ++i)  // vector i: row (tid >> 6) + 4 i, columns 2 (tid & 63) ..
+    o.r[i] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Ag + (int64_t)(4 * i) * lda) + off);
+}
+__device__ __forceinline__ void strip_load_b(StripB& o, const double* __restrict__ Bg, int64_t ldb, int tid) {
+  const unsigned off = (unsigned)(((int64_t)(tid >> 4) * ldb + ((tid & 15) << 1)) * 8);
+#pragma unroll
+  for (int i = 0; i < 8; ++i)  // vector i: row (tid >> 4) + 16 i, columns 2 (tid & 15) ..
+    o.r[i] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Bg + (int64_t)(16 * i) * ldb) + off);
+}
+// AMASK: A keeps k <= m.  BSRC 0: B from `ob`; 1: B from `ob`, keeping k >= bcol0 + n (the lower-triangular inverse of a leaf);
+// 2: B is the strip held in the accumulators `tb` (the result of a previous product, rows = k).
+template <bool AMASK, int BSRC>
+__device__ __forceinline__ void strip_mma(StripAcc& acc, const StripA& oa, const StripB& ob, const StripAcc& tb, int bcol0,
+                                          double* lds, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+  const int rb0 = wave, rb1 = 7 - wave;
+  auto stage = [&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    double* sA = lds + (c & 1) * P_BUF;
+    double* sB = sA + PBK * PLDA;
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int row = wave + 4 * ii, c2 = (tid & 63) << 1, k = PBK * c + row;
+      v2d t = oa.r[4 * c + ii];
+      if (AMASK) {
+        t.x = (k <= c2) ? t.x : 0.0;
+        t.y = (k <= c2 + 1) ? t.y : 0.0;
+      }
+      *reinterpret_cast<v2d*>(sA + row * PLDA + c2) = t;
+    }
+    if (BSRC < 2) {
+      const int row = tid >> 4, c2 = (tid & 15) << 1, k = PBK * c + row;
+      v2d t = ob.r[c];
+      if (BSRC == 1) {
+        t.x = (k >= bcol0 + c2) ? t.x : 0.0;
+        t.y = (k >= bcol0 + c2 + 1) ? t.y : 0.0;
+      }
+      *reinterpret_cast<v2d*>(sB + row * PLDB + c2) = t;
+    } else {
+      // rows 16 c .. 16 c + 15 of the strip in `tb` are row block c: wave c (its block 0) or wave 7 - c (its block 1)
+      constexpr int a = c < 4 ? 0 : 1;
+      if (wave == (c < 4 ? c : 7 - c)) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) sB[(4 * v + lk) * PLDB + 16 * b + li] = tb.c[a][b][v];
+      }
+    }
+  };
+  auto compute = [&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    const double* sA = lds + (c & 1) * P_BUF;
+    const double* sB = sA + PBK * PLDA;
+    const bool do0 = !AMASK || c <= rb0, do1 = !AMASK || c <= rb1;  // (wave-uniform)
+    const double* pa = sA + lk * PLDA + li;
+    const double* pb = sB + lk * PLDB + li;
+    if (do1) {
+#pragma unroll
+      for (int kk = 0; kk < PBK / 4; ++kk) {
+        const double b0 = pb[4 * kk * PLDB], b1 = pb[4 * kk * PLDB + 16];
+        const double a1 = pa[4 * kk * PLDA + 16 * rb1];
+        if (do0) {
+          const double a0 = pa[4 * kk * PLDA + 16 * rb0];
+          acc.c[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc.c[0][0], 0, 0, 0);
+          acc.c[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc.c[0][1], 0, 0, 0);
+        }
+        acc.c[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc.c[1][0], 0, 0, 0);
+        acc.c[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc.c[1][1], 0, 0, 0);
+      }
+    }
+  };
+  auto step = [&](auto cc) {
+    constexpr int c = decltype(cc)::value;
+    if constexpr (c + 1 < 128 / PBK) stage(std::integral_constant<int, c + 1>{});
+    compute(cc);
+    __syncthreads();
+  };
+  stage(std::integral_constant<int, 0>{});
+  __syncthreads();
+  step(std::integral_constant<int, 0>{});
+  step(std::integral_constant<int, 1>{});
+  step(std::integral_constant<int, 2>{});
+  step(std::integral_constant<int, 3>{});
+  step(std::integral_constant<int, 4>{});
+  step(std::integral_constant<int, 5>{});
+  step(std::integral_constant<int, 6>{});
+  step(std::integral_constant<int, 7>{});
+}
+__device__ __forceinline__ void strip_zero(StripAcc& acc) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) acc.c[a][b] = (v4d){0.0, 0.0, 0.0, 0.0};
+}
+
+// Wait until *flag >= target (thread 0 polls; everybody learns the outcome).  false: the launch is being abandoned.
+__device__ __forceinline__ bool panel_wait(int* flag, int target, int* flags, int tid) {
+  __shared__ int s_ok;
+  if (tid == 0) {
+    int ok = 1;
+    int spins = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (__hip_atomic_load(flags + PF_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || ++spins > (1 << 21)) {
+        ok = 0;
+        __hip_atomic_store(flags + PF_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    s_ok = ok;
+  }
+  __syncthreads();
+  const int ok = s_ok;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the publisher wrote before raising the flag is visible from here
+  __syncthreads();
+  return ok != 0;
+}
+// Everything this work-group has written becomes visible to whoever sees the flag change.
+__device__ __forceinline__ void panel_publish(int* flag, int tid) {
+  __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have left the CU
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+__global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
+                                                           int64_t ldi, int C, int32_t* info, int row_offset, int* flags) {
+  extern __shared__ __attribute__((aligned(16))) double img[];
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0) {  // the chain
+    for (int j = 0; j < C; ++j) {
+      PSTAMP(4 * j);
+      if (j > 0 && !panel_wait(flags + PF_DIAG + j, 4, flags, tid)) break;
+      PSTAMP(4 * j + 1);
+      leaf_body(A + (int64_t)(128 * j) * lda + 128 * j, lda, Linv + (int64_t)(128 * j) * ldi + 128 * j, ldi, 128, info,
+                row_offset + 128 * j);
+      PSTAMP(4 * j + 2);
+      panel_publish(flags + PF_LEAF + j, tid);
+      PSTAMP(4 * j + 3);
+    }
+    if (tid == 0 && __hip_atomic_load(flags + PF_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) atomicCAS(info, 0, 1 << 30);
+    return;
+  }
+  const int W = (int)gridDim.x - 1, w = (int)blockIdx.x - 1, nf = 4 * (C - 1), ns = 2 * nf;
+  const int lane = tid & 63, wave = tid >> 6, li = lane & 15, lk = lane >> 4;
+  const int rbase[2] = {16 * wave, 16 * (7 - wave)};  // first rows of this wave's two 16-row blocks (see StripAcc)
+  auto tileA = [&](int r, int c) { return A + (int64_t)(128 * r) * lda + 128 * c; };
+  auto tileI = [&](int r, int c) { return Linv + (int64_t)(128 * r) * ldi + 128 * c; };
+  StripA oa;
+  StripB ob;
+  StripAcc none;
+  strip_zero(none);
+  // row j of the inverse, strip (i, q)
+  auto inverse_row = [&](int j, int i, int q) {
+    StripAcc t;
+    strip_zero(t);
+    for (int m = i; m < j; ++m) {
+      strip_load_a(oa, tileA(m, j), lda, tid);
+      strip_load_b(ob, tileI(m, i) + 32 * q, ldi, tid);
+      if (m == i) strip_mma<false, 1>(t, oa, ob, none, 32 * q, img, tid);
+      else strip_mma<false, 0>(t, oa, ob, none, 0, img, tid);
+    }
+    strip_load_a(oa, tileI(j, j), ldi, tid);
+    StripAcc x;
+    strip_zero(x);
+    strip_mma<true, 2>(x, oa, ob, t, 0, img, tid);
+    double* lo = tileI(j, i) + 32 * q;                   // Linv[j,i] strip: rows m, columns n
+    double* up = tileI(i, j) + (int64_t)(32 * q) * ldi;  // its mirror: rows n, columns m
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const int m = rbase[a] + 4 * v + lk, n = 16 * b + li;
+          const double val = -x.c[a][b][v];
+          lo[(int64_t)m * ldi + n] = val;
+          up[(int64_t)n * ldi + m] = val;
+        }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();  // (the next row of this strip reads what this one wrote)
+  };
+  bool ok = true;
+  for (int j = 0; j < C && ok; ++j) {
+    // S: the strips of block row j
+    for (int s = w; s < nf && ok; s += W) {
+      const int c = 1 + (s >> 2), q = s & 3;
+      if (c <= j) continue;
+      const bool stamp = (c == j + 1 && q == 0);
+      double* Bp = tileA(j, c) + 32 * q;
+      strip_load_b(ob, Bp, lda, tid);  // this work-group's own data (its update of the previous step): fetched while the leaf runs
+      if (stamp) PSTAMP(128 + 8 * j);
+      ok = panel_wait(flags + PF_LEAF + j, 1, flags, tid);
+      if (!ok) break;
+      if (stamp) PSTAMP(128 + 8 * j + 1);
+      strip_load_a(oa, tileI(j, j), ldi, tid);
+      StripAcc x;
+      strip_zero(x);
+      strip_mma<true, 0>(x, oa, ob, none, 0, img, tid);
+      if (stamp) PSTAMP(128 + 8 * j + 2);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) Bp[(int64_t)(rbase[a] + 4 * v + lk) * lda + 16 * b + li] = x.c[a][b][v];
+      panel_publish(flags + PF_SOLVED + j * PMAXC + c, tid);
+      if (stamp) PSTAMP(128 + 8 * j + 3);
+    }
+    // U: rank-128 update of the strips below block row j
+    for (int s = w; s < nf && ok; s += W) {
+      const int c = 1 + (s >> 2), q = s & 3;
+      if (c <= j) continue;
+      const bool stamp = (c == j + 1 && q == 0);
+      strip_load_b(ob, tileA(j, c) + 32 * q, lda, tid);  // own S result
+      for (int r = j + 1; r <= c && ok; ++r) {
+        double* Cp = tileA(r, c) + 32 * q;
+        double cold[2][2][4];  // own data as well: fetched before the wait
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) cold[a][b][v] = Cp[(int64_t)(rbase[a] + 4 * v + lk) * lda + 16 * b + li];
+        ok = panel_wait(flags + PF_SOLVED + j * PMAXC + r, 4, flags, tid);
+        if (!ok) break;
+        if (stamp) PSTAMP(128 + 8 * j + 4);
+        strip_load_a(oa, tileA(j, r), lda, tid);
+        StripAcc x;
+        strip_zero(x);
+        strip_mma<false, 0>(x, oa, ob, none, 0, img, tid);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              const int m = rbase[a] + 4 * v + lk, n = 16 * b + li;
+              if (r < c || m <= 32 * q + n) Cp[(int64_t)m * lda + n] = cold[a][b][v] - x.c[a][b][v];  // diagonal tile: upper triangle only
+            }
+      }
+      if (stamp) PSTAMP(128 + 8 * j + 5);
+      if (ok && c == j + 1) panel_publish(flags + PF_DIAG + c, tid);
+      else { __builtin_amdgcn_s_waitcnt(0); __syncthreads(); }
+      if (stamp) PSTAMP(128 + 8 * j + 6);
+    }
+    // inverse: row j-1 (row C-1 after the loop)
+    for (int s = w; s < ns && ok; s += W) {
+      if (s < nf) continue;
+      const int i = (s - nf) >> 2, q = s & 3, jj = j - 1;
+      if (jj < 1 || i >= jj) continue;
+      ok = panel_wait(flags + PF_LEAF + jj, 1, flags, tid);
+      if (ok) inverse_row(jj, i, q);
+    }
+  }
+  for (int s = w; s < ns && ok; s += W) {
+    if (s < nf) continue;
+    const int i = (s - nf) >> 2, q = s & 3, jj = C - 1;
+    if (jj < 1 || i >= jj) continue;
+    ok = panel_wait(flags + PF_LEAF + jj, 1, flags, tid);
+    if (ok) inverse_row(jj, i, q);
+  }
+}
+
 }  // namespace
+
+#ifdef GPP_PANEL_STAMP
+extern "C" int gpp_debug_panel_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_panel_stamps), sizeof(unsigned long long) * 512);
+}
+#endif
+size_t gpp_panel_flag_bytes() { return (((size_t)PF_INTS * sizeof(int) + 255) / 256) * 256; }
+int gpp_panel_max_leaves() { return PMAXC; }
+
+// n = 128 C rows (C <= 32); `flags` = gpp_panel_flag_bytes() bytes of device memory that no other launch in flight uses;
+// `max_wgs` = work-groups the stream's CUs hold at one each (the grid never exceeds it: see the kernel's comment).
+hipError_t gpp_launch_panel(hipStream_t s, double* A, int64_t lda, double* Linv, int64_t ldi, int n, int32_t* info,
+                            int row_offset, int* flags, int max_wgs) {
+  if (n <= 0) return hipSuccess;
+  if (n % NB != 0 || n / NB > PMAXC || max_wgs < 2 || !flags) return hipErrorInvalidValue;
+  const int C = n / NB;
+  static std::atomic<bool> attr_set[64];
+  // the leaf's 72 KiB image is the larger tenant: like the leaf alone, a panel work-group fits the slot a finished GEMM work-group
+  // leaves behind on a CU (see gpp_leaf_potrf_inv)
+  const size_t shmem = (size_t)NT * TSZ * sizeof(double);
+  static_assert((size_t)2 * P_BUF <= (size_t)NT * TSZ, "the strip buffers must fit the leaf image");
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(gpp_panel_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)shmem);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  e = hipMemsetAsync(flags, 0, gpp_panel_flag_bytes(), s);
+  if (e != hipSuccess) return e;
+  const int workers = C > 1 ? std::min(8 * (C - 1), max_wgs - 1) : 0;
+  hipLaunchKernelGGL(gpp_panel_potrf_inv, dim3((unsigned)(1 + workers)), dim3(256), shmem, s, A, lda, Linv, ldi, C, info, row_offset,
+                     flags);
+  return hipGetLastError();
+}
 
 hipError_t gpp_launch_leaf(hipStream_t s, double* A, int64_t lda, double* Linv, int64_t ldi, int n, int32_t* info,
                            int row_offset, int batch, int64_t sA, int64_t sLi) {
