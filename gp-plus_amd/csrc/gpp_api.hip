@@ -155,14 +155,14 @@ hipError_t potrf_rec(const Ctx& c, int64_t o, int64_t n) {
 
 // Cooperative panel (gpp_leaf.hip): the block [o, o+n) factored AND inverted by one launch — used for the look-ahead's diagonal
 // blocks and for a whole small matrix.  GPP_COOP_PANEL=0 restores the chain of leaf-step launches + pair merges (experiment knob).
-constexpr int64_t PANEL_MAX_N = 1024;
+constexpr int64_t PANEL_MAX_N = 2048;
 inline bool panel_enabled() {
   static const bool on = !(getenv("GPP_COOP_PANEL") && atoi(getenv("GPP_COOP_PANEL")) == 0);
   return on;
 }
 inline bool panel_fits(const gpp_handle_s* h, int64_t n) {
   static const int64_t nmax = getenv("GPP_PANEL_MAX_N") ? atol(getenv("GPP_PANEL_MAX_N")) : PANEL_MAX_N;  // experiment knob
-  return panel_enabled() && h->panel_flags && n > NBLK && n % NBLK == 0 && n <= nmax && n / NBLK <= gpp_panel_max_leaves();
+  return panel_enabled() && h->panel_flags && h->ncu >= 2 && n > 2 * NBLK && n <= nmax && (n + NBLK - 1) / NBLK <= gpp_panel_max_leaves();
 }
 hipError_t launch_panel(gpp_handle_s* h, const Ctx& c, int64_t o, int64_t n, int max_wgs) {
   int* fl = reinterpret_cast<int*>(h->panel_flags + (size_t)(h->panel_next % GPP_PANEL_RING) * gpp_panel_flag_bytes());
@@ -387,7 +387,7 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
     const bool coop = T != nullptr && panel_fits(h, nb);
     if (coop) {
       // factor + complete inverse of the diagonal block in ONE cooperative launch on the panel's CUs
-      HIP_TRY(launch_panel(h, cp, o, nb, h->cu_split == 1 ? h->panel_cus : 64));
+      HIP_TRY(launch_panel(h, cp, o, nb, h->cu_split == 1 ? h->panel_cus : std::min(64, h->ncu)));
       if (h->inv_nblocks < 128) {
         h->inv_o[h->inv_nblocks] = o;
         h->inv_n[h->inv_nblocks] = nb;
@@ -593,6 +593,11 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->inv_nblocks = 0;
   h->panel_flags = nullptr;
   h->panel_next = 0;
+  h->ncu = 0;
+  if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->ncu < 2) {
+    (void)hipGetLastError();
+    h->ncu = 0;
+  }
   // (allocated here, not lazily: a first use inside a stream capture could not allocate)
   if (hipMalloc(reinterpret_cast<void**>(&h->panel_flags), GPP_PANEL_RING * gpp_panel_flag_bytes()) != hipSuccess) {
     (void)hipGetLastError();
@@ -708,7 +713,11 @@ int gpp_potrf_ws(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv,
     GPP_TRY(potrf_lookahead(h, c, N, LOOKAHEAD_NB, T, ldt));
   } else if (panel_fits(h, N)) {
     // a small matrix: factor and inverse by one cooperative launch on the caller's stream; gpp_trtri finds the inverse complete
-    GPP_TRY(launch_panel(h, c, 0, N, 256));
+    // (every work-group of the launch must fit on the stream's CUs at once: on the handle's own CU-masked streams that is fewer)
+    int wgs = h->ncu;
+    if (h->cu_split == 1 && h->stream == h->panel_stream) wgs = h->panel_cus;
+    else if (h->cu_split == 1 && (h->stream == h->upd_stream || h->stream == h->fill_stream)) wgs = h->ncu - h->panel_cus;
+    GPP_TRY(launch_panel(h, c, 0, N, wgs));
     h->inv_nblocks = 1;
     h->inv_o[0] = 0;
     h->inv_n[0] = N;

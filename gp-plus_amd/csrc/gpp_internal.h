@@ -29,6 +29,7 @@ struct gpp_handle_s {
   // before its launch, and no more than PANEL_RING panels are ever in flight on one handle
   char* panel_flags;
   int panel_next;
+  int ncu;                   // CUs of the device: a panel launch never has more work-groups than its stream's CUs hold
 };
 constexpr int GPP_PANEL_RING = 8;
 

@@ -470,17 +470,44 @@ struct StripAcc {
 struct StripA { v2d r[32]; };
 struct StripB { v2d r[8]; };
 // (addresses = work-group-uniform row base + ONE per-thread 32-bit byte offset: no address registers per load)
-__device__ __forceinline__ void strip_load_a(StripA& o, const double* __restrict__ Ag, int64_t lda, int tid) {
+// klim / mlim / nlim: valid rows and columns of the operand (the last tile of a ragged block is smaller); the rest reads as zero.
+// A 16-byte vector that starts on the last valid column reads one double past it: still inside the row (ld is even, gpp.h).
+__device__ __forceinline__ void strip_load_a(StripA& o, const double* __restrict__ Ag, int64_t lda, int tid, int klim = 128,
+                                             int mlim = 128) {
   const unsigned off = (unsigned)(((int64_t)(tid >> 6) * lda + ((tid & 63) << 1)) * 8);
+  if (klim == 128 && mlim == 128) {
 #pragma unroll
-  for (int i = 0; i < 32; ++i)  // vector i: row (tid >> 6) + 4 i, columns 2 (tid & 63) ..
-    o.r[i] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Ag + (int64_t)(4 * i) * lda) + off);
+    for (int i = 0; i < 32; ++i)  // vector i: row (tid >> 6) + 4 i, columns 2 (tid & 63) ..
+      o.r[i] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Ag + (int64_t)(4 * i) * lda) + off);
+  } else {
+    const int c2 = (tid & 63) << 1;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+      const bool ok = ((tid >> 6) + 4 * i < klim) & (c2 < mlim);
+      // (uniform row base, per-thread offset: a dropped vector reads the first element of a valid row instead)
+      const v2d t = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Ag + (int64_t)(4 * i < klim ? 4 * i : 0) * lda) + (ok ? off : 0u));
+      o.r[i].x = ok ? t.x : 0.0;
+      o.r[i].y = (ok & (c2 + 1 < mlim)) ? t.y : 0.0;
+    }
+  }
 }
-__device__ __forceinline__ void strip_load_b(StripB& o, const double* __restrict__ Bg, int64_t ldb, int tid) {
+__device__ __forceinline__ void strip_load_b(StripB& o, const double* __restrict__ Bg, int64_t ldb, int tid, int klim = 128,
+                                             int nlim = 32) {
   const unsigned off = (unsigned)(((int64_t)(tid >> 4) * ldb + ((tid & 15) << 1)) * 8);
+  if (klim == 128 && nlim >= 32) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i)  // vector i: row (tid >> 4) + 16 i, columns 2 (tid & 15) ..
-    o.r[i] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Bg + (int64_t)(16 * i) * ldb) + off);
+    for (int i = 0; i < 8; ++i)  // vector i: row (tid >> 4) + 16 i, columns 2 (tid & 15) ..
+      o.r[i] = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Bg + (int64_t)(16 * i) * ldb) + off);
+  } else {
+    const int c2 = (tid & 15) << 1;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const bool ok = ((tid >> 4) + 16 * i < klim) & (c2 < nlim);
+      const v2d t = *reinterpret_cast<const v2d*>(reinterpret_cast<const char*>(Bg + (int64_t)(16 * i < klim ? 16 * i : 0) * ldb) + (ok ? off : 0u));
+      o.r[i].x = ok ? t.x : 0.0;
+      o.r[i].y = (ok & (c2 + 1 < nlim)) ? t.y : 0.0;
+    }
+  }
 }
 // AMASK: A keeps k <= m.  BSRC 0: B from `ob`; 1: B from `ob`, keeping k >= bcol0 + n (the lower-triangular inverse of a leaf);
 // 2: B is the strip held in the accumulators `tb` (the result of a previous product, rows = k).
@@ -601,15 +628,17 @@ __device__ __forceinline__ void panel_publish(int* flag, int tid) {
 }
 
 __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
-                                                           int64_t ldi, int C, int32_t* info, int row_offset, int* flags) {
+                                                           int64_t ldi, int n, int32_t* info, int row_offset, int* flags) {
   extern __shared__ __attribute__((aligned(16))) double img[];
   const int tid = threadIdx.x;
+  const int C = (n + 127) >> 7, nl = n - 128 * (C - 1);  // leaves; rows of the last one (1 .. 128)
+  auto ext = [&](int t) { return t == C - 1 ? nl : 128; };
   if (blockIdx.x == 0) {  // the chain
     for (int j = 0; j < C; ++j) {
       PSTAMP(4 * j);
       if (j > 0 && !panel_wait(flags + PF_DIAG + j, 4, flags, tid)) break;
       PSTAMP(4 * j + 1);
-      leaf_body(A + (int64_t)(128 * j) * lda + 128 * j, lda, Linv + (int64_t)(128 * j) * ldi + 128 * j, ldi, 128, info,
+      leaf_body(A + (int64_t)(128 * j) * lda + 128 * j, lda, Linv + (int64_t)(128 * j) * ldi + 128 * j, ldi, ext(j), info,
                 row_offset + 128 * j);
       PSTAMP(4 * j + 2);
       panel_publish(flags + PF_LEAF + j, tid);
@@ -631,13 +660,14 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
   auto inverse_row = [&](int j, int i, int q) {
     StripAcc t;
     strip_zero(t);
+    const int ej = ext(j);  // (i < j: tile column i is never the ragged one)
     for (int m = i; m < j; ++m) {
-      strip_load_a(oa, tileA(m, j), lda, tid);
+      strip_load_a(oa, tileA(m, j), lda, tid, 128, ej);
       strip_load_b(ob, tileI(m, i) + 32 * q, ldi, tid);
       if (m == i) strip_mma<false, 1>(t, oa, ob, none, 32 * q, img, tid);
       else strip_mma<false, 0>(t, oa, ob, none, 0, img, tid);
     }
-    strip_load_a(oa, tileI(j, j), ldi, tid);
+    strip_load_a(oa, tileI(j, j), ldi, tid, ej, ej);
     StripAcc x;
     strip_zero(x);
     strip_mma<true, 2>(x, oa, ob, t, 0, img, tid);
@@ -649,10 +679,12 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
       for (int b = 0; b < 2; ++b)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-          const int m = rbase[a] + 4 * v + lk, n = 16 * b + li;
+          const int m = rbase[a] + 4 * v + lk, nn = 16 * b + li;
           const double val = -x.c[a][b][v];
-          lo[(int64_t)m * ldi + n] = val;
-          up[(int64_t)n * ldi + m] = val;
+          if (m < ej) {
+            lo[(int64_t)m * ldi + nn] = val;
+            up[(int64_t)nn * ldi + m] = val;
+          }
         }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();  // (the next row of this strip reads what this one wrote)
@@ -665,7 +697,8 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
       if (c <= j) continue;
       const bool stamp = (c == j + 1 && q == 0);
       double* Bp = tileA(j, c) + 32 * q;
-      strip_load_b(ob, Bp, lda, tid);  // this work-group's own data (its update of the previous step): fetched while the leaf runs
+      const int nlim = ext(c) - 32 * q;  // valid columns of this strip (<= 0: nothing to do but to be counted)
+      strip_load_b(ob, Bp, lda, tid, 128, nlim);  // this work-group's own data (its update of the previous step): fetched while the leaf runs
       if (stamp) PSTAMP(128 + 8 * j);
       ok = panel_wait(flags + PF_LEAF + j, 1, flags, tid);
       if (!ok) break;
@@ -680,7 +713,8 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-          for (int v = 0; v < 4; ++v) Bp[(int64_t)(rbase[a] + 4 * v + lk) * lda + 16 * b + li] = x.c[a][b][v];
+          for (int v = 0; v < 4; ++v)
+            if (16 * b + li < nlim) Bp[(int64_t)(rbase[a] + 4 * v + lk) * lda + 16 * b + li] = x.c[a][b][v];
       panel_publish(flags + PF_SOLVED + j * PMAXC + c, tid);
       if (stamp) PSTAMP(128 + 8 * j + 3);
     }
@@ -689,20 +723,25 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
       const int c = 1 + (s >> 2), q = s & 3;
       if (c <= j) continue;
       const bool stamp = (c == j + 1 && q == 0);
-      strip_load_b(ob, tileA(j, c) + 32 * q, lda, tid);  // own S result
+      const int nlim = ext(c) - 32 * q;
+      strip_load_b(ob, tileA(j, c) + 32 * q, lda, tid, 128, nlim);  // own S result
       for (int r = j + 1; r <= c && ok; ++r) {
         double* Cp = tileA(r, c) + 32 * q;
+        const int er = ext(r);
         double cold[2][2][4];  // own data as well: fetched before the wait
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
           for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int v = 0; v < 4; ++v) cold[a][b][v] = Cp[(int64_t)(rbase[a] + 4 * v + lk) * lda + 16 * b + li];
+            for (int v = 0; v < 4; ++v) {
+              const int m = rbase[a] + 4 * v + lk, nn = 16 * b + li;
+              cold[a][b][v] = (m < er && nn < nlim) ? Cp[(int64_t)m * lda + nn] : 0.0;
+            }
         ok = panel_wait(flags + PF_SOLVED + j * PMAXC + r, 4, flags, tid);
         if (!ok) break;
         if (stamp) PSTAMP(128 + 8 * j + 4);
-        strip_load_a(oa, tileA(j, r), lda, tid);
+        strip_load_a(oa, tileA(j, r), lda, tid, 128, er);
         StripAcc x;
         strip_zero(x);
         strip_mma<false, 0>(x, oa, ob, none, 0, img, tid);
@@ -712,8 +751,9 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
           for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int v = 0; v < 4; ++v) {
-              const int m = rbase[a] + 4 * v + lk, n = 16 * b + li;
-              if (r < c || m <= 32 * q + n) Cp[(int64_t)m * lda + n] = cold[a][b][v] - x.c[a][b][v];  // diagonal tile: upper triangle only
+              const int m = rbase[a] + 4 * v + lk, nn = 16 * b + li;
+              // (diagonal tile: upper triangle only)
+              if (m < er && nn < nlim && (r < c || m <= 32 * q + nn)) Cp[(int64_t)m * lda + nn] = cold[a][b][v] - x.c[a][b][v];
             }
       }
       if (stamp) PSTAMP(128 + 8 * j + 5);
@@ -749,13 +789,13 @@ extern "C" int gpp_debug_panel_stamps(unsigned long long* host) {
 size_t gpp_panel_flag_bytes() { return (((size_t)PF_INTS * sizeof(int) + 255) / 256) * 256; }
 int gpp_panel_max_leaves() { return PMAXC; }
 
-// n = 128 C rows (C <= 32); `flags` = gpp_panel_flag_bytes() bytes of device memory that no other launch in flight uses;
+// n <= 128 * 32 rows (the last leaf may be ragged); `flags` = gpp_panel_flag_bytes() bytes of device memory that no other launch in flight uses;
 // `max_wgs` = work-groups the stream's CUs hold at one each (the grid never exceeds it: see the kernel's comment).
 hipError_t gpp_launch_panel(hipStream_t s, double* A, int64_t lda, double* Linv, int64_t ldi, int n, int32_t* info,
                             int row_offset, int* flags, int max_wgs) {
   if (n <= 0) return hipSuccess;
-  if (n % NB != 0 || n / NB > PMAXC || max_wgs < 2 || !flags) return hipErrorInvalidValue;
-  const int C = n / NB;
+  const int C = (n + NB - 1) / NB;
+  if (C > PMAXC || max_wgs < 2 || !flags) return hipErrorInvalidValue;
   static std::atomic<bool> attr_set[64];
   // the leaf's 72 KiB image is the larger tenant: like the leaf alone, a panel work-group fits the slot a finished GEMM work-group
   // leaves behind on a CU (see gpp_leaf_potrf_inv)
@@ -773,7 +813,7 @@ hipError_t gpp_launch_panel(hipStream_t s, double* A, int64_t lda, double* Linv,
   e = hipMemsetAsync(flags, 0, gpp_panel_flag_bytes(), s);
   if (e != hipSuccess) return e;
   const int workers = C > 1 ? std::min(8 * (C - 1), max_wgs - 1) : 0;
-  hipLaunchKernelGGL(gpp_panel_potrf_inv, dim3((unsigned)(1 + workers)), dim3(256), shmem, s, A, lda, Linv, ldi, C, info, row_offset,
+  hipLaunchKernelGGL(gpp_panel_potrf_inv, dim3((unsigned)(1 + workers)), dim3(256), shmem, s, A, lda, Linv, ldi, n, info, row_offset,
                      flags);
   return hipGetLastError();
 }

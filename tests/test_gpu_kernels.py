@@ -378,7 +378,10 @@ def test_batched_evaluation_matches_single(gpu_ctx, n, d, S, dU, shared):
         tol = dict(rtol=1e-11, atol=1e-11)
         np.testing.assert_allclose(out3[b].cpu().numpy(), o1.cpu().numpy(), **tol)
         np.testing.assert_allclose(al[b].cpu().numpy(), a1.cpu().numpy(), rtol=1e-9, atol=1e-9 * float(a1.abs().max()))
-        np.testing.assert_allclose(np.tril(Ki[b].cpu().numpy()), np.tril(K1.cpu().numpy()), rtol=1e-9, atol=1e-9 * float(K1.abs().max()))
+        # (the strict upper triangle of K1 is never written and still holds the NaN fill: scale from the lower triangle.  The batched
+        #  path factors in leaf steps, the single one with the cooperative panel: equal to rounding, not bitwise)
+        K1l = np.tril(K1.cpu().numpy())
+        np.testing.assert_allclose(np.tril(Ki[b].cpu().numpy()), K1l, rtol=1e-9, atol=1e-9 * float(np.abs(K1l).max()))
         np.testing.assert_allclose(gw[b].cpu().numpy(), w1.cpu().numpy(), rtol=1e-9, atol=1e-9 * float(w1.abs().max()))
         np.testing.assert_allclose(gs[b].item(), s1.item(), rtol=1e-9)
         np.testing.assert_allclose(gt[b].cpu().numpy(), t1.cpu().numpy(), rtol=1e-9, atol=1e-9 * float(t1.abs().max()))

@@ -275,3 +275,77 @@ def test_predict_tn_matches_scipy_and_the_nt_form(gpu_ctx, n, m):
     m2 = torch.empty(m, dtype=torch.float64, device="cuda")
     gpu_ctx.predict(Li, al, Ksn, None, None, m2, None)
     np.testing.assert_allclose(m2.cpu().numpy(), mean, rtol=1e-8, atol=sc)
+
+
+# ---- cooperative panel (gpp_panel_potrf_inv): one launch factors AND inverts a block of up to 2048 rows ---------------------------
+def _spd_block(n, seed):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, 5))
+    d2 = ((X[:, None, :] - X[None, :, :]) ** 2).sum(-1)
+    return np.exp(-0.35 * d2) + 2e-3 * np.eye(n)
+
+
+@pytest.mark.parametrize("n,use_ws", [(257, True), (384, False), (500, True), (777, False), (1000, True), (1024, True),
+                                      (1152, False), (2000, True), (2048, False)])
+def test_panel_factors_and_inverts_in_one_launch(gpu_ctx, n, use_ws):
+    """256 < n <= 2048 on the caller's stream: the panel leaves U AND the complete inverse (lower + mirror), so gpp_trtri has
+    nothing to do — checked by calling it on a poisoned scratch.  Ragged last leaves (n not a multiple of 128) included; the
+    strict lower triangle of A is neither read nor written."""
+    K = _spd_block(n, n)
+    A, Li, T = _sq(n), _sq(n, 0.0), _sq(n)
+    A.copy_(_dev(np.triu(K) + np.tril(np.full((n, n), np.nan), -1)))
+    info = torch.full((1,), -1, dtype=torch.int32, device="cuda")
+    gpu_ctx.potrf(A, Li, info, T if use_ws else None)
+    assert int(info.item()) == 0
+    Lref = np.linalg.cholesky(K)
+    Ah = A.cpu().numpy()
+    np.testing.assert_allclose(np.triu(Ah), Lref.T, rtol=0, atol=1e-11 * np.abs(Lref).max())
+    assert np.isnan(Ah[np.tril_indices(n, -1)]).all()
+    before = Li.clone()
+    gpu_ctx.trtri(A, Li, T)  # T is all NaN: any merge still done here would show
+    assert torch.equal(Li, before)
+    full = Li.cpu().numpy()
+    np.testing.assert_allclose(np.tril(full) @ Lref, np.eye(n), rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(np.triu(full, 1), np.tril(full, -1).T)
+
+
+def test_panel_reports_the_failing_minor_and_is_repeatable(gpu_ctx):
+    n = 1000
+    K = _spd_block(n, 3)
+    bad = K.copy()
+    bad[700, 700] = -1.0
+    A, Li = _sq(n), _sq(n, 0.0)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    A.copy_(_dev(bad))
+    gpu_ctx.potrf(A, Li, info)
+    assert int(info.item()) == 701
+    # the same block twice, and beside another stream's traffic: bitwise the same factor and inverse (every strip has one owner)
+    outs = []
+    side = torch.cuda.Stream()
+    noise = torch.empty(64 << 20, dtype=torch.float64, device="cuda")
+    for rep in range(3):
+        A.copy_(_dev(K))
+        Li.zero_()
+        torch.cuda.synchronize()
+        if rep == 2:
+            with torch.cuda.stream(side):
+                for _ in range(8):
+                    noise.fill_(float(rep))
+        gpu_ctx.potrf(A, Li, info)
+        torch.cuda.synchronize()
+        assert int(info.item()) == 0
+        outs.append((torch.triu(A).clone(), Li.clone()))
+    for U2, L2 in outs[1:]:
+        assert torch.equal(U2, outs[0][0]) and torch.equal(L2, outs[0][1])
+
+
+def test_panel_inside_the_lookahead_reports_the_failing_minor(gpu_ctx):
+    """n = 5000: the look-ahead's diagonal blocks are panel launches on the CU-masked stream; a bad pivot in the third block."""
+    n = 5000
+    K = _spd_block(n, 11)
+    K[1300, 1300] = -5.0
+    A, Li, T = _sq(n), _sq(n, 0.0), _sq(n)
+    A.copy_(_dev(K))
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    gpu_ctx.potrf(A, Li, info, T)
+    assert int(info.item()) == 1301
