@@ -567,6 +567,14 @@ extern "C" {
 #endif
 const char* gpp_version(void) { return "gpp_hip 0.3 (gfx950, fp64 MFMA) src " GPP_SRC_HASH; }
 
+#ifdef GPP_PANEL_STAMP
+// probe build only: the whole ring of panel flag blocks, and the block the next launch will use
+int gpp_debug_panel_flags(gpp_handle_t h, int* out, int nints, int* next_slot) {
+  if (next_slot) *next_slot = h->panel_next % GPP_PANEL_RING;
+  return (int)hipMemcpy(out, h->panel_flags, (size_t)nints * sizeof(int), hipMemcpyDeviceToHost);
+}
+#endif
+
 int gpp_create(gpp_handle_t* out, int device) {
   if (!out) return -1;
   int ndev = 0;
@@ -599,8 +607,10 @@ int gpp_create(gpp_handle_t* out, int device) {
     h->ncu = 0;
   }
   // (allocated here, not lazily: a first use inside a stream capture could not allocate)
-  if (hipMalloc(reinterpret_cast<void**>(&h->panel_flags), GPP_PANEL_RING * gpp_panel_flag_bytes()) != hipSuccess) {
+  if (hipMalloc(reinterpret_cast<void**>(&h->panel_flags), GPP_PANEL_RING * gpp_panel_flag_bytes()) != hipSuccess ||
+      hipMemset(h->panel_flags, 0, GPP_PANEL_RING * gpp_panel_flag_bytes()) != hipSuccess) {
     (void)hipGetLastError();
+    if (h->panel_flags) (void)hipFree(h->panel_flags);
     h->panel_flags = nullptr;  // the leaf-step chain is used instead
   }
   *out = h;
@@ -701,7 +711,7 @@ int gpp_potrf_ws(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv,
     if (int r = check_mat(T, ldt, N, 7)) return r;
   }
   if (!info_dev) return -9;
-  GPP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int32_t), h->stream));
+  GPP_TRY(gpp_launch_zero_i32(h->stream, info_dev, 1));  // (a kernel, not a memset: see gpp_launch_zero_i32)
   Ctx c{h->stream, A, ld, Linv, ldi, info_dev};
   h->inv_N = N;
   h->inv_nblocks = 0;
@@ -1128,7 +1138,7 @@ int gpp_potrf_batched(gpp_handle_t h, double* A, int64_t N, int64_t ld, int64_t 
   if ((sA & 1) || (sLi & 1)) return -5;
   if (!info_dev) return -9;
   if (int r = check_batch(batch, 10)) return r;
-  GPP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int32_t) * (size_t)batch, h->stream));
+  GPP_TRY(gpp_launch_zero_i32(h->stream, info_dev, batch));
   Ctx c{h->stream, A, ld, Linv, ldi, info_dev};
   GPP_TRY(potrf_blk_batched(c, N, batch, sA, sLi));
   return 0;

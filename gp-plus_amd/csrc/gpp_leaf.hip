@@ -438,8 +438,12 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
 // gets onto the chip at some point: the grid never exceeds what the stream's CUs hold at one work-group each (72 KiB of LDS, ~350
 // registers per lane).
 // A wait gives up after ~1 s (then *info = 1 << 30 and every work-group leaves): a logic error must not hang the GPU.
+// The flag block is all zero between launches: the LAST work-group to leave clears it (a counter of finished work-groups), so
+// no memset precedes the launch — which also keeps memset nodes out of captured graphs (on this stack a replayed
+// hipMemsetAsync node of a few KiB came to write an address-like 8-byte pattern instead of zeros once the process had
+// synchronised the device: tools/_dbg notes in profiles/r03_potrf_experiments.txt).
 constexpr int PMAXC = 32;                         // leaves per launch the flag block is laid out for
-constexpr int PF_ABORT = 0, PF_LEAF = 1, PF_DIAG = 1 + PMAXC, PF_SOLVED = 1 + 2 * PMAXC;  // offsets (ints) in a flag block
+constexpr int PF_ABORT = 0, PF_DONE = 1, PF_LEAF = 2, PF_DIAG = 2 + PMAXC, PF_SOLVED = 2 + 2 * PMAXC;  // offsets (ints) in a flag block
 constexpr int PF_INTS = PF_SOLVED + PMAXC * PMAXC;
 constexpr int PBK = 16;                           // k rows per staged chunk
 constexpr int PLDA = 128 + 16, PLDB = 32 + 16;    // LDS row strides (doubles): two consecutive k rows fall in different bank halves
@@ -604,6 +608,14 @@ __device__ __forceinline__ bool panel_wait(int* flag, int target, int* flags, in
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       if (__hip_atomic_load(flags + PF_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || ++spins > (1 << 21)) {
         ok = 0;
+#ifdef GPP_PANEL_STAMP
+        if (spins > (1 << 21)) {  // the wait that gave up
+          flags[PF_INTS + 8] = (int)blockIdx.x;
+          flags[PF_INTS + 9] = (int)(flag - flags);
+          flags[PF_INTS + 10] = target;
+          flags[PF_INTS + 11] = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#endif
         __hip_atomic_store(flags + PF_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -627,12 +639,31 @@ __device__ __forceinline__ void panel_publish(int* flag, int tid) {
   }
 }
 
+// A work-group is done with the flag block; the last one of the launch to say so zeroes it for the next launch.
+__device__ __forceinline__ void panel_leave(int* flags, int tid) {
+  __shared__ int s_last;
+  __syncthreads();
+  if (tid == 0)
+    s_last = __hip_atomic_fetch_add(flags + PF_DONE, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (s_last)
+    for (int i = tid; i < PF_INTS; i += 256) __hip_atomic_store(flags + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
                                                            int64_t ldi, int n, int32_t* info, int row_offset, int* flags) {
   extern __shared__ __attribute__((aligned(16))) double img[];
   const int tid = threadIdx.x;
   const int C = (n + 127) >> 7, nl = n - 128 * (C - 1);  // leaves; rows of the last one (1 .. 128)
   auto ext = [&](int t) { return t == C - 1 ? nl : 128; };
+#ifdef GPP_PANEL_STAMP
+  if (blockIdx.x == 0 && tid == 0) {  // what did the launch find in its flag block?
+    flags[PF_INTS + 0] = __hip_atomic_load(flags + PF_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flags[PF_INTS + 1] = __hip_atomic_load(flags + PF_LEAF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flags[PF_INTS + 2] = __hip_atomic_load(flags + PF_LEAF + C - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    flags[PF_INTS + 3] += 1;  // launches on this block since the last memset that reached it
+  }
+#endif
   if (blockIdx.x == 0) {  // the chain
     for (int j = 0; j < C; ++j) {
       PSTAMP(4 * j);
@@ -645,6 +676,7 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
       PSTAMP(4 * j + 3);
     }
     if (tid == 0 && __hip_atomic_load(flags + PF_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) atomicCAS(info, 0, 1 << 30);
+    panel_leave(flags, tid);
     return;
   }
   const int W = (int)gridDim.x - 1, w = (int)blockIdx.x - 1, nf = 4 * (C - 1), ns = 2 * nf;
@@ -777,6 +809,7 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
     ok = panel_wait(flags + PF_LEAF + jj, 1, flags, tid);
     if (ok) inverse_row(jj, i, q);
   }
+  panel_leave(flags, tid);
 }
 
 }  // namespace
@@ -786,10 +819,22 @@ extern "C" int gpp_debug_panel_stamps(unsigned long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_panel_stamps), sizeof(unsigned long long) * 512);
 }
 #endif
+namespace {
+__global__ void gpp_zero_i32(int32_t* p, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+}  // namespace
+hipError_t gpp_launch_zero_i32(hipStream_t s, int32_t* p, int n) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gpp_zero_i32, dim3((unsigned)std::min(64, (n + 255) / 256)), dim3(256), 0, s, p, n);
+  return hipGetLastError();
+}
+
 size_t gpp_panel_flag_bytes() { return (((size_t)PF_INTS * sizeof(int) + 255) / 256) * 256; }
 int gpp_panel_max_leaves() { return PMAXC; }
 
-// n <= 128 * 32 rows (the last leaf may be ragged); `flags` = gpp_panel_flag_bytes() bytes of device memory that no other launch in flight uses;
+// n <= 128 * 32 rows (the last leaf may be ragged); `flags` = gpp_panel_flag_bytes() bytes of ZEROED device memory that no other launch
+// in flight uses (the launch leaves them zeroed again);
 // `max_wgs` = work-groups the stream's CUs hold at one each (the grid never exceeds it: see the kernel's comment).
 hipError_t gpp_launch_panel(hipStream_t s, double* A, int64_t lda, double* Linv, int64_t ldi, int n, int32_t* info,
                             int row_offset, int* flags, int max_wgs) {
@@ -810,8 +855,6 @@ hipError_t gpp_launch_panel(hipStream_t s, double* A, int64_t lda, double* Linv,
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
-  e = hipMemsetAsync(flags, 0, gpp_panel_flag_bytes(), s);
-  if (e != hipSuccess) return e;
   const int workers = C > 1 ? std::min(8 * (C - 1), max_wgs - 1) : 0;
   hipLaunchKernelGGL(gpp_panel_potrf_inv, dim3((unsigned)(1 + workers)), dim3(256), shmem, s, A, lda, Linv, ldi, n, info, row_offset,
                      flags);

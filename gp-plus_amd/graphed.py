@@ -71,7 +71,8 @@ class GraphedObjective:
         with torch.cuda.graph(self.graph):
             self.out = body()
         self._lib_scratch = self.gctx._ws  # (same reason: the library's scratch buffer is replaced when a larger one is needed)
-        self.replays = 0
+        self.replays = 0   # evaluations asked of the graph
+        self.declined = 0  # ... of which it handed back to the eager path (status != 0 or non-finite numbers)
 
     def evaluate(self, theta: np.ndarray) -> Optional[Tuple[float, np.ndarray]]:
         self.theta_host.copy_(torch.from_numpy(np.ascontiguousarray(theta, dtype=np.float64)))
@@ -85,5 +86,6 @@ class GraphedObjective:
         res = self.out_host.numpy()
         value, status = float(res[0]), res[-1]
         if status != 0.0 or not np.isfinite(value) or not np.all(np.isfinite(res[1:-1])):
+            self.declined += 1
             return None
         return value, res[1:-1].copy()

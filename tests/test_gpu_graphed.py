@@ -57,7 +57,7 @@ def test_replay_equals_eager_evaluation(kind):
     with settings.graphed_objective(False):
         eager = [_objective(m).fun(x) for x in points]
     got = [obj.fun(x) for x in points]
-    assert obj._graph is not None and obj._graph.replays == len(points)
+    assert obj._graph is not None and obj._graph.replays == len(points) and obj._graph.declined == 0
     for (fe, ge), (fg, gg) in zip(eager, got):
         # the same launches on the same data in the same order
         assert fg == pytest.approx(fe, rel=1e-13, abs=0)
@@ -68,6 +68,18 @@ def test_replay_equals_eager_evaluation(kind):
     again = [obj.fun(x) for x in reversed(points)]
     for (f1, g1), (f2, g2) in zip(reversed(got), again):
         assert f1 == f2 and np.array_equal(g1, g2)
+    # ... and eager evaluations of the same model, device-wide synchronisations and other GPU work in between change nothing:
+    # every replay is served by the graph (a replayed memset node that turned to garbage after a device synchronisation once
+    # made every later replay decline — the library now launches no memsets inside an evaluation)
+    with settings.graphed_objective(False):
+        other = _objective(m)
+    for k in range(12):
+        other.fun(points[k % len(points)])
+        torch.cuda.synchronize()
+        torch.randn(512, 512, device="cuda").sum().item()
+        f, g = obj.fun(points[k % len(points)])
+        assert f == got[k % len(points)][0] and np.array_equal(g, got[k % len(points)][1])
+    assert obj._graph.declined == 0
 
 
 def test_points_the_replay_cannot_serve_take_the_eager_path():
