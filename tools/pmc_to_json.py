@@ -32,7 +32,7 @@ def main():
            "(gfx950 correction); fabric-side counters, Infinity-Cache hits included")
     fp, wp = sums(fP, "FETCH_SIZE"), sums(wP, "WRITE_SIZE")
     fpt, wpt = sums(fPT, "FETCH_SIZE"), sums(wPT, "WRITE_SIZE")
-    lau = "gpp_gemm_f64<2, 64, 64, 1, 16, 2>"
+    lau = "gpp_gemm_f64<2, 64, 64, 1, 16, 2"  # (prefix: later template parameters follow)
     fl, wl = sums(fA, "FETCH_SIZE", lau), sums(wA, "WRITE_SIZE", lau)
     recs = {
         "potrf": ("gpp_potrf_ws stage (all launches of one factorisation at N=20000, incl. the covariance build's 1.6 GB)", fp, wp,
