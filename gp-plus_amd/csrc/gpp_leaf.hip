@@ -634,7 +634,12 @@ __device__ __forceinline__ void panel_publish(int* flag, int tid) {
   __builtin_amdgcn_s_waitcnt(0);  // this wave's stores have left the CU
   __syncthreads();
   if (tid == 0) {
+    // The explicit wait behind the fence is REQUIRED: for `fence release` (or a release atomic) hipcc 7.2 emits buffer_wbl2 here
+    // WITHOUT the s_waitcnt vmcnt(0) that has to separate the write-back from the atomic (its counter bookkeeping does not see
+    // the write-back as outstanding), so a flag could overtake the data it publishes — seen as one wrong factor in ~50 000
+    // launches, only beside a stream that saturates memory (tools/stress_panel.py; the ISA: buffer_wbl2 sc1, global_atomic_add)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_waitcnt(0);
     __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
