@@ -48,6 +48,19 @@ def _need(t: torch.Tensor, dtype, name: str) -> None:
         raise GppError(f"{name} must be contiguous")
 
 
+#: status word of a factorisation whose cooperative panel kernel gave up waiting for one of its own work-groups (gpp_leaf.hip:
+#: a wait is abandoned after ~1 s instead of hanging the GPU).  NOT "matrix not positive definite": adding jitter cannot help.
+INFO_PANEL_TIMEOUT = 1 << 30
+
+
+def check_status(info: int) -> None:
+    """Raise for the status words that are not LAPACK's "leading minor k is not positive definite"."""
+    if info >= INFO_PANEL_TIMEOUT:
+        raise GppError("gpp_potrf: the cooperative panel kernel timed out waiting for one of its work-groups (another kernel "
+                       "holding the stream's CUs for seconds, or a caller-supplied CU-masked stream with fewer CUs than the "
+                       "launch assumed); GPP_COOP_PANEL=0 selects the leaf-step factorisation")
+
+
 def square_buffer(n: int, device) -> torch.Tensor:
     """Uninitialised n x n fp64 matrix whose rows are padded to a multiple of 16 doubles (128-byte lines)."""
     ld = max(16, (n + 15) // 16 * 16)

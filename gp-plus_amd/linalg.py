@@ -21,7 +21,7 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from .backend import (KIND_RBF, OP_MLL_EVAL, UPLO_FULL, UPLO_UPPER, GppContext, get_context, square_buffer)
+from .backend import (KIND_RBF, OP_MLL_EVAL, UPLO_FULL, UPLO_UPPER, GppContext, check_status, get_context, square_buffer)
 from .errors import NanError, NotPSDError
 from . import settings
 
@@ -165,6 +165,7 @@ def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_spl
             after()
         ws.info_event.synchronize()
         info = int(ws.info_host[0])
+        check_status(info)
         if info == 0:
             if jit > 0:
                 warnings.warn(f"A not p.d., added jitter of {jit:.1e} to the diagonal", RuntimeWarning)

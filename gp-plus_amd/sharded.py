@@ -45,7 +45,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-from .backend import KIND_RBF, UPLO_FULL, GppContext, get_context, square_buffer
+from .backend import KIND_RBF, UPLO_FULL, GppContext, check_status, get_context, square_buffer
 from .errors import NanError, NotPSDError
 from . import settings
 
@@ -462,6 +462,7 @@ class ShardedMLLFunction(torch.autograd.Function):
         for jit in jitters:
             with _stage("shard_factor"):
                 info = _factor(gctx, comm, ws, Ud, wd, sd, td, grp, kind, d_split, jit)
+            check_status(info)
             if info == 0:
                 used = jit
                 break

@@ -231,3 +231,15 @@ def test_bench_watchdog_ends_a_hung_second_leg_on_every_rank():
     assert "hang" in rec["sharded"]["error"] and rec["n_gpus"] == 2
     assert took < 120, took
     assert "exitcode  : 3" in p.stderr or "exitcode: 3" in p.stderr or "(exitcode: 3)" in p.stderr, p.stderr[-1500:]
+
+
+def test_panel_timeout_status_is_not_reported_as_indefinite():
+    """info = 2**30 is the cooperative panel kernel giving up a wait (gpp_leaf.hip), not a failing leading minor: the host raises
+    GppError for it instead of retrying with jitter."""
+    from gpplus_amd._lib import GppError
+    from gpplus_amd.backend import INFO_PANEL_TIMEOUT, check_status
+
+    check_status(0)
+    check_status(251)  # LAPACK-style "leading minor 251": left to the jitter policy
+    with pytest.raises(GppError, match="timed out"):
+        check_status(INFO_PANEL_TIMEOUT)
