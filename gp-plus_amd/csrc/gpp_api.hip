@@ -369,7 +369,9 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   // WITHOUT a mask.  Measured: potrf 56.6 -> 55.5 ms at N = 20000, 173.3 -> 165 ms at 30000; the masked part is sized in
   // entries of the upper triangle (4.5e7 .. 9e7 equal; 2e8 loses the gain, 1.5e7 half of it).
   static const bool split_upd_on = !(getenv("GPP_SPLIT_UPD") && atoi(getenv("GPP_SPLIT_UPD")) == 0);  // experiment knob
-  static const int64_t split_elems = getenv("GPP_SPLIT_ELEMS") ? atol(getenv("GPP_SPLIT_ELEMS")) : 60000000;
+  // (round 3, with the panel kernel — the next diagonal block now takes 0.6 instead of ~1 ms: 3e7 against 6e7 entries, twice each:
+  //  potrf 15.28 vs 15.76 ms at N = 12288, 51.2-51.5 vs 51.5-51.8 at 20000, 154.0-154.5 vs 156.0-157.6 at 30000, 1139 vs 1144-1147 at 60000)
+  static const int64_t split_elems = getenv("GPP_SPLIT_ELEMS") ? atol(getenv("GPP_SPLIT_ELEMS")) : 30000000;
   const bool split_upd = split_upd_on && !border && h->cu_split == 1;
   hipStream_t cx = h->full_stream;
   struct { bool on; GemmArgs g; hipEvent_t rows_ready; int64_t rows_masked; } pend{false, GemmArgs{}, nullptr, 0};
