@@ -61,6 +61,14 @@ def _factor_batched(gctx: GppContext, ws: BatchedWorkspace, U, w, sf2, tau, grp,
     """Build + factor all elements; failing ones are retried with gpytorch's jitter schedule added to THEIR noise.
     Returns the boolean mask (B,) of elements that are positive definite in the end.  ``after()`` enqueues the rest of
     the evaluation before the host waits for the status words (one wait per attempt, covering the factorisation only)."""
+    if torch.cuda.is_current_stream_capturing():
+        # inside a HIP-graph capture (optim/mll_batched.py) nothing may wait for the host: ONE attempt without jitter; the status
+        # words stay on the device and the owner of the graph re-runs the step eagerly when any of them is not zero
+        gctx.kernel_build_batched(U, w, sf2, tau, grp, ws.A, kind=kind, d_split=d_split, uplo=UPLO_UPPER)
+        gctx.potrf_batched(ws.A, ws.Li, ws.info)
+        if after is not None:
+            after()
+        return ws.info == 0
     jitters = [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
     extra = torch.zeros(ws.B, 1, dtype=torch.float64, device=U.device)
     ok = None

@@ -117,6 +117,62 @@ class BatchedObjective:
         return -(mll + prior) / N
 
 
+class _GraphedLossAndGrad:
+    """loss (B,) and its gradients for the stacked parameters as ONE replayed HIP graph (``torch.cuda.CUDAGraph``).
+
+    A batched evaluation at the examples' sizes is ~1 ms of GPU work issued by ~1.7 ms of Python (vmap over the model's own
+    forward, ~40 library calls, autograd); the launches depend on shapes only.  The graph reads the stacked parameters (updated
+    in place by Adam) and the ``active`` mask (updated in place by the driver) and leaves loss and gradients in fixed buffers.
+    Nothing may wait for the host inside a capture, so the factorisation makes its no-jitter attempt only
+    (``batched._factor_batched``); ``step()`` returns False when any element's status is not zero and the driver then evaluates
+    that iteration eagerly (per-element jitter retries) — same numbers either way."""
+
+    def __init__(self, obj: BatchedObjective, params: List[torch.nn.Parameter], active: torch.Tensor):
+        from ..backend import get_context
+        from ..batched import get_batched_workspace
+
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("graph replay needs a GPU device")
+        self.params = params
+        N = int(obj.model.train_targets.shape[0])
+        self.ws = get_batched_workspace(get_context(dev), obj.B, N)  # held: dropped from the cache when another (B, N) is asked for
+        self.status_host = torch.zeros(obj.B, dtype=torch.int32).pin_memory()
+        self.done = torch.cuda.Event()
+
+        def body():
+            loss = obj.loss()
+            grads = torch.autograd.grad(torch.nansum(torch.where(active, loss, torch.zeros_like(loss))), params, allow_unused=True)
+            return loss.detach(), grads  # (None for a parameter the loss does not depend on, as ``backward`` leaves its .grad)
+
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.grads = body()
+        self._scratch = get_context(dev)._ws
+        self.replays = self.declined = 0
+
+    def step(self) -> bool:
+        self.ws.epoch += 1
+        self.graph.replay()
+        self.status_host.copy_(self.ws.info, non_blocking=True)
+        self.done.record()
+        self.done.synchronize()
+        self.replays += 1
+        if bool((self.status_host != 0).any()):
+            self.declined += 1
+            return False
+        for p, g in zip(self.params, self.grads):
+            p.grad = g
+        return True
+
+
 def fit_model_torch_batched(model, lr_default: float = 0.01, num_iter: int = 100, num_restarts: int = 0,
                             break_steps: int = 50, verbose: bool = False) -> Tuple[float, List[List[float]]]:
     """Drop-in for ``fit_model_torch`` (same return value) that advances all restarts together."""
@@ -136,10 +192,21 @@ def fit_model_torch_batched(model, lr_default: float = 0.01, num_iter: int = 100
     H = torch.full((num_iter, B), math.nan, dtype=torch.float64, device=dev)  # loss histories stay on the GPU
     last = torch.full((B,), math.inf, dtype=torch.float64, device=dev)
     done_at = num_iter
+    graphed = None
+    from .. import settings
+    if settings.graphed_objective.value() and dev.type == "cuda" and num_iter > 8:
+        try:
+            graphed = _GraphedLossAndGrad(obj, params, active)
+        except RuntimeError:  # (a capture the stack refuses: the eager loop below is the same computation)
+            graphed = None
+    fit_model_torch_batched.last_graph = graphed  # (for tests and tools: replays / declined counters)
     for j in range(num_iter):
-        opt.zero_grad(set_to_none=True)
-        loss = obj.loss()
-        torch.nansum(torch.where(active, loss, torch.zeros_like(loss))).backward()
+        if graphed is not None and graphed.step():
+            loss = graphed.loss
+        else:
+            opt.zero_grad(set_to_none=True)
+            loss = obj.loss()
+            torch.nansum(torch.where(active, loss, torch.zeros_like(loss))).backward()
         before = [p.detach().clone() for p in params]
         opt.step()
         with torch.no_grad():
@@ -161,7 +228,7 @@ def fit_model_torch_batched(model, lr_default: float = 0.01, num_iter: int = 100
                 stop_l = [bool((torch.mean(torch.Tensor(Hc[:break_steps, b_].tolist())) - Hc[break_steps, b_].item()) <= 0)
                           for b_ in range(B)]
                 stop = active & torch.tensor(stop_l, device=dev)
-                active = active & ~stop
+                active.copy_(active & ~stop)  # (in place: the replayed graph reads this very tensor)
                 if verbose:
                     print(f"iter {j}: best loss {float(last.min()):.4f}, {int(active.sum())} of {B} runs active")
                 if not bool(active.any()):

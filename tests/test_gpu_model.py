@@ -619,3 +619,40 @@ def test_fit_model_torch_batched_stops_runs_like_the_sequential_driver(gpu_ctx):
     assert [len(h) for h in hb] == [len(h) for h in hs]
     assert any(len(h) < 260 for h in hs)            # the scenario does exercise the early stop
     assert abs(fb - fs) <= 1e-8 * abs(fs)
+
+
+def test_batched_driver_replayed_graph_equals_the_eager_loop(gpu_ctx):
+    """``fit_model_torch_batched`` evaluates loss + gradients of every Adam step by replaying ONE captured HIP graph
+    (optim/mll_batched.py::_GraphedLossAndGrad); with ``settings.graphed_objective(False)`` the same launches are issued
+    eagerly.  Same histories bit for bit, same winner, every step served by the graph — also for a model whose latent map makes
+    the features trainable, and with runs stopping early (the ``active`` mask is an input of the graph)."""
+    from gpplus_amd import settings
+    from gpplus_amd.models import GP_Plus
+    from gpplus_amd.optim import fit_model_torch_batched
+    from gpplus_amd.utils import set_seed
+
+    def fit(on, kind):
+        set_seed(5)
+        if kind == "mixed":
+            m = _toy_model("mixed", n=200, seed=3)
+            kw = dict(num_restarts=3, num_iter=40)
+        else:
+            rng = np.random.default_rng(0)
+            X = rng.uniform(0, 1, (150, 3))
+            y = np.sin(3 * X[:, 0]) + X[:, 1] + 0.05 * rng.standard_normal(150)
+            m = GP_Plus(torch.tensor(X), torch.tensor(y), dtype=torch.float64, device="cuda")
+            kw = dict(num_restarts=5, num_iter=260, break_steps=50, lr_default=0.3)
+        set_seed(9)
+        with settings.graphed_objective(on):
+            f, h = fit_model_torch_batched(m, **kw)
+        g = fit_model_torch_batched.last_graph
+        return f, h, m.state_dict(), g
+
+    for kind in ("mixed", "early-stop"):
+        f1, h1, s1, g1 = fit(True, kind)
+        f0, h0, s0, g0 = fit(False, kind)
+        assert g0 is None and g1 is not None and g1.replays > 0 and g1.declined == 0
+        assert f1 == f0 and h1 == h0
+        for k, v in s0.items():
+            if torch.is_tensor(v):
+                assert torch.equal(s1[k], v), k
