@@ -556,6 +556,11 @@ def main():
         return dry_run(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the exact-GP path has no CPU fallback")
+    if args.share_gpu or args.streams > 1:
+        # several tenants on ONE GPU: two cooperative panel launches (one work-group per CU of the same 32-CU set) can each hold
+        # part of those CUs and wait for the rest — the library would detect that after ~1 s and the host would switch the panel
+        # off for the context (tools/tenant_probe.py); start without it instead
+        os.environ["GPP_COOP_PANEL"] = "0"
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)

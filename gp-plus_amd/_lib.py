@@ -27,6 +27,7 @@ _SIGNATURES = {
     "gpp_destroy": (c_int, [c_void_p]),
     "gpp_set_stream": (c_int, [c_void_p, c_void_p]),
     "gpp_internal_stream": (c_int, [c_void_p, c_int, POINTER(c_void_p)]),
+    "gpp_set_option": (c_int, [c_void_p, c_int, c_int]),
     "gpp_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int64, c_int64, c_int, c_int]),
     "gpp_set_workspace": (c_int, [c_void_p, c_void_p, c_size_t]),
     "gpp_kernel_build": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,

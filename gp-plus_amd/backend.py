@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import atexit
 import ctypes
+import os
 import threading
 import weakref
 from typing import Dict, Optional, Tuple
@@ -20,6 +21,7 @@ from ._lib import GppError, check
 
 KIND_RBF, KIND_MATERN32, KIND_MATERN52 = 0, 1, 2
 UPLO_FULL, UPLO_LOWER, UPLO_UPPER = 0, 1, 2
+OPT_COOP_PANEL, OPT_PANEL_FAULT = 1, 2  # gpp_set_option (include/gpp.h)
 OP_MLL_EVAL, OP_PREDICT = 0, 1
 #: the tile kernels stage at most this many feature columns (manifold + quantitative) per point in LDS (gpp_build.hip DMAX)
 MAX_FEATURES = 64
@@ -59,6 +61,22 @@ def check_status(info: int) -> None:
         raise GppError("gpp_potrf: the cooperative panel kernel timed out waiting for one of its work-groups (another kernel "
                        "holding the stream's CUs for seconds, or a caller-supplied CU-masked stream with fewer CUs than the "
                        "launch assumed); GPP_COOP_PANEL=0 selects the leaf-step factorisation")
+
+
+def panel_timed_out(ctx: "GppContext", info: int) -> bool:
+    """True when ``info`` is the cooperative panel's time-out status AND the context still had the panel switched on: the panel is
+    switched off for this context (the chain of leaf-step launches needs no co-residency) and the caller factors again.
+    Happens when several contexts — threads or processes — share one GPU and two panel launches each hold part of the same CUs."""
+    if info < INFO_PANEL_TIMEOUT:
+        return False
+    if not ctx.coop_panel:
+        check_status(info)  # cannot happen without a panel: report it
+    import warnings
+
+    warnings.warn("libgpp_hip: a cooperative panel launch timed out (another tenant of this GPU held part of its CUs); this "
+                  "context now factors with leaf-step launches", RuntimeWarning)
+    ctx.set_option(OPT_COOP_PANEL, 0)
+    return True
 
 
 def square_buffer(n: int, device) -> torch.Tensor:
@@ -102,12 +120,18 @@ class GppContext:
         with torch.cuda.device(self.index):
             check(self.lib.gpp_create(ctypes.byref(h), self.index), "gpp_create")
         self.h = h
+        self.coop_panel = os.environ.get("GPP_COOP_PANEL", "1") != "0"  # mirrors the handle's GPP_OPT_COOP_PANEL
         self._ws: Optional[torch.Tensor] = None
 
     # -- plumbing --------------------------------------------------------------------------------
     def _stream(self) -> None:
         s = torch.cuda.current_stream(self.index).cuda_stream
         check(self.lib.gpp_set_stream(self.h, ctypes.c_void_p(s)), "gpp_set_stream")
+
+    def set_option(self, option: int, value: int) -> None:
+        check(self.lib.gpp_set_option(self.h, int(option), int(value)), "gpp_set_option")
+        if option == OPT_COOP_PANEL:
+            self.coop_panel = bool(value)
 
     @_on_own_device
     def internal_streams(self):

@@ -162,9 +162,13 @@ inline bool panel_enabled() {
 }
 inline bool panel_fits(const gpp_handle_s* h, int64_t n) {
   static const int64_t nmax = getenv("GPP_PANEL_MAX_N") ? atol(getenv("GPP_PANEL_MAX_N")) : PANEL_MAX_N;  // experiment knob
-  return panel_enabled() && h->panel_flags && h->ncu >= 2 && n > 2 * NBLK && n <= nmax && (n + NBLK - 1) / NBLK <= gpp_panel_max_leaves();
+  return h->coop_panel && h->panel_flags && h->ncu >= 2 && n > 2 * NBLK && n <= nmax && (n + NBLK - 1) / NBLK <= gpp_panel_max_leaves();
 }
 hipError_t launch_panel(gpp_handle_s* h, const Ctx& c, int64_t o, int64_t n, int max_wgs) {
+  if (h->panel_fault) {  // test hook: behave like a launch whose wait timed out
+    h->panel_fault = 0;
+    return gpp_launch_fill_i32(c.s, c.info, 1, GPP_INFO_PANEL_TIMEOUT);
+  }
   int* fl = reinterpret_cast<int*>(h->panel_flags + (size_t)(h->panel_next % GPP_PANEL_RING) * gpp_panel_flag_bytes());
   ++h->panel_next;
   return gpp_launch_panel(c.s, c.A + o * c.ld + o, c.ld, c.Li + o * c.ldi + o, c.ldi, (int)n, c.info, (int)o, fl, max_wgs);
@@ -603,6 +607,8 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->inv_nblocks = 0;
   h->panel_flags = nullptr;
   h->panel_next = 0;
+  h->coop_panel = panel_enabled() ? 1 : 0;
+  h->panel_fault = 0;
   h->ncu = 0;
   if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->ncu < 2) {
     (void)hipGetLastError();
@@ -634,6 +640,14 @@ int gpp_destroy(gpp_handle_t h) {
 int gpp_set_stream(gpp_handle_t h, void* stream) {
   if (!h) return -1;
   h->stream = reinterpret_cast<hipStream_t>(stream);
+  return 0;
+}
+
+int gpp_set_option(gpp_handle_t h, int option, int value) {
+  if (!h) return -1;
+  if (option == GPP_OPT_COOP_PANEL) h->coop_panel = value ? 1 : 0;
+  else if (option == GPP_OPT_PANEL_FAULT) h->panel_fault = value ? 1 : 0;
+  else return -2;
   return 0;
 }
 
@@ -713,7 +727,7 @@ int gpp_potrf_ws(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv,
     if (int r = check_mat(T, ldt, N, 7)) return r;
   }
   if (!info_dev) return -9;
-  GPP_TRY(gpp_launch_zero_i32(h->stream, info_dev, 1));  // (a kernel, not a memset: see gpp_launch_zero_i32)
+  GPP_TRY(gpp_launch_fill_i32(h->stream, info_dev, 1, 0));  // (a kernel, not a memset: see gpp_launch_fill_i32)
   Ctx c{h->stream, A, ld, Linv, ldi, info_dev};
   h->inv_N = N;
   h->inv_nblocks = 0;
@@ -1140,7 +1154,7 @@ int gpp_potrf_batched(gpp_handle_t h, double* A, int64_t N, int64_t ld, int64_t 
   if ((sA & 1) || (sLi & 1)) return -5;
   if (!info_dev) return -9;
   if (int r = check_batch(batch, 10)) return r;
-  GPP_TRY(gpp_launch_zero_i32(h->stream, info_dev, batch));
+  GPP_TRY(gpp_launch_fill_i32(h->stream, info_dev, batch, 0));
   Ctx c{h->stream, A, ld, Linv, ldi, info_dev};
   GPP_TRY(potrf_blk_batched(c, N, batch, sA, sLi));
   return 0;

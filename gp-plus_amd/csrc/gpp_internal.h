@@ -30,6 +30,8 @@ struct gpp_handle_s {
   char* panel_flags;
   int panel_next;
   int ncu;                   // CUs of the device: a panel launch never has more work-groups than its stream's CUs hold
+  int coop_panel;            // GPP_OPT_COOP_PANEL
+  int panel_fault;           // GPP_OPT_PANEL_FAULT: the next panel launch only reports the time-out status (tests)
 };
 constexpr int GPP_PANEL_RING = 8;
 
@@ -128,9 +130,9 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a, int ba
 // A holds the UPPER factor (A = U^T U, i.e. L = U^T read/written with swapped indices); the n x n diagonal block of
 // Linv receives inv(L) in its lower triangle and the mirror image inv(L)^T in its strict upper triangle.
 // batch > 1: independent blocks at A + b*sA, Linv + b*sLi, info + b (one work-group each).
-// p[0..n) = 0 by a kernel.  Status words are cleared inside evaluations that may be captured into a HIP graph, and this stack's
+// p[0..n) = value by a kernel.  Status words are cleared inside evaluations that may be captured into a HIP graph, and this stack's
 // replayed memset nodes are not to be trusted (gpp_leaf.hip, the panel's flag block).
-hipError_t gpp_launch_zero_i32(hipStream_t s, int32_t* p, int n);
+hipError_t gpp_launch_fill_i32(hipStream_t s, int32_t* p, int n, int32_t value);
 // cooperative panel (gpp_leaf.hip): factor AND invert a diagonal block of n = 128 C rows in one launch
 size_t gpp_panel_flag_bytes();
 int gpp_panel_max_leaves();

@@ -20,6 +20,7 @@
 //   (4) trailing tiles acc(i,j) -= L(i,s) L(j,s)^T on the MFMA (one v_mfma_f64_16x16x4_f64 per 16x16x4 step).
 // Then the 8 diagonal tiles are inverted in parallel (2 per wave, lane per column) and the inverse is assembled by
 // pair merging at tile level (sizes 16, 32, 64): X21 = -X22 (L21 X11), MFMA again.
+#include "../../include/gpp.h"
 #include "gpp_internal.h"
 #include <algorithm>
 #include <atomic>
@@ -680,7 +681,7 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
       panel_publish(flags + PF_LEAF + j, tid);
       PSTAMP(4 * j + 3);
     }
-    if (tid == 0 && __hip_atomic_load(flags + PF_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) atomicCAS(info, 0, 1 << 30);
+    if (tid == 0 && __hip_atomic_load(flags + PF_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) atomicCAS(info, 0, GPP_INFO_PANEL_TIMEOUT);
     panel_leave(flags, tid);
     return;
   }
@@ -825,13 +826,13 @@ extern "C" int gpp_debug_panel_stamps(unsigned long long* host) {
 }
 #endif
 namespace {
-__global__ void gpp_zero_i32(int32_t* p, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+__global__ void gpp_fill_i32(int32_t* p, int n, int32_t value) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = value;
 }
 }  // namespace
-hipError_t gpp_launch_zero_i32(hipStream_t s, int32_t* p, int n) {
+hipError_t gpp_launch_fill_i32(hipStream_t s, int32_t* p, int n, int32_t value) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(gpp_zero_i32, dim3((unsigned)std::min(64, (n + 255) / 256)), dim3(256), 0, s, p, n);
+  hipLaunchKernelGGL(gpp_fill_i32, dim3((unsigned)std::min(64, (n + 255) / 256)), dim3(256), 0, s, p, n, value);
   return hipGetLastError();
 }
 

@@ -71,6 +71,7 @@ class GraphedObjective:
         with torch.cuda.graph(self.graph):
             self.out = body()
         self._lib_scratch = self.gctx._ws  # (same reason: the library's scratch buffer is replaced when a larger one is needed)
+        self.last_status = 0
         self.replays = 0   # evaluations asked of the graph
         self.declined = 0  # ... of which it handed back to the eager path (status != 0 or non-finite numbers)
 
@@ -85,6 +86,7 @@ class GraphedObjective:
         self.replays += 1
         res = self.out_host.numpy()
         value, status = float(res[0]), res[-1]
+        self.last_status = int(status) if np.isfinite(status) else -1
         if status != 0.0 or not np.isfinite(value) or not np.all(np.isfinite(res[1:-1])):
             self.declined += 1
             return None

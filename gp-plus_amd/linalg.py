@@ -21,7 +21,7 @@ from typing import Dict, Optional, Tuple
 
 import torch
 
-from .backend import (KIND_RBF, OP_MLL_EVAL, UPLO_FULL, UPLO_UPPER, GppContext, check_status, get_context, square_buffer)
+from .backend import (KIND_RBF, OP_MLL_EVAL, UPLO_FULL, UPLO_UPPER, GppContext, get_context, panel_timed_out, square_buffer)
 from .errors import NanError, NotPSDError
 from . import settings
 
@@ -138,7 +138,9 @@ def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_spl
             after()
         return 0.0
     jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
-    for jit in jitters:
+    attempts = list(jitters)
+    while attempts:
+        jit = attempts.pop(0)
         # The factorisation's launches (a DAG over the library's internal streams, ~1000 launches at N = 20000) run fastest
         # when they are enqueued while the device executes them, and measurably slower when they were parked in the
         # queues beforehand — N = 20000: potrf 55.7 ms when enqueued on an idle device, 58.0 when enqueued ~1 ms ahead
@@ -165,7 +167,9 @@ def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_spl
             after()
         ws.info_event.synchronize()
         info = int(ws.info_host[0])
-        check_status(info)
+        if panel_timed_out(ctx, info):
+            attempts.insert(0, jit)  # not a statement about the matrix: the same attempt again, without the panel
+            continue
         if info == 0:
             if jit > 0:
                 warnings.warn(f"A not p.d., added jitter of {jit:.1e} to the diagonal", RuntimeWarning)
@@ -379,13 +383,19 @@ def dense_log_prob(cov: torch.Tensor, diff: torch.Tensor) -> torch.Tensor:
     Li, T = square_buffer(N, dev), square_buffer(N, dev)
     info = torch.zeros(1, dtype=torch.int32, device=dev)
     jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
-    prev = 0.0
-    for jit in jitters:
-        if jit > 0:
+    prev, attempts, fresh = 0.0, list(jitters), True
+    while attempts:
+        jit = attempts.pop(0)
+        if not fresh:
             A.copy_(cov)
             A.diagonal().add_(jit)
+        fresh = False
         gctx.potrf(A, Li, info)
-        if int(info.item()) == 0:
+        status = int(info.item())
+        if panel_timed_out(gctx, status):
+            attempts.insert(0, jit)  # the same attempt again, without the cooperative panel
+            continue
+        if status == 0:
             break
         prev = jit
     else:

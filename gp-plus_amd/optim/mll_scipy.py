@@ -95,6 +95,11 @@ class MLLObjective:
             if res is not None:
                 return res
             # the factorisation failed without jitter (or the objective is not finite): this point goes the eager way
+            from ..backend import INFO_PANEL_TIMEOUT
+            if g.last_status >= INFO_PANEL_TIMEOUT:
+                # a cooperative panel launch inside the graph timed out (another tenant of this GPU): the eager evaluation below
+                # switches the panel off for this context, and the graph is captured again without it at the next call
+                self._graph = None
         old = self.model.state_dict()
         old.update(self.unpack_parameters(x))
         self.model.load_state_dict(old)

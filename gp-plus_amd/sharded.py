@@ -45,7 +45,7 @@ from typing import List, Optional, Tuple
 import torch
 import torch.distributed as dist
 
-from .backend import KIND_RBF, UPLO_FULL, GppContext, check_status, get_context, square_buffer
+from .backend import INFO_PANEL_TIMEOUT, KIND_RBF, UPLO_FULL, GppContext, get_context, panel_timed_out, square_buffer
 from .errors import NanError, NotPSDError
 from . import settings
 
@@ -459,10 +459,18 @@ class ShardedMLLFunction(torch.autograd.Function):
         jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
         used = None
         from .linalg import _stage
-        for jit in jitters:
+        attempts = list(jitters)
+        while attempts:
+            jit = attempts.pop(0)
             with _stage("shard_factor"):
                 info = _factor(gctx, comm, ws, Ud, wd, sd, td, grp, kind, d_split, jit)
-            check_status(info)
+            if info >= INFO_PANEL_TIMEOUT:
+                # (the status is the MAX over the ranks: every rank sees it and repeats the attempt; the rank whose panel gave up —
+                #  or every rank, it costs 1-2 % — switches the panel off)
+                if gctx.coop_panel:
+                    panel_timed_out(gctx, info)
+                attempts.insert(0, jit)
+                continue
             if info == 0:
                 used = jit
                 break

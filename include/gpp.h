@@ -65,6 +65,17 @@ int gpp_set_stream(gpp_handle_t h, void* stream);
  * factorisations with its own updates (the sharded evaluation, gp-plus_amd/sharded.py) enqueues on them through
  * gpp_set_stream.  *out receives a hipStream_t. */
 int gpp_internal_stream(gpp_handle_t h, int which, void** out);
+/* Per-handle switches.  GPP_OPT_COOP_PANEL (default 1, or 0 with GPP_COOP_PANEL=0 in the environment): factor diagonal blocks and
+ * small matrices with the cooperative panel kernel, whose work-groups wait for each other on the device and therefore must all be
+ * resident together.  When several handles (threads or processes) share one GPU two such launches can each hold part of the same
+ * CUs; a wait inside the kernel then gives up after ~1 s and the factorisation reports *info = GPP_INFO_PANEL_TIMEOUT — the
+ * caller switches the option off and factors again (gp-plus_amd/linalg.py does).  GPP_OPT_PANEL_FAULT (default 0): the NEXT
+ * panel launch reports that time-out without running (one shot; for tests of the caller's recovery).
+ * No reference counterpart: the reference's factorisation is torch.linalg.cholesky_ex behind gpytorch (optim/mll_torch.py:116). */
+#define GPP_OPT_COOP_PANEL 1
+#define GPP_OPT_PANEL_FAULT 2
+#define GPP_INFO_PANEL_TIMEOUT (1 << 30)
+int gpp_set_option(gpp_handle_t h, int option, int value);
 size_t gpp_workspace_bytes(gpp_handle_t h, int op, int64_t N, int64_t M, int D, int S);
 int gpp_set_workspace(gpp_handle_t h, void* ws, size_t bytes);
 

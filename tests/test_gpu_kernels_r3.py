@@ -349,3 +349,59 @@ def test_panel_inside_the_lookahead_reports_the_failing_minor(gpu_ctx):
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
     gpu_ctx.potrf(A, Li, info, T)
     assert int(info.item()) == 1301
+
+
+def test_panel_timeout_is_recovered_by_the_host(gpu_ctx):
+    """GPP_OPT_PANEL_FAULT makes the next panel launch report the time-out status (what a wait inside the kernel reports after ~1 s
+    when another tenant of the GPU holds part of its CUs).  The C ABI returns it in ``info``; ``linalg`` switches the panel off for
+    the context, factors again with leaf-step launches and the evaluation comes out as without the incident."""
+    import warnings
+
+    from gpplus_amd.backend import INFO_PANEL_TIMEOUT, OPT_COOP_PANEL, OPT_PANEL_FAULT
+    from gpplus_amd.models import GP_Plus
+
+    if not gpu_ctx.coop_panel:
+        pytest.skip("the cooperative panel is switched off (GPP_COOP_PANEL=0)")
+    n = 1000
+    K = _spd_block(n, 5)
+    A, Li = _sq(n), _sq(n, 0.0)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    A.copy_(_dev(K))
+    gpu_ctx.set_option(OPT_PANEL_FAULT, 1)
+    gpu_ctx.potrf(A, Li, info)
+    assert int(info.item()) == INFO_PANEL_TIMEOUT
+    A.copy_(_dev(K))
+    gpu_ctx.potrf(A, Li, info)  # one shot: the next launch is a real one
+    assert int(info.item()) == 0
+    # through the model: same loss and gradients as a clean evaluation, one warning, the panel off afterwards
+    rng = np.random.default_rng(1)
+    X = rng.uniform(size=(600, 4))
+    y = np.sin(X.sum(1))
+    m = GP_Plus(torch.tensor(X), torch.tensor(y), dtype=torch.float64, device=torch.device("cuda:0"))
+    from gpplus_amd.gpcore import ExactMarginalLogLikelihood
+
+    mll = ExactMarginalLogLikelihood(m.likelihood, m)
+
+    def evaluate():
+        m.zero_grad()
+        loss = -mll(m(*m.train_inputs), m.train_targets)
+        loss.backward()
+        return loss.item(), [p.grad.clone() for p in m.parameters() if p.grad is not None]
+
+    m.train()
+    clean = evaluate()
+    try:
+        gpu_ctx.set_option(OPT_PANEL_FAULT, 1)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            hit = evaluate()
+        assert any("panel launch timed out" in str(x.message) for x in w)
+        assert not gpu_ctx.coop_panel
+        # (the retry factors with leaf-step launches: equal to rounding, not bitwise)
+        assert hit[0] == pytest.approx(clean[0], rel=1e-12)
+        for a, b in zip(hit[1], clean[1]):
+            torch.testing.assert_close(a, b, rtol=1e-9, atol=1e-12)
+    finally:
+        gpu_ctx.set_option(OPT_PANEL_FAULT, 0)
+        gpu_ctx.set_option(OPT_COOP_PANEL, 1)
+    assert gpu_ctx.coop_panel

@@ -18,7 +18,9 @@ KEEP=$(awk '/== repeatability/{p=1} p' $P/r03_restarts_and_sharded_1rank.txt 2>/
 (echo "Sharded evaluation with ONE rank (the algorithm without communication), tools/run_sharded.py; round 3 (back-substitution, head/tail row solves)"
  grep "^N=" $R/sharded_1rank_20000.txt; grep "^N=" $R/sharded_1rank_60000.txt
  echo; echo "== dispatches >= 100 us of one evaluation at N = 20000 (rocprofv3 --kernel-trace, tools/trace_window.py)"; cat $R/trace_sharded_big_kernels.txt
- echo; echo "== restart batching (tools/bench_restarts.py)"; grep -v amdgpu $R/restarts.txt
+ echo; echo "== restart batching (tools/bench_restarts.py; the batched driver replays loss + gradients of each Adam step as one HIP graph,"
+ echo "   the 'batched evaluation' lines time BatchedObjective.loss() + backward issued eagerly: replayed, a step is 0.42 ms at N = 100, B = 5;"
+ echo "   0.75 ms at N = 500, B = 5; 1.42 ms at N = 500, B = 65)"; grep -v amdgpu $R/restarts.txt
  echo; echo "$KEEP") > $P/r03_restarts_and_sharded_1rank.txt.new && mv $P/r03_restarts_and_sharded_1rank.txt.new $P/r03_restarts_and_sharded_1rank.txt
 grep -v "amdgpu\|Warning" $R/configs.txt > $P/r03_configs_C1_C5_single_gpu.txt
 (echo "One trailing-update launch C(upper) -= A^T A (gpp_gemm_f64<2,64,64,0,16,2>), isolated launches: rate vs tile count (tools/small_update_probe.py)"
