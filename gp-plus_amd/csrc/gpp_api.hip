@@ -351,7 +351,11 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   HIP_TRY(hipStreamWaitEvent(cp.s, ev, 0));
   HIP_TRY(hipStreamWaitEvent(cu.s, ev, 0));
   const char* env_nb = getenv("GPP_LOOKAHEAD_NB");  // experiment knob: "big,small,threshold"
-  long nb_big = NB, nb_small = NB / 2, nb_thresh = 6 * NB;  // measured best at N = 20000 (70.6 ms vs 71.7 for 1024 flat)
+  // Round 1 measured 1024 above / 512 below 6144 remaining rows best (70.6 vs 71.7 ms for 1024 flat at N = 20000); with the panel
+  // kernel a 1024-row block costs 0.58 ms where two 512-row blocks cost 2 x (0.29 + 0.07 ms hand-off), and 1024 flat wins (means
+  // of 3: potrf 15.50 -> 15.22 ms at N = 12288, 25.27 -> 24.87 at 15000, 51.84 -> 51.46 at 20000, 155.3 -> 155.3 at 30000).
+  // (The bordering range chooses its own height below.)
+  long nb_big = NB, nb_small = NB, nb_thresh = 0;
   if (env_nb) sscanf(env_nb, "%ld,%ld,%ld", &nb_big, &nb_small, &nb_thresh);
   // bordering pays while the factorisation is bound by its chain of diagonal blocks (measured: 9.6 -> 7.8 ms per
   // evaluation at N = 6144, 16.3 -> 14.0 at 8192, 26.5 -> 24.4 at 10000, a tie at 12288, 147 -> 156 at 20000 where the
@@ -384,7 +388,10 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   static const bool defer_be = !(getenv("GPP_DEFER_BE") && atoi(getenv("GPP_DEFER_BE")) == 0);  // experiment knob
   // with bordering the block height matters little; one height per N measured best (512 up to ~7000 rows: 7.5 vs 8.3 ms per
   // evaluation at 6144; 1024 above: 23.3 vs 24.2 ms at 10000)
-  if (border && !env_nb) nb_thresh = (N <= 7168) ? N + 1 : 0;
+  if (border && !env_nb) {
+    nb_small = NB / 2;
+    nb_thresh = (N <= 7168) ? N + 1 : 0;
+  }
   for (int64_t o = 0, nb = 0; o < N; o += nb) {
     // tall block rows while the trailing update is long enough to hide their diagonal factorisation, shorter after
     const int64_t want = (N - o >= nb_thresh) ? nb_big : nb_small;
