@@ -199,7 +199,7 @@ def fit_model_torch_batched(model, lr_default: float = 0.01, num_iter: int = 100
             graphed = _GraphedLossAndGrad(obj, params, active)
         except RuntimeError:  # (a capture the stack refuses: the eager loop below is the same computation)
             graphed = None
-    fit_model_torch_batched.last_graph = graphed  # (for tests and tools: replays / declined counters)
+    fit_model_torch_batched.last_graph = None  # (for tests and tools: the finished fit's counters, set below)
     for j in range(num_iter):
         if graphed is not None and graphed.step():
             loss = graphed.loss
@@ -234,6 +234,11 @@ def fit_model_torch_batched(model, lr_default: float = 0.01, num_iter: int = 100
                 if not bool(active.any()):
                     done_at = j + 1
                     break
+    if graphed is not None:
+        # only the counters outlive the fit: the graph and its private memory pool are released here
+        from types import SimpleNamespace
+        fit_model_torch_batched.last_graph = SimpleNamespace(replays=graphed.replays, declined=graphed.declined)
+        graphed = None
     Hc = H[:done_at].cpu()
     hist = [[v for v in Hc[:, b_].tolist() if not math.isnan(v)] for b_ in range(B)]
     best = int(torch.argmin(last).item())
