@@ -243,3 +243,37 @@ def test_panel_timeout_status_is_not_reported_as_indefinite():
     check_status(251)  # LAPACK-style "leading minor 251": left to the jitter policy
     with pytest.raises(GppError, match="timed out"):
         check_status(INFO_PANEL_TIMEOUT)
+
+
+def test_panel_hand_off_waits_for_the_write_back_before_raising_a_flag():
+    """gpp_panel_potrf_inv publishes data to other work-groups with  fence(release, agent) + flag atomic.  hipcc 7.2 lowered that to
+    ``buffer_wbl2 sc1`` followed DIRECTLY by the ``global_atomic_add`` (no ``s_waitcnt vmcnt(0)`` in between), so a flag could become
+    visible before the data: one wrong factor in ~50 000 launches under memory pressure.  The source now carries an explicit wait;
+    this test reads the ISA hipcc produces for gfx950 and fails if any L2 write-back is again followed by an atomic without the
+    wait (whatever future compiler or edit causes it)."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(ROOT, "gp-plus_amd", "csrc", "gpp_leaf.hip")
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, "leaf.s")
+        p = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", src, "-o", out],
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [l.strip() for l in open(out) if l.strip() and not l.strip().startswith((";", ".", "//"))]
+    instr = [l for l in lines if re.match(r"^[a-z_0-9]+(\s|$)", l)]
+    wb = [i for i, l in enumerate(instr) if l.startswith("buffer_wbl2")]
+    assert wb, "no L2 write-back found: has the panel kernel lost its release fences?"
+    for i in wb:
+        for l in instr[i + 1:i + 40]:
+            if l.startswith("s_waitcnt") and "vmcnt(0)" in l:
+                break
+            assert not l.startswith(("global_atomic", "flat_atomic", "buffer_atomic")), \
+                "an atomic follows buffer_wbl2 without s_waitcnt vmcnt(0): " + " | ".join(instr[i:i + 12])
+        else:
+            raise AssertionError("no s_waitcnt vmcnt(0) within 40 instructions of a buffer_wbl2")
