@@ -74,6 +74,21 @@ def make_config(name: str, n: int = None):
     raise ValueError(name)
 
 
+def make_test_points(name: str, X: torch.Tensor, m: int = 256) -> torch.Tensor:
+    """``m`` seeded prediction points for config ``name``: training rows (seeded choice) whose quantitative columns are
+    displaced by Gaussian steps of 0.02 ... 1.0 standard deviations (the step size cycles over five values), so the
+    predictive variances run from noise-dominated to near-prior; categorical / source columns keep their levels.
+    Shared by tests/golden/make_fullsize.py and the full-size parity test (models/gpregression.py:122-149)."""
+    qual = {"C3": (0, 5), "C4": (10,)}.get(name, ())
+    rng = np.random.default_rng(1234 + sum(map(ord, name)))
+    rows = rng.choice(X.shape[0], size=m, replace=False)
+    Xt = X[torch.as_tensor(rows)].clone().double()
+    step = np.array([0.02, 0.1, 0.3, 0.6, 1.0])[np.arange(m) % 5][:, None] * rng.standard_normal((m, X.shape[1]))
+    for c in qual:
+        step[:, c] = 0.0
+    return Xt + torch.as_tensor(step)
+
+
 def apply_theta(model, theta) -> None:
     """Load the evaluation point into a ``GP_Plus`` (keys are the reference's state_dict names)."""
     sd = model.state_dict()

@@ -488,27 +488,43 @@ class OracleGP:
 
     # ---- prediction --------------------------------------------------------------------------------
     @torch.no_grad()
-    def predict(self, xtest, return_std: bool = True, include_noise: bool = True):
-        """models/gpregression.py:122-149 + [3P] exact prediction strategy on the joint forward over cat([train, test])."""
+    def _predict_parts(self, xtest):
+        """models/gpregression.py:126-134 + [3P] exact prediction strategy on the joint forward over cat([train, test]):
+        scaled-space mean, noise-free variance (before the clamp) and the test points' own noise, from ONE factorisation."""
         xtest = torch.as_tensor(xtest, dtype=DT)
         xall = torch.cat([self.train_x, xtest], dim=0)
         m, K = self.forward(xall)
         n = self.N
         Ky = K[:n, :n] + torch.diag(self.noise_vector(self.train_x))
         L, _ = psd_safe_cholesky(Ky)
+        del Ky
         r = (self.y_sc - m[:n]).unsqueeze(-1)
         alpha = torch.cholesky_solve(r, L).squeeze(-1)
         Ksn = K[n:, :n]
         mean = m[n:] + Ksn @ alpha
+        V = torch.linalg.solve_triangular(L, Ksn.T, upper=False)
+        var = torch.diagonal(K[n:, n:]) - (V * V).sum(0)
+        return mean, var, self.noise_vector(xtest)
+
+    @torch.no_grad()
+    def predict(self, xtest, return_std: bool = True, include_noise: bool = True):
+        """models/gpregression.py:122-149 (un-scaling :142-147; [3P] settings.min_variance clamp, double: 1e-10)."""
+        mean, var, noise = self._predict_parts(xtest)
         out_mean = self.y_min + self.y_std * mean
         if not return_std:
             return out_mean
-        V = torch.linalg.solve_triangular(L, Ksn.T, upper=False)
-        var = torch.diagonal(K[n:, n:]) - (V * V).sum(0)
         if include_noise:
-            var = var + self.noise_vector(xtest)
+            var = var + noise
         var = var.clamp_min(1e-10)  # [3P] settings.min_variance (double)
         return out_mean, var.sqrt() * self.y_std
+
+    @torch.no_grad()
+    def predict_all(self, xtest):
+        """(mean, std incl. noise, std without noise) of ``predict`` from one factorisation (fixture generation at the
+        BASELINE sizes, tests/golden/make_fullsize.py)."""
+        mean, var, noise = self._predict_parts(xtest)
+        return (self.y_min + self.y_std * mean, (var + noise).clamp_min(1e-10).sqrt() * self.y_std,
+                var.clamp_min(1e-10).sqrt() * self.y_std)
 
     @torch.no_grad()
     def evaluation(self, xtest, ytest, alpha: float = 0.05):

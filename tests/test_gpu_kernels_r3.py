@@ -228,7 +228,7 @@ def test_exp_for_nonpositive_arguments_is_accurate_to_a_few_ulp(gpu_ctx):
     assert den < 1e-307
 
 
-@pytest.mark.parametrize("n,m", [(600, 130), (1000, 1), (257, 700)])
+@pytest.mark.parametrize("n,m", [(600, 130), (1000, 1), (257, 700), (5000, 3000)])
 def test_predict_tn_matches_scipy_and_the_nt_form(gpu_ctx, n, m):
     """gpp_predict_tn (transposed cross block, V = Kns^T L^-T as a TN product against the mirror, mean = V z) against scipy and
     against gpp_predict on the same factor; the mean-only form of gpp_predict (V = NULL) as well."""
@@ -238,10 +238,14 @@ def test_predict_tn_matches_scipy_and_the_nt_form(gpu_ctx, n, m):
     rng = np.random.default_rng(n + m)
     U = rng.standard_normal((n, d))
     w = rng.uniform(0.05, 0.5, d)
-    K = 0.8 * np.exp(-((U[:, None, :] - U[None, :, :]) ** 2 * w).sum(-1)) + 1e-3 * np.eye(n)
+    def sqd(P, Q):  # weighted squared distances without the (p, q, d) intermediate (n = 5000: 1.4 GB)
+        Pw, Qw = P * np.sqrt(w), Q * np.sqrt(w)
+        return np.maximum((Pw ** 2).sum(1)[:, None] + (Qw ** 2).sum(1)[None, :] - 2.0 * Pw @ Qw.T, 0.0)
+
+    K = 0.8 * np.exp(-sqd(U, U)) + 1e-3 * np.eye(n)
     Us = rng.standard_normal((m, d))
     r = rng.standard_normal(n)
-    Ks = 0.8 * np.exp(-((Us[:, None, :] - U[None, :, :]) ** 2 * w).sum(-1))
+    Ks = 0.8 * np.exp(-sqd(Us, U))
     cf = sla.cho_factor(K, lower=True)
     alpha = sla.cho_solve(cf, r)
     mean = Ks @ alpha
@@ -250,8 +254,10 @@ def test_predict_tn_matches_scipy_and_the_nt_form(gpu_ctx, n, m):
     A, Li, T = _sq(n), _sq(n), _sq(n)
     A.copy_(_dev(K))
     info = torch.zeros(1, dtype=torch.int32, device="cuda")
-    gpu_ctx.potrf(A, Li, info)
+    # n >= 3840 with the scratch: the look-ahead driver + cooperative panel + bordered inverse, the path every config but C1 takes
+    gpu_ctx.potrf(A, Li, info, T if n >= 3840 else None)
     gpu_ctx.trtri(A, Li, T)
+    assert int(info.item()) == 0
     z = torch.empty(n, dtype=torch.float64, device="cuda")
     out3 = torch.empty(3, dtype=torch.float64, device="cuda")
     gpu_ctx.mll_reduce(A, Li, _dev(r), z, out3)

@@ -88,10 +88,11 @@ def test_predict_matches_golden(gpu_ctx, fixture, tag, kw):
     np.testing.assert_allclose(only_mean.cpu().numpy(), mean.cpu().numpy(), rtol=0, atol=0)
 
 
-@pytest.mark.parametrize("n,d,seed", [(64, 3, 0), (777, 8, 1), (2048, 8, 2), (4097, 5, 3), (6200, 8, 4)])
+@pytest.mark.parametrize("n,d,seed", [(64, 3, 0), (777, 8, 1), (2048, 8, 2), (4097, 5, 3), (6200, 8, 4), (12288, 6, 5)])
 def test_against_oracle_on_fresh_inputs(gpu_ctx, n, d, seed):
-    """Same seeded inputs through the oracle (CPU) and the product (GPU), incl. a non-multiple-of-tile size and the sizes
-    whose inverse is built by bordering inside the look-ahead factorisation (n >= 4096)."""
+    """Same seeded inputs through the oracle (CPU) and the product (GPU), incl. a non-multiple-of-tile size, the sizes
+    whose inverse is built by bordering inside the look-ahead factorisation (n >= 4096) and one above that range (12 288:
+    look-ahead without bordering); loss, every gradient AND the predictions (models/gpregression.py:122-149) at each size."""
     from oracle.gp_oracle import OracleGP
     from gpplus_amd.models import GP_Plus
 
@@ -114,6 +115,15 @@ def test_against_oracle_on_fresh_inputs(gpu_ctx, n, d, seed):
     for k, g in go.items():
         gref = g.numpy().reshape(grads[k].shape)
         np.testing.assert_allclose(grads[k], gref, rtol=RTOL_MLL, atol=RTOL_MLL * max(np.abs(gref).max(), 1e-12), err_msg=k)
+    # predictions from the same factor path: points at 0.05 ... 1 standard deviations from training rows
+    Xt = X[rng.choice(n, 96, replace=False)] + np.array([0.05, 0.3, 1.0])[np.arange(96) % 3][:, None] * rng.standard_normal((96, d))
+    om, osd, osd0 = o.predict_all(Xt)
+    m.eval()
+    mean, std = m.predict(torch.tensor(Xt), return_std=True, include_noise=True)
+    _, std0 = m.predict(torch.tensor(Xt), return_std=True, include_noise=False)
+    np.testing.assert_allclose(mean.cpu().numpy(), om.numpy(), rtol=RTOL_PRED, atol=1e-7)
+    np.testing.assert_allclose(std.cpu().numpy(), osd.numpy(), rtol=RTOL_PRED, atol=1e-7)
+    np.testing.assert_allclose(std0.cpu().numpy(), osd0.numpy(), rtol=RTOL_PRED, atol=1e-7)
 
 
 def test_rbfkernel_mode_and_fixed_noise(gpu_ctx):

@@ -275,6 +275,18 @@ def test_full_size_configs_match_the_oracle(gpu_ctx, cfg):
     ref = float(fx["loss"])
     assert abs(loss - ref) <= RTOL * abs(ref), (loss, ref)
     _assert_grads(grads, {k[len("grad::"):]: v for k, v in fx.items() if k.startswith("grad::")})
+    # a13 at the BASELINE size (models/gpregression.py:122-149): predictive mean / std with and without noise at 256 seeded
+    # test points, on the factor path N >= 3840 takes (look-ahead + cooperative panel [+ bordered inverse], gpp_predict_tn)
+    from gpplus_amd.test_functions.baseline_configs import make_test_points
+    Xt = make_test_points(cfg, X)
+    np.testing.assert_allclose(np.array([float(Xt.sum()), float((Xt ** 2).sum())]), fx["test_checksum"], rtol=1e-12)
+    m.eval()
+    mean, std = m.predict(Xt, return_std=True, include_noise=True)
+    np.testing.assert_allclose(mean.cpu().numpy(), fx["pred_mean"], rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(std.cpu().numpy(), fx["pred_std"], rtol=1e-4, atol=1e-8)
+    _, std0 = m.predict(Xt, return_std=True, include_noise=False)
+    np.testing.assert_allclose(std0.cpu().numpy(), fx["pred_std_nonoise"], rtol=1e-4, atol=1e-7)
+    np.testing.assert_array_equal(m.predict(Xt, return_std=False).cpu().numpy(), mean.cpu().numpy())
     del m
     import gpplus_amd.linalg as L
     L._workspaces.clear()
