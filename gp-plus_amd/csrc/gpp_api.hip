@@ -171,7 +171,8 @@ hipError_t launch_panel(gpp_handle_s* h, const Ctx& c, int64_t o, int64_t n, int
   }
   int* fl = reinterpret_cast<int*>(h->panel_flags + (size_t)(h->panel_next % GPP_PANEL_RING) * gpp_panel_flag_bytes());
   ++h->panel_next;
-  return gpp_launch_panel(c.s, c.A + o * c.ld + o, c.ld, c.Li + o * c.ldi + o, c.ldi, (int)n, c.info, (int)o, fl, max_wgs);
+  return gpp_launch_panel(c.s, c.A + o * c.ld + o, c.ld, c.Li + o * c.ldi + o, c.ldi, (int)n, c.info, (int)o, fl, max_wgs,
+                          h->panel_timeout_ms);
 }
 
 // ---- triangular inverse by pair merging -------------------------------------------------------------------------
@@ -616,6 +617,7 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->panel_next = 0;
   h->coop_panel = panel_enabled() ? 1 : 0;
   h->panel_fault = 0;
+  h->panel_timeout_ms = 500;
   h->ncu = 0;
   if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->ncu < 2) {
     (void)hipGetLastError();
@@ -654,7 +656,10 @@ int gpp_set_option(gpp_handle_t h, int option, int value) {
   if (!h) return -1;
   if (option == GPP_OPT_COOP_PANEL) h->coop_panel = value ? 1 : 0;
   else if (option == GPP_OPT_PANEL_FAULT) h->panel_fault = value ? 1 : 0;
-  else return -2;
+  else if (option == GPP_OPT_PANEL_TIMEOUT_MS) {
+    if (value < 1 || value > 60000) return -3;
+    h->panel_timeout_ms = value;
+  } else return -2;
   return 0;
 }
 

@@ -25,13 +25,15 @@ struct gpp_handle_s {
   int64_t inv_N;             // N of that factorisation (0: nothing recorded)
   int inv_nblocks;
   int64_t inv_o[128], inv_n[128];
-  // flag blocks of the cooperative panel launches (gpp_leaf.hip), used round-robin: a block is zeroed in stream order right
-  // before its launch, and no more than PANEL_RING panels are ever in flight on one handle
+  // flag blocks of the cooperative panel launches (gpp_leaf.hip), used round-robin: a launch finds its block zeroed and the last
+  // work-group to leave zeroes it again; no more than PANEL_RING panels are ever in flight on one handle, and a handle is used from
+  // ONE stream at a time (a captured graph keeps the slot it was captured with: replay it on the stream the handle works on)
   char* panel_flags;
   int panel_next;
   int ncu;                   // CUs of the device: a panel launch never has more work-groups than its stream's CUs hold
   int coop_panel;            // GPP_OPT_COOP_PANEL
   int panel_fault;           // GPP_OPT_PANEL_FAULT: the next panel launch only reports the time-out status (tests)
+  int panel_timeout_ms;      // GPP_OPT_PANEL_TIMEOUT_MS: budget of a wait inside the panel kernel (100 MHz constant clock)
 };
 constexpr int GPP_PANEL_RING = 8;
 
@@ -137,7 +139,7 @@ hipError_t gpp_launch_fill_i32(hipStream_t s, int32_t* p, int n, int32_t value);
 size_t gpp_panel_flag_bytes();
 int gpp_panel_max_leaves();
 hipError_t gpp_launch_panel(hipStream_t s, double* A, int64_t lda, double* Linv, int64_t ldi, int n, int32_t* info, int row_offset,
-                            int* flags, int max_wgs);
+                            int* flags, int max_wgs, int timeout_ms);
 hipError_t gpp_launch_leaf(hipStream_t s, double* A, int64_t lda, double* Linv, int64_t ldi, int n, int32_t* info,
                            int row_offset, int batch = 1, int64_t sA = 0, int64_t sLi = 0);
 

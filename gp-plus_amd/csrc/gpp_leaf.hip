@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
 // of a fixed global order (step j: S, then U, then the inverse row j-1) — no cycles, provided every work-group of the launch
 // gets onto the chip at some point: the grid never exceeds what the stream's CUs hold at one work-group each (72 KiB of LDS, ~350
 // registers per lane).
-// A wait gives up after ~1 s (then *info = 1 << 30 and every work-group leaves): a logic error must not hang the GPU.
+// A wait gives up after `budget` ticks of the 100 MHz constant clock (default 0.5 s; then *info = 2^30 + the milliseconds waited and
+// every work-group leaves): a logic error or a co-tenant must not hang the GPU.
 // The flag block is all zero between launches: the LAST work-group to leave clears it (a counter of finished work-groups), so
 // no memset precedes the launch — which also keeps memset nodes out of captured graphs (on this stack a replayed
 // hipMemsetAsync node of a few KiB came to write an address-like 8-byte pattern instead of zeros once the process had
@@ -601,23 +602,35 @@ __device__ __forceinline__ void strip_zero(StripAcc& acc) {
 }
 
 // Wait until *flag >= target (thread 0 polls; everybody learns the outcome).  false: the launch is being abandoned.
-__device__ __forceinline__ bool panel_wait(int* flag, int target, int* flags, int tid) {
+// The wait is bounded by the 100 MHz constant clock (s_memrealtime), not by a poll count: `budget` ticks of 10 ns, whatever the
+// core clock and however slow a poll is beside a kernel that saturates memory.  The wait that gives up leaves 1 + the milliseconds
+// it waited in PF_ABORT; the chain work-group reports them in the low bits of the status word.
+__device__ __forceinline__ bool panel_wait(int* flag, int target, int* flags, int tid, long long budget) {
   __shared__ int s_ok;
   if (tid == 0) {
     int ok = 1;
-    int spins = 0;
+    long long t0 = 0;
+    bool timed = false;
     while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (__hip_atomic_load(flags + PF_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || ++spins > (1 << 21)) {
+      if (!timed) {  // the clock is read only by waits that actually wait
+        t0 = (long long)wall_clock64();
+        timed = true;
+      }
+      const long long waited = (long long)wall_clock64() - t0;
+      if (__hip_atomic_load(flags + PF_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 || waited > budget) {
         ok = 0;
 #ifdef GPP_PANEL_STAMP
-        if (spins > (1 << 21)) {  // the wait that gave up
+        if (waited > budget) {  // the wait that gave up
           flags[PF_INTS + 8] = (int)blockIdx.x;
           flags[PF_INTS + 9] = (int)(flag - flags);
           flags[PF_INTS + 10] = target;
           flags[PF_INTS + 11] = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #endif
-        __hip_atomic_store(flags + PF_ABORT, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (waited > budget) {
+          const long long ms = waited / 100000;
+          __hip_atomic_store(flags + PF_ABORT, 1 + (int)(ms > 0xFFFFF ? 0xFFFFF : ms), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         break;
       }
       __builtin_amdgcn_s_sleep(2);
@@ -649,15 +662,22 @@ __device__ __forceinline__ void panel_publish(int* flag, int tid) {
 __device__ __forceinline__ void panel_leave(int* flags, int tid) {
   __shared__ int s_last;
   __syncthreads();
-  if (tid == 0)
-    s_last = __hip_atomic_fetch_add(flags + PF_DONE, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+  if (tid == 0) {
+    // release + relaxed add + acquire written out, with the same explicit wait as panel_publish: an ACQ_REL atomic is lowered to
+    // buffer_wbl2 + atomic and is exposed to the same missing s_waitcnt (tests/test_host_cpu.py checks every write-back of the file)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __builtin_amdgcn_s_waitcnt(0);
+    s_last = __hip_atomic_fetch_add(flags + PF_DONE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
   __syncthreads();
   if (s_last)
     for (int i = tid; i < PF_INTS; i += 256) __hip_atomic_store(flags + i, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ A, int64_t lda, double* __restrict__ Linv,
-                                                           int64_t ldi, int n, int32_t* info, int row_offset, int* flags) {
+                                                           int64_t ldi, int n, int32_t* info, int row_offset, int* flags,
+                                                           long long budget) {
   extern __shared__ __attribute__((aligned(16))) double img[];
   const int tid = threadIdx.x;
   const int C = (n + 127) >> 7, nl = n - 128 * (C - 1);  // leaves; rows of the last one (1 .. 128)
@@ -673,7 +693,7 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
   if (blockIdx.x == 0) {  // the chain
     for (int j = 0; j < C; ++j) {
       PSTAMP(4 * j);
-      if (j > 0 && !panel_wait(flags + PF_DIAG + j, 4, flags, tid)) break;
+      if (j > 0 && !panel_wait(flags + PF_DIAG + j, 4, flags, tid, budget)) break;
       PSTAMP(4 * j + 1);
       leaf_body(A + (int64_t)(128 * j) * lda + 128 * j, lda, Linv + (int64_t)(128 * j) * ldi + 128 * j, ldi, ext(j), info,
                 row_offset + 128 * j);
@@ -681,7 +701,10 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
       panel_publish(flags + PF_LEAF + j, tid);
       PSTAMP(4 * j + 3);
     }
-    if (tid == 0 && __hip_atomic_load(flags + PF_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) atomicCAS(info, 0, GPP_INFO_PANEL_TIMEOUT);
+    if (tid == 0) {  // status: 2^30 + the milliseconds the abandoned wait had waited (capped at 2^20 - 1)
+      const int ab = __hip_atomic_load(flags + PF_ABORT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (ab != 0) atomicCAS(info, 0, GPP_INFO_PANEL_TIMEOUT | ((ab - 1) & 0xFFFFF));
+    }
     panel_leave(flags, tid);
     return;
   }
@@ -738,7 +761,7 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
       const int nlim = ext(c) - 32 * q;  // valid columns of this strip (<= 0: nothing to do but to be counted)
       strip_load_b(ob, Bp, lda, tid, 128, nlim);  // this work-group's own data (its update of the previous step): fetched while the leaf runs
       if (stamp) PSTAMP(128 + 8 * j);
-      ok = panel_wait(flags + PF_LEAF + j, 1, flags, tid);
+      ok = panel_wait(flags + PF_LEAF + j, 1, flags, tid, budget);
       if (!ok) break;
       if (stamp) PSTAMP(128 + 8 * j + 1);
       strip_load_a(oa, tileI(j, j), ldi, tid);
@@ -776,7 +799,7 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
               const int m = rbase[a] + 4 * v + lk, nn = 16 * b + li;
               cold[a][b][v] = (m < er && nn < nlim) ? Cp[(int64_t)m * lda + nn] : 0.0;
             }
-        ok = panel_wait(flags + PF_SOLVED + j * PMAXC + r, 4, flags, tid);
+        ok = panel_wait(flags + PF_SOLVED + j * PMAXC + r, 4, flags, tid, budget);
         if (!ok) break;
         if (stamp) PSTAMP(128 + 8 * j + 4);
         strip_load_a(oa, tileA(j, r), lda, tid, 128, er);
@@ -804,7 +827,7 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
       if (s < nf) continue;
       const int i = (s - nf) >> 2, q = s & 3, jj = j - 1;
       if (jj < 1 || i >= jj) continue;
-      ok = panel_wait(flags + PF_LEAF + jj, 1, flags, tid);
+      ok = panel_wait(flags + PF_LEAF + jj, 1, flags, tid, budget);
       if (ok) inverse_row(jj, i, q);
     }
   }
@@ -812,7 +835,7 @@ __global__ __launch_bounds__(256) void gpp_panel_potrf_inv(double* __restrict__ 
     if (s < nf) continue;
     const int i = (s - nf) >> 2, q = s & 3, jj = C - 1;
     if (jj < 1 || i >= jj) continue;
-    ok = panel_wait(flags + PF_LEAF + jj, 1, flags, tid);
+    ok = panel_wait(flags + PF_LEAF + jj, 1, flags, tid, budget);
     if (ok) inverse_row(jj, i, q);
   }
   panel_leave(flags, tid);
@@ -843,7 +866,7 @@ int gpp_panel_max_leaves() { return PMAXC; }
 // in flight uses (the launch leaves them zeroed again);
 // `max_wgs` = work-groups the stream's CUs hold at one each (the grid never exceeds it: see the kernel's comment).
 hipError_t gpp_launch_panel(hipStream_t s, double* A, int64_t lda, double* Linv, int64_t ldi, int n, int32_t* info,
-                            int row_offset, int* flags, int max_wgs) {
+                            int row_offset, int* flags, int max_wgs, int timeout_ms) {
   if (n <= 0) return hipSuccess;
   const int C = (n + NB - 1) / NB;
   if (C > PMAXC || max_wgs < 2 || !flags) return hipErrorInvalidValue;
@@ -862,8 +885,9 @@ hipError_t gpp_launch_panel(hipStream_t s, double* A, int64_t lda, double* Linv,
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   const int workers = C > 1 ? std::min(8 * (C - 1), max_wgs - 1) : 0;
+  const long long budget = (long long)(timeout_ms > 0 ? timeout_ms : 500) * 100000;  // ticks of the 100 MHz constant clock
   hipLaunchKernelGGL(gpp_panel_potrf_inv, dim3((unsigned)(1 + workers)), dim3(256), shmem, s, A, lda, Linv, ldi, n, info, row_offset,
-                     flags);
+                     flags, budget);
   return hipGetLastError();
 }
 

@@ -90,9 +90,9 @@ class ExactGP(GP):
 
             def var_and_v(cache=cache, Us=Us):
                 if "V" not in lazy:
-                    if cache.stale():
-                        raise RuntimeError("the prediction workspace was reused by another model before the variance of this "
-                                           "prediction was evaluated; read .variance / .stddev right after the call")
+                    # another model of the same size may have factored into the shared workspace since this prediction was
+                    # made (p1 = m1(x); p2 = m2(x); p1.stddev): the cache rebuilds its factor from its own inputs
+                    cache.refresh()
                     with torch.no_grad():
                         _, lazy["var"], lazy["V"] = predict_from_cache(cache, Us, need_var=True, need_V=True)
                 return lazy["var"], lazy["V"]

@@ -313,15 +313,30 @@ class FactorCache:
     """Cholesky factor, its inverse and alpha = Ky^-1 (y - m) of the training covariance: the analogue of gpytorch's
     prediction strategy caches (mean_cache / covar_cache) used by models/gpregression.py:122-149."""
 
-    def __init__(self, gctx, L, Linv, alpha, U, spec, jitter, ws=None, z=None):
+    def __init__(self, gctx, L, Linv, alpha, U, spec, jitter, ws=None, z=None, refactor=None):
         self.gctx, self.L, self.Linv, self.alpha, self.U, self.spec, self.jitter = gctx, L, Linv, alpha, U, spec, jitter
         self.z = z  # Linv (y - m): the mean of a prediction that also wants the variance is V z
         # L and Linv live in the shared prediction workspace: another model's factorisation of the same size overwrites
         # them.  ``stale()`` tells the owner to factor again instead of predicting from someone else's matrices.
         self._ws, self._epoch = ws, (ws.epoch if ws is not None else 0)
+        self._refactor = refactor  # (tau, grp, r = y - m): what ``refresh`` needs besides U and spec (O(N) copies)
 
     def stale(self) -> bool:
         return self._ws is not None and self._ws.epoch != self._epoch
+
+    def refresh(self) -> None:
+        """Factor again when another model of the same size has taken the shared workspace since (two GPs fitted on one X
+        whose predictions are read alternately): the lazily evaluated variance of an EARLIER prediction stays valid, as it
+        is in gpytorch, whose prediction strategy owns its caches.  Same inputs, same jitter schedule: the same factor."""
+        if not self.stale():
+            return
+        if self._refactor is None:
+            raise RuntimeError("the prediction workspace was reused by another model and this cache cannot be rebuilt")
+        tau, grp, r = self._refactor
+        with torch.cuda.device(self.U.device):
+            fresh = _factorize(self.U, self.spec, tau, grp, torch.zeros_like(r), r)
+        self.L, self.Linv, self.alpha, self.z, self.jitter = fresh.L, fresh.Linv, fresh.alpha, fresh.z, fresh.jitter
+        self._ws, self._epoch = fresh._ws, fresh._epoch
 
 
 @torch.no_grad()
@@ -347,7 +362,7 @@ def _factorize(U, spec: KernelSpec, tau, grp, mean, y) -> FactorCache:
     gctx.mll_reduce(ws.A, ws.Li, ws.r, ws.z, ws.out3)
     gctx.alpha(ws.Li, ws.z, ws.alpha)
     return FactorCache(gctx, ws.A, ws.Li, ws.alpha.clone(), Ud, KernelSpec(wd, sd.reshape(()), spec.kind, spec.d_split), jit, ws,
-                       z=ws.z.clone())
+                       z=ws.z.clone(), refactor=(td.clone(), None if grp is None else grp.clone(), ws.r.clone()))
 
 
 @torch.no_grad()

@@ -460,6 +460,7 @@ class ShardedMLLFunction(torch.autograd.Function):
         used = None
         from .linalg import _stage
         attempts = list(jitters)
+        timeouts = 0
         while attempts:
             jit = attempts.pop(0)
             with _stage("shard_factor"):
@@ -467,6 +468,10 @@ class ShardedMLLFunction(torch.autograd.Function):
             if info >= INFO_PANEL_TIMEOUT:
                 # (the status is the MAX over the ranks: every rank sees it and repeats the attempt; the rank whose panel gave up —
                 #  or every rank, it costs 1-2 % — switches the panel off)
+                timeouts += 1
+                if timeouts > 2:  # every rank has switched its panel off by now: this is not a time-out any more
+                    from .backend import check_status
+                    check_status(info)
                 if gctx.coop_panel:
                     panel_timed_out(gctx, info)
                 attempts.insert(0, jit)

@@ -68,12 +68,15 @@ int gpp_internal_stream(gpp_handle_t h, int which, void** out);
 /* Per-handle switches.  GPP_OPT_COOP_PANEL (default 1, or 0 with GPP_COOP_PANEL=0 in the environment): factor diagonal blocks and
  * small matrices with the cooperative panel kernel, whose work-groups wait for each other on the device and therefore must all be
  * resident together.  When several handles (threads or processes) share one GPU two such launches can each hold part of the same
- * CUs; a wait inside the kernel then gives up after ~1 s and the factorisation reports *info = GPP_INFO_PANEL_TIMEOUT — the
+ * CUs; a wait inside the kernel then gives up after GPP_OPT_PANEL_TIMEOUT_MS (default 500) milliseconds of the device's 100 MHz
+ * constant clock — wall time, independent of the core clock and of how slow a poll is beside other tenants — and the factorisation
+ * reports *info = GPP_INFO_PANEL_TIMEOUT + the milliseconds the abandoned wait had waited (low 20 bits) — the
  * caller switches the option off and factors again (gp-plus_amd/linalg.py does).  GPP_OPT_PANEL_FAULT (default 0): the NEXT
  * panel launch reports that time-out without running (one shot; for tests of the caller's recovery).
  * No reference counterpart: the reference's factorisation is torch.linalg.cholesky_ex behind gpytorch (optim/mll_torch.py:116). */
 #define GPP_OPT_COOP_PANEL 1
 #define GPP_OPT_PANEL_FAULT 2
+#define GPP_OPT_PANEL_TIMEOUT_MS 3
 #define GPP_INFO_PANEL_TIMEOUT (1 << 30)
 int gpp_set_option(gpp_handle_t h, int option, int value);
 size_t gpp_workspace_bytes(gpp_handle_t h, int op, int64_t N, int64_t M, int D, int S);

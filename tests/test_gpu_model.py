@@ -537,6 +537,15 @@ def test_two_models_share_the_prediction_workspace(gpu_ctx):
     a2 = ma.predict(Z, return_std=False).cpu().numpy().copy()
     np.testing.assert_allclose(a2, a1, rtol=1e-12)
     assert np.abs(a1 - b1).max() > 0.5
+    # the advisor's sequence: the LAZY variance of an earlier prediction is read after another model of the same size has
+    # predicted (p1 = m1(x); p2 = m2(x); p1.stddev) — works in gpytorch, whose prediction strategy owns its caches
+    ref_a = ma(Z).stddev.cpu().numpy().copy()
+    ref_b = mb(Z).stddev.cpu().numpy().copy()
+    p1 = ma(Z)
+    p2 = mb(Z)
+    np.testing.assert_allclose(p1.stddev.cpu().numpy(), ref_a, rtol=1e-12)
+    np.testing.assert_allclose(p2.stddev.cpu().numpy(), ref_b, rtol=1e-12)
+    np.testing.assert_allclose(p1.covariance_matrix.diagonal().sqrt().cpu().numpy(), ref_a, rtol=1e-9)
 
 
 def _toy_model(kind, n=260, seed=0):
