@@ -347,11 +347,76 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   Ctx cp = cm, cu = cm;
   cp.s = h->panel_stream;
   cu.s = h->upd_stream;
+  const char* env_nb = getenv("GPP_LOOKAHEAD_NB");  // experiment knob: "big,small,threshold"
+  static const int64_t border_max_x = getenv("GPP_BORDER_MAX") ? atol(getenv("GPP_BORDER_MAX")) : BORDER_MAX_N;
+  // ---- statically scheduled steps (round 4) -----------------------------------------------------------------------------------
+  // While a step's trailing update is longer than its chain (diagonal block -> head solve -> next diagonal block's update), a
+  // launch per product loses to wave quantisation (2-4 waves of 280-us tiles per launch from the middle on), to the gaps between
+  // dependent launches and to masked and unmasked launches competing for CUs (profiles/r03_timeline_potrf.txt: steps 0-12 take
+  // 46.8 ms for 40.0 ms of work at the rate of a long launch).  Those steps run as ONE persistent launch on the throughput
+  // CUs whose work-groups walk host-precomputed tile lists gated by counters (gpp_plan.hip), the diagonal blocks on the panel's CUs
+  // behind one-wave gate kernels, and between two of them a short filler launch gives the panel's CUs a share of the update.
+  // The chain-bound tail (fewer than GPP_EXEC_MIN_REM rows left) continues below with launches, whose chain is shorter.
+  PotrfExecPlan* plan = nullptr;
+  {
+    static const bool exec_env = !(getenv("GPP_EXEC_SCHED") && atoi(getenv("GPP_EXEC_SCHED")) == 0);                 // knobs
+    static const int64_t exec_min_rem = getenv("GPP_EXEC_MIN_REM") ? atol(getenv("GPP_EXEC_MIN_REM")) : 6500;
+    static const int64_t exec_max_n = getenv("GPP_EXEC_MAX_N") ? atol(getenv("GPP_EXEC_MAX_N")) : 33000;
+    const int K = (int)((N - exec_min_rem) / NB);
+    if (exec_env && h->exec_sched && h->coop_panel && T && N > border_max_x && N <= exec_max_n && !env_nb && h->cu_split == 1 &&
+        NB % NBLK == 0 && panel_fits(h, NB) && K >= 2) {
+      const int W = 2 * (h->ncu - h->panel_cus), F = 2 * h->panel_cus;
+      PotrfExecPlan* P = h->exec_plan;
+      if (P && (P->N != N || P->nb != NB || P->K != K || P->W != W || P->F != F)) {
+        HIP_TRY(hipDeviceSynchronize());  // (a launch may still be reading the old plan)
+        gpp_plan_free(P);
+        P = h->exec_plan = nullptr;
+      }
+      if (!P) {
+        PotrfExecTuning tune;
+        tune.t_tile = getenv("GPP_EXEC_TTILE") ? atof(getenv("GPP_EXEC_TTILE")) : 275.0;
+        tune.t_block = getenv("GPP_EXEC_TBLOCK") ? atof(getenv("GPP_EXEC_TBLOCK")) : 800.0;
+        tune.solve_pos = getenv("GPP_EXEC_PS") ? atoi(getenv("GPP_EXEC_PS")) : 4;
+        tune.fill = getenv("GPP_EXEC_FILL") ? atoi(getenv("GPP_EXEC_FILL")) : 1;
+        P = h->exec_plan = gpp_plan_potrf_exec(N, NB, K, W, F, tune);
+      }
+      if (P) {
+        if (P->A != cm.A || P->ld != cm.ld || P->Li != cm.Li || P->ldi != cm.ldi || P->T != T || P->ldt != ldt || !P->d_tasks) {
+          if (P->d_tasks) HIP_TRY(hipDeviceSynchronize());
+          gpp_plan_bind(P, cm.A, cm.ld, cm.Li, cm.ldi, T, ldt);
+          HIP_TRY(gpp_plan_upload(P));
+        }
+        plan = P;
+        HIP_TRY(gpp_launch_fill_i32(cm.s, P->d_counters, P->ncounters, 0));
+      }
+    }
+  }
   hipEvent_t ev = next_event(h);
   HIP_TRY(hipEventRecord(ev, cm.s));  // inputs (kernel build) are ready
   HIP_TRY(hipStreamWaitEvent(cp.s, ev, 0));
   HIP_TRY(hipStreamWaitEvent(cu.s, ev, 0));
-  const char* env_nb = getenv("GPP_LOOKAHEAD_NB");  // experiment knob: "big,small,threshold"
+  int64_t o_begin = 0;
+  if (plan) {
+    const long long budget = (long long)(h->panel_timeout_ms > 0 ? h->panel_timeout_ms : 500) * 100000 * 4;
+    ExecLaunch el{plan->d_groups, plan->d_tasks, plan->d_offsets, plan->d_counters, cm.info, budget, 0};
+    HIP_TRY(gpp_launch_exec(cu.s, plan->W, el));
+    for (int b = 0; b <= plan->K; ++b) {
+      if (b > 0) HIP_TRY(gpp_launch_exec_gate(cp.s, plan->d_counters, gpp_plan_counter(b, 1), plan->gate_target[b], cm.info, budget));
+      HIP_TRY(launch_panel(h, cp, (int64_t)b * NB, NB, h->panel_cus));
+      if (h->inv_nblocks < 128) {
+        h->inv_o[h->inv_nblocks] = (int64_t)b * NB;
+        h->inv_n[h->inv_nblocks] = NB;
+        ++h->inv_nblocks;
+      }
+      if (b < plan->K) HIP_TRY(gpp_launch_exec_signal(cp.s, plan->d_counters, gpp_plan_counter(b, 0)));
+      if (b >= 1 && plan->fill_workers[b - 1] > 0) {
+        ExecLaunch fl = el;
+        fl.worker_base = plan->W + (b - 1) * std::max(plan->F, 1);
+        HIP_TRY(gpp_launch_exec(cp.s, plan->fill_workers[b - 1], fl));
+      }
+    }
+    o_begin = (int64_t)plan->K * NB;  // the launches below continue with block row K, whose diagonal block is already enqueued
+  }
   // Round 1 measured 1024 above / 512 below 6144 remaining rows best (70.6 vs 71.7 ms for 1024 flat at N = 20000); with the panel
   // kernel a 1024-row block costs 0.58 ms where two 512-row blocks cost 2 x (0.29 + 0.07 ms hand-off), and 1024 flat wins (means
   // of 3: potrf 15.50 -> 15.22 ms at N = 12288, 25.27 -> 24.87 at 15000, 51.84 -> 51.46 at 20000, 155.3 -> 155.3 at 30000).
@@ -361,7 +426,7 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   // bordering pays while the factorisation is bound by its chain of diagonal blocks (measured: 9.6 -> 7.8 ms per
   // evaluation at N = 6144, 16.3 -> 14.0 at 8192, 26.5 -> 24.4 at 10000, a tie at 12288, 147 -> 156 at 20000 where the
   // throughput CUs have no idle time to give and the long-K bordering products are slower than batched pair merges)
-  static const int64_t border_max = getenv("GPP_BORDER_MAX") ? atol(getenv("GPP_BORDER_MAX")) : BORDER_MAX_N;  // knob
+  const int64_t border_max = border_max_x;  // knob GPP_BORDER_MAX
   const bool border = T != nullptr && N <= border_max;
   // the first product of a bordering step needs neither this block's factor nor its inverse: it is issued before them
   // and only the second waits for D (measured: 4.54 -> 4.44 ms per evaluation at 4096, 13.7 -> 13.4 at 8192, even above)
@@ -393,13 +458,15 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
     nb_small = NB / 2;
     nb_thresh = (N <= 7168) ? N + 1 : 0;
   }
-  for (int64_t o = 0, nb = 0; o < N; o += nb) {
+  for (int64_t o = o_begin, nb = 0; o < N; o += nb) {
     // tall block rows while the trailing update is long enough to hide their diagonal factorisation, shorter after
     const int64_t want = (N - o >= nb_thresh) ? nb_big : nb_small;
     nb = std::min(want, N - o);
     const int64_t rem = N - o - nb;
     const bool coop = T != nullptr && panel_fits(h, nb);
-    if (coop) {
+    if (plan && o == o_begin) {
+      // this diagonal block was enqueued with the statically scheduled steps; the throughput stream continues behind their launch
+    } else if (coop) {
       // factor + complete inverse of the diagonal block in ONE cooperative launch on the panel's CUs
       HIP_TRY(launch_panel(h, cp, o, nb, h->cu_split == 1 ? h->panel_cus : std::min(64, h->ncu)));
       if (h->inv_nblocks < 128) {
@@ -618,6 +685,8 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->coop_panel = panel_enabled() ? 1 : 0;
   h->panel_fault = 0;
   h->panel_timeout_ms = 500;
+  h->exec_plan = nullptr;
+  h->exec_sched = 1;
   h->ncu = 0;
   if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->ncu < 2) {
     (void)hipGetLastError();
@@ -642,6 +711,7 @@ int gpp_destroy(gpp_handle_t h) {
   if (h->full_stream) (void)hipStreamDestroy(h->full_stream);
   for (int i = 0; i < h->n_events; ++i) (void)hipEventDestroy(h->events[i]);
   if (h->panel_flags) (void)hipFree(h->panel_flags);
+  if (h->exec_plan) gpp_plan_free(h->exec_plan);
   delete h;
   return 0;
 }
@@ -656,6 +726,7 @@ int gpp_set_option(gpp_handle_t h, int option, int value) {
   if (!h) return -1;
   if (option == GPP_OPT_COOP_PANEL) h->coop_panel = value ? 1 : 0;
   else if (option == GPP_OPT_PANEL_FAULT) h->panel_fault = value ? 1 : 0;
+  else if (option == GPP_OPT_EXEC_SCHED) h->exec_sched = value ? 1 : 0;
   else if (option == GPP_OPT_PANEL_TIMEOUT_MS) {
     if (value < 1 || value > 60000) return -3;
     h->panel_timeout_ms = value;

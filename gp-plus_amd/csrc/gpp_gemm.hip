@@ -17,6 +17,7 @@
 // per chunk.  WT = 32 / 16 variants (64^2 / 32^2 tiles) and a 128 x 32 tile serve the small sub-problems, where the
 // grid of 128^2 tiles would leave most of the 256 CUs idle; they stage K in chunks of 64 with one LDS buffer (template
 // parameters BK, NBUF below).  Work-groups are independent along two batch dimensions (grid.y, grid.z).
+#include "../../include/gpp.h"
 #include "gpp_internal.h"
 
 #include <algorithm>
@@ -180,8 +181,14 @@ __device__ __forceinline__ void load_fast(const double* __restrict__ ubase, cons
 // registers during the MFMAs, two barriers per chunk.  (k-contiguous operands, VAR != 2, only exist with BK = 16.)
 // WR = rows of waves in the work-group: 2 (256 threads, 2 x 2 waves: every instantiation of the evaluation) or 4 (512 threads, 4 x 2
 // waves, a 256 x 128 tile on ONE work-group per CU: the experiment of DESIGN.md section 3.5 — 25 % fewer operand bytes per flop).
-template <int VAR, int WTM, int WTN, int TAG = 0, int BK = 16, int NBUF = 2, int WR = 2>
-__global__ __launch_bounds__(128 * WR, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM < 64) ? 2 : 1) void gpp_gemm_f64(GemmArgs p) {
+// One output tile (tm, tn) of the product described by ``p``: the body shared by the launch-per-product kernel (gpp_gemm_f64, p in
+// the kernel arguments) and the static-schedule executor (gpp_exec_f64, p in a device array read through the constant address
+// space: scalar loads, re-materialisable like kernel arguments).  A, B, C: the batch element's operands; c2off: its offset into
+// the mirrored output p.C2.  Ends with a work-group barrier after the last LDS read, so the caller may stage another tile at once.
+template <int VAR, int WTM, int WTN, int TAG, int BK, int NBUF, int WR, class P>
+__device__ __forceinline__ void gemm_tile(const P& p, const int tm, const int tn, const double* __restrict__ A,
+                                          const double* __restrict__ B, double* __restrict__ C, const int64_t c2off,
+                                          double* __restrict__ smem) {
   static_assert(BK == 16 || VAR == 2, "wide K chunks are implemented for row-contiguous (TN) operands only");
   static_assert(BK % 16 == 0 && (NBUF == 1 || NBUF == 2), "bad staging parameters");
   static_assert(WR == 2 || (WR == 4 && VAR == 2 && BK == 16 && NBUF == 2 && WTM == 64 && WTN == 64), "the tall tile is TN only");
@@ -196,69 +203,6 @@ __global__ __launch_bounds__(128 * WR, ((VAR == 2 && !(BK > 16 && WTM >= 64)) ||
   constexpr int OPA = (WR == 2) ? OPSZ : BK * LDA, OPB = (WR == 2) ? OPSZ : BK * LDB;
   constexpr int NVA = BK * TM / (2 * NTH), NVB = BK * TN / (2 * NTH);  // 16-byte vectors per thread and chunk
   constexpr int RB = WTM / 4, CB = WTN / 16;
-  extern __shared__ __attribute__((aligned(16))) double smem[];  // NBUF * 2 * OPSZ doubles (see gemm_lds_bytes)
-
-  int tm, tn;
-  if (p.swz) {
-    // XCD-aware mapping (blocks are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2): the 64 work-groups
-    // an XCD runs concurrently (32 CUs x 2) form ONE 8 x 8 super-tile of output tiles, so every staged A chunk is
-    // shared by 8 and every B chunk by 8 work-groups of that L2.  Tiles outside the matrix / triangle exit at once.
-    const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
-    const int S = (i >> 6) * 8 + xcd, w = i & 63;
-    const int super_n = (p.tiles_n + 7) >> 3;
-    const int sm = S / super_n, sn = S - sm * super_n;
-    tm = sm * 8 + (w >> 3);
-    tn = sn * 8 + (w & 7);
-    if (tm >= p.tiles_m || tn >= p.tiles_n) return;
-    if ((p.c_lower == 1 && tn > tm) || (p.c_lower == 2 && tn < tm)) return;
-  } else {
-    const int t = (p.batch_fast ? (int)(blockIdx.x / (unsigned)p.nbatch) : (int)blockIdx.x) + (int)p.tile_base;
-    if (p.c_lower == 1 && p.row_mod >= 1) {
-      // owned tile rows tm = row_off + row_mod * i, row i has tm + 1 tiles: S(i) = i (row_off + 1) + row_mod i (i-1) / 2
-      const float a = 0.5f * (float)p.row_mod, b = (float)p.row_off + 1.f - a;
-      int i = (int)((-b + sqrtf(b * b + 4.f * a * (float)t)) / (2.f * a));
-      auto S = [&](int q) { return q * (p.row_off + 1) + p.row_mod * (q * (q - 1) / 2); };
-      while (S(i + 1) <= t) ++i;
-      while (S(i) > t) --i;
-      tm = p.row_off + p.row_mod * i;
-      tn = t - S(i);
-    } else if (p.c_lower == 1 && TM == 2 * TN) {
-      // tall tiles, lower triangle: tile row tm (TM rows) has the column tiles 0 .. 2 tm + 1; S(tm) = tm (tm + 1) tiles precede it
-      tm = (int)((sqrtf(4.f * (float)t + 1.f) - 1.f) * 0.5f);
-      while ((tm + 1) * (tm + 2) <= t) ++tm;
-      while (tm * (tm + 1) > t) --tm;
-      tn = t - tm * (tm + 1);
-      if (tn >= p.tiles_n) return;
-    } else if (p.c_lower) {
-      tm = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-      while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
-      while (tm * (tm + 1) / 2 > t) --tm;
-      tn = t - tm * (tm + 1) / 2;
-      // lower triangle, column blocks owned block-cyclically (the sharded back-substitution): another rank's column block
-      if (p.c_lower == 1 && p.own_mod > 1 && (tn / p.own_bt + p.own_off) % p.own_mod != 0) return;
-      if (p.c_lower == 2) {  // upper triangle: same enumeration, mirrored tile
-        const int q = tm;
-        tm = tn;
-        tn = q;
-        if (p.own_mod > 1 && (tm / p.own_bt + p.own_off) % p.own_mod != 0) return;  // another rank's block row
-        if ((tn + 1) * TN <= p.skip_lead) return;  // (tm <= tn) inside the leading block another launch has updated
-        if (p.row_limit > 0 && tm * TM >= p.row_limit) return;  // below the trapezoid this launch produces
-      }
-    } else if (p.col_major) {
-      // column-major tile order: consecutive work-groups share the column tile (hence the K range when it depends on
-      // the column, and the B chunks) and run in lockstep
-      tn = t / p.tiles_m;
-      tm = t - tn * p.tiles_m;
-    } else {
-      tm = t / p.tiles_n;
-      tn = t - tm * p.tiles_n;
-      if (p.row_reverse) tm = p.tiles_m - 1 - tm;  // longest K ranges (khi grows with the row) first: short tail
-    }
-  }
-  const int64_t bi = p.batch_fast ? (int64_t)(blockIdx.x % (unsigned)p.nbatch) : (int64_t)blockIdx.y;  // batch element
-  const double* __restrict__ A = p.A + bi * p.sA + (int64_t)blockIdx.z * p.zA;
-  const double* __restrict__ B = p.B + bi * p.sB + (int64_t)blockIdx.z * p.zB;
-  double* __restrict__ C = p.C + bi * p.sC + (int64_t)blockIdx.z * p.zC;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -454,11 +398,78 @@ __global__ __launch_bounds__(128 * WR, ((VAR == 2 && !(BK > 16 && WTM >= 64)) ||
         if (ok) {
           C[(int64_t)m * p.ldc + n] = v;
           if (p.C2)  // mirrored (transposed) copy
-            p.C2[bi * p.sC2 + (int64_t)blockIdx.z * p.zC2 + (int64_t)n * p.ldc2 + m] = v;
+            p.C2[c2off + (int64_t)n * p.ldc2 + m] = v;
         }
       }
     }
   }
+}
+
+template <int VAR, int WTM, int WTN, int TAG = 0, int BK = 16, int NBUF = 2, int WR = 2>
+__global__ __launch_bounds__(128 * WR, ((VAR == 2 && !(BK > 16 && WTM >= 64)) || WTM < 64) ? 2 : 1) void gpp_gemm_f64(GemmArgs p) {
+  constexpr int TM = WR * WTM, TN = 2 * WTN;  // work-group tile: TM rows x TN columns (WR x 2 waves)
+  extern __shared__ __attribute__((aligned(16))) double smem[];  // NBUF * 2 * OPSZ doubles (see gemm_lds_bytes)
+  int tm, tn;
+  if (p.swz) {
+    // XCD-aware mapping (blocks are dealt round-robin to the 8 XCDs, each with a private 4 MiB L2): the 64 work-groups
+    // an XCD runs concurrently (32 CUs x 2) form ONE 8 x 8 super-tile of output tiles, so every staged A chunk is
+    // shared by 8 and every B chunk by 8 work-groups of that L2.  Tiles outside the matrix / triangle exit at once.
+    const int b = blockIdx.x, xcd = b & 7, i = b >> 3;
+    const int S = (i >> 6) * 8 + xcd, w = i & 63;
+    const int super_n = (p.tiles_n + 7) >> 3;
+    const int sm = S / super_n, sn = S - sm * super_n;
+    tm = sm * 8 + (w >> 3);
+    tn = sn * 8 + (w & 7);
+    if (tm >= p.tiles_m || tn >= p.tiles_n) return;
+    if ((p.c_lower == 1 && tn > tm) || (p.c_lower == 2 && tn < tm)) return;
+  } else {
+    const int t = (p.batch_fast ? (int)(blockIdx.x / (unsigned)p.nbatch) : (int)blockIdx.x) + (int)p.tile_base;
+    if (p.c_lower == 1 && p.row_mod >= 1) {
+      // owned tile rows tm = row_off + row_mod * i, row i has tm + 1 tiles: S(i) = i (row_off + 1) + row_mod i (i-1) / 2
+      const float a = 0.5f * (float)p.row_mod, b = (float)p.row_off + 1.f - a;
+      int i = (int)((-b + sqrtf(b * b + 4.f * a * (float)t)) / (2.f * a));
+      auto S = [&](int q) { return q * (p.row_off + 1) + p.row_mod * (q * (q - 1) / 2); };
+      while (S(i + 1) <= t) ++i;
+      while (S(i) > t) --i;
+      tm = p.row_off + p.row_mod * i;
+      tn = t - S(i);
+    } else if (p.c_lower == 1 && TM == 2 * TN) {
+      // tall tiles, lower triangle: tile row tm (TM rows) has the column tiles 0 .. 2 tm + 1; S(tm) = tm (tm + 1) tiles precede it
+      tm = (int)((sqrtf(4.f * (float)t + 1.f) - 1.f) * 0.5f);
+      while ((tm + 1) * (tm + 2) <= t) ++tm;
+      while (tm * (tm + 1) > t) --tm;
+      tn = t - tm * (tm + 1);
+      if (tn >= p.tiles_n) return;
+    } else if (p.c_lower) {
+      tm = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+      while ((tm + 1) * (tm + 2) / 2 <= t) ++tm;
+      while (tm * (tm + 1) / 2 > t) --tm;
+      tn = t - tm * (tm + 1) / 2;
+      // lower triangle, column blocks owned block-cyclically (the sharded back-substitution): another rank's column block
+      if (p.c_lower == 1 && p.own_mod > 1 && (tn / p.own_bt + p.own_off) % p.own_mod != 0) return;
+      if (p.c_lower == 2) {  // upper triangle: same enumeration, mirrored tile
+        const int q = tm;
+        tm = tn;
+        tn = q;
+        if (p.own_mod > 1 && (tm / p.own_bt + p.own_off) % p.own_mod != 0) return;  // another rank's block row
+        if ((tn + 1) * TN <= p.skip_lead) return;  // (tm <= tn) inside the leading block another launch has updated
+        if (p.row_limit > 0 && tm * TM >= p.row_limit) return;  // below the trapezoid this launch produces
+      }
+    } else if (p.col_major) {
+      // column-major tile order: consecutive work-groups share the column tile (hence the K range when it depends on
+      // the column, and the B chunks) and run in lockstep
+      tn = t / p.tiles_m;
+      tm = t - tn * p.tiles_m;
+    } else {
+      tm = t / p.tiles_n;
+      tn = t - tm * p.tiles_n;
+      if (p.row_reverse) tm = p.tiles_m - 1 - tm;  // longest K ranges (khi grows with the row) first: short tail
+    }
+  }
+  const int64_t bi = p.batch_fast ? (int64_t)(blockIdx.x % (unsigned)p.nbatch) : (int64_t)blockIdx.y;  // batch element
+  gemm_tile<VAR, WTM, WTN, TAG, BK, NBUF, WR>(p, tm, tn, p.A + bi * p.sA + (int64_t)blockIdx.z * p.zA, p.B + bi * p.sB + (int64_t)blockIdx.z * p.zB,
+                                             p.C + bi * p.sC + (int64_t)blockIdx.z * p.zC, bi * p.sC2 + (int64_t)blockIdx.z * p.zC2, smem);
+
 }
 
 // LDS bytes of an instantiation (dynamic: the wide-chunk variants exceed the 64 KiB static limit)
@@ -503,6 +514,119 @@ hipError_t launch_var(hipStream_t s, int tm, int tn, dim3 grid, const GemmArgs& 
   if (tm == 32 && tn == 32) return launch_inst<VAR, 16, 16, 0, SBK, SNB>(s, grid, a);
   if (tm == 128 && tn == 32) return launch_inst<VAR, 64, 16, 0, SBK, SNB>(s, grid, a);
   return hipErrorInvalidValue;
+}
+
+
+// ---- static-schedule executor ---------------------------------------------------------------------------------------------
+// (see gpp_internal.h.)  Task lists and product descriptors are read through the CONSTANT address space: scalar loads the compiler
+// may repeat at will, exactly like kernel arguments — the tile body compiles to the code of the launch-per-product kernel.
+#define GPP_AS4 __attribute__((address_space(4)))
+typedef const GemmArgs GPP_AS4 CGemmArgs;
+typedef const ExecTask GPP_AS4 CExecTask;
+typedef const int32_t GPP_AS4 CInt32;
+
+__device__ __forceinline__ int exec_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// thread 0 polls until both counters have reached their values; false: the launch is being abandoned (time-out or abort word)
+__device__ __forceinline__ bool exec_poll(int* counters, int w0, int v0, int w1, int v1, long long budget, int32_t* info) {
+  long long t0 = 0;
+  bool timed = false;
+  for (;;) {
+    const bool r0 = w0 < 0 || exec_load(counters + w0) >= v0;
+    const bool r1 = w1 < 0 || exec_load(counters + w1) >= v1;
+    if (r0 & r1) return true;
+    if (!timed) {
+      t0 = (long long)wall_clock64();
+      timed = true;
+    }
+    const long long waited = (long long)wall_clock64() - t0;
+    if (exec_load(counters) != 0) return false;
+    if (waited > budget) {
+      const long long ms = waited / 100000;
+      __hip_atomic_store(counters, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      atomicCAS(info, 0, GPP_INFO_PANEL_TIMEOUT | (int)(ms > 0xFFFFF ? 0xFFFFF : ms));
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void gpp_exec_f64(ExecLaunch e) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int s_ok;
+  const int tid = threadIdx.x;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  CInt32* offsets = (CInt32*)e.offsets;
+  CExecTask* tasks = (CExecTask*)e.tasks + offsets[e.worker_base + (int)blockIdx.x];
+  CGemmArgs* groups = (CGemmArgs*)e.groups;
+#pragma clang diagnostic pop
+  for (int idx = 0;; ++idx) {
+    const int g = tasks[idx].group;
+    if (g < 0) break;
+    const int w0 = tasks[idx].wait_id[0], w1 = tasks[idx].wait_id[1];
+    if (w0 >= 0 || w1 >= 0) {
+      if (tid == 0) s_ok = exec_poll(e.counters, w0, tasks[idx].wait_val[0], w1, tasks[idx].wait_val[1], e.budget, e.info) ? 1 : 0;
+      __syncthreads();
+      const int ok = s_ok;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the publishers wrote before their increments is visible from here
+      __syncthreads();
+      if (!ok) break;
+    }
+    const CGemmArgs& p = groups[g];
+    const int tm = tasks[idx].tm, tn = tasks[idx].tn;
+    if (p.op == 0) {
+      gemm_tile<2, 64, 64, 0, 16, 2, 2>(p, tm, tn, p.A, p.B, p.C, (int64_t)0, smem);
+    } else {
+      // copy the M x 128 strip tn of B into C: 64 16-byte vectors per row, 4 rows per pass, 8 passes in flight
+      const int c = tn * 128 + ((tid & 63) << 1), r4 = tid >> 6;
+      if (c < p.N) {
+        const bool pair = c + 1 < p.N;
+        for (int r0 = 0; r0 < p.M; r0 += 32) {
+          v2d v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = r0 + 4 * q + r4;
+            const double* src = p.B + (int64_t)(r < p.M ? r : 0) * p.ldb + c;
+            if (pair) v[q] = *reinterpret_cast<const v2d*>(src);
+            else v[q] = (v2d){*src, 0.0};
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = r0 + 4 * q + r4;
+            if (r < p.M) {
+              double* dst = p.C + (int64_t)r * p.ldc + c;
+              if (pair) *reinterpret_cast<v2d*>(dst) = v[q];
+              else *dst = v[q].x;
+            }
+          }
+        }
+      }
+    }
+    const int i0 = tasks[idx].inc_id[0], i1 = tasks[idx].inc_id[1];
+    if (i0 >= 0 || i1 >= 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left the CU
+      __syncthreads();
+      if (tid == 0) {
+        // (the explicit wait between the write-back and the increments is REQUIRED: see panel_publish in gpp_leaf.hip)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (i0 >= 0) __hip_atomic_fetch_add(e.counters + i0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i1 >= 0) __hip_atomic_fetch_add(e.counters + i1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(64) void gpp_exec_gate(int* counters, int id, int target, int32_t* info, long long budget) {
+  if (threadIdx.x == 0) (void)exec_poll(counters, id, target, -1, 0, budget, info);
+}
+__global__ __launch_bounds__(64) void gpp_exec_signal(int* counters, int id) {
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(counters + id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 }  // namespace
@@ -576,4 +700,28 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int
     case 2: return launch_var<2>(s, tile_m, tile_n, grid, a);
     default: return hipErrorInvalidValue;
   }
+}
+
+hipError_t gpp_launch_exec(hipStream_t s, int nworkers, const ExecLaunch& e) {
+  if (nworkers <= 0) return hipSuccess;
+  constexpr size_t bytes = gemm_lds_bytes(2, 128, 128, 16, 2);
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  hipError_t err = hipGetDevice(&dev);
+  if (err != hipSuccess) return err;
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(gpp_exec_f64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (err != hipSuccess) return err;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(gpp_exec_f64, dim3((unsigned)nworkers), dim3(256), bytes, s, e);
+  return hipGetLastError();
+}
+hipError_t gpp_launch_exec_gate(hipStream_t s, int* counters, int id, int target, int32_t* info, long long budget) {
+  hipLaunchKernelGGL(gpp_exec_gate, dim3(1), dim3(64), 0, s, counters, id, target, info, budget);
+  return hipGetLastError();
+}
+hipError_t gpp_launch_exec_signal(hipStream_t s, int* counters, int id) {
+  hipLaunchKernelGGL(gpp_exec_signal, dim3(1), dim3(64), 0, s, counters, id);
+  return hipGetLastError();
 }

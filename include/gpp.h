@@ -77,6 +77,9 @@ int gpp_internal_stream(gpp_handle_t h, int which, void** out);
 #define GPP_OPT_COOP_PANEL 1
 #define GPP_OPT_PANEL_FAULT 2
 #define GPP_OPT_PANEL_TIMEOUT_MS 3
+#define GPP_OPT_EXEC_SCHED 4 /* default 1 (0 with GPP_EXEC_SCHED=0): the throughput-bound steps of gpp_potrf_ws's look-ahead run as one
+                              * statically scheduled persistent launch (gpp_plan.hip); needs GPP_OPT_COOP_PANEL and shares its
+                              * time-out / recovery: its work-groups must all be resident on the throughput stream's CUs */
 #define GPP_INFO_PANEL_TIMEOUT (1 << 30)
 int gpp_set_option(gpp_handle_t h, int option, int value);
 size_t gpp_workspace_bytes(gpp_handle_t h, int op, int64_t N, int64_t M, int D, int S);

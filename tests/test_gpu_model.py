@@ -116,7 +116,8 @@ def test_against_oracle_on_fresh_inputs(gpu_ctx, n, d, seed):
         gref = g.numpy().reshape(grads[k].shape)
         np.testing.assert_allclose(grads[k], gref, rtol=RTOL_MLL, atol=RTOL_MLL * max(np.abs(gref).max(), 1e-12), err_msg=k)
     # predictions from the same factor path: points at 0.05 ... 1 standard deviations from training rows
-    Xt = X[rng.choice(n, 96, replace=False)] + np.array([0.05, 0.3, 1.0])[np.arange(96) % 3][:, None] * rng.standard_normal((96, d))
+    mt = min(96, n)
+    Xt = X[rng.choice(n, mt, replace=False)] + np.array([0.05, 0.3, 1.0])[np.arange(mt) % 3][:, None] * rng.standard_normal((mt, d))
     om, osd, osd0 = o.predict_all(Xt)
     m.eval()
     mean, std = m.predict(torch.tensor(Xt), return_std=True, include_noise=True)
