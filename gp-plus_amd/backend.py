@@ -21,7 +21,7 @@ from ._lib import GppError, check
 
 KIND_RBF, KIND_MATERN32, KIND_MATERN52 = 0, 1, 2
 UPLO_FULL, UPLO_LOWER, UPLO_UPPER = 0, 1, 2
-OPT_COOP_PANEL, OPT_PANEL_FAULT, OPT_PANEL_TIMEOUT_MS = 1, 2, 3  # gpp_set_option (include/gpp.h)
+OPT_COOP_PANEL, OPT_PANEL_FAULT, OPT_PANEL_TIMEOUT_MS, OPT_EXEC_SCHED = 1, 2, 3, 4  # gpp_set_option (include/gpp.h)
 OP_MLL_EVAL, OP_PREDICT = 0, 1
 #: the tile kernels stage at most this many feature columns (manifold + quantitative) per point in LDS (gpp_build.hip DMAX)
 MAX_FEATURES = 64

@@ -22,6 +22,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <new>
 
 namespace {
@@ -360,8 +361,8 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   PotrfExecPlan* plan = nullptr;
   {
     static const bool exec_env = !(getenv("GPP_EXEC_SCHED") && atoi(getenv("GPP_EXEC_SCHED")) == 0);                 // knobs
-    static const int64_t exec_min_rem = getenv("GPP_EXEC_MIN_REM") ? atol(getenv("GPP_EXEC_MIN_REM")) : 6500;
-    static const int64_t exec_max_n = getenv("GPP_EXEC_MAX_N") ? atol(getenv("GPP_EXEC_MAX_N")) : 33000;
+    static const int64_t exec_min_rem = getenv("GPP_EXEC_MIN_REM") ? atol(getenv("GPP_EXEC_MIN_REM")) : 5500;
+    static const int64_t exec_max_n = getenv("GPP_EXEC_MAX_N") ? atol(getenv("GPP_EXEC_MAX_N")) : 66000;
     const int K = (int)((N - exec_min_rem) / NB);
     if (exec_env && h->exec_sched && h->coop_panel && T && N > border_max_x && N <= exec_max_n && !env_nb && h->cu_split == 1 &&
         NB % NBLK == 0 && panel_fits(h, NB) && K >= 2) {
@@ -377,6 +378,8 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
         tune.t_tile = getenv("GPP_EXEC_TTILE") ? atof(getenv("GPP_EXEC_TTILE")) : 275.0;
         tune.t_block = getenv("GPP_EXEC_TBLOCK") ? atof(getenv("GPP_EXEC_TBLOCK")) : 800.0;
         tune.solve_pos = getenv("GPP_EXEC_PS") ? atoi(getenv("GPP_EXEC_PS")) : 4;
+        tune.solve_pos_later = getenv("GPP_EXEC_PS2") ? atoi(getenv("GPP_EXEC_PS2")) : 0;
+        tune.la_frac = getenv("GPP_EXEC_LAF") ? atof(getenv("GPP_EXEC_LAF")) : 0.4;
         tune.fill = getenv("GPP_EXEC_FILL") ? atoi(getenv("GPP_EXEC_FILL")) : 1;
         P = h->exec_plan = gpp_plan_potrf_exec(N, NB, K, W, F, tune);
       }
@@ -398,21 +401,24 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   int64_t o_begin = 0;
   if (plan) {
     const long long budget = (long long)(h->panel_timeout_ms > 0 ? h->panel_timeout_ms : 500) * 100000 * 4;
-    ExecLaunch el{plan->d_groups, plan->d_tasks, plan->d_offsets, plan->d_counters, cm.info, budget, 0};
+    ExecLaunch el{plan->d_groups, plan->d_tasks, plan->d_offsets, plan->d_counters, cm.info, budget, 0, plan->d_trace};
     HIP_TRY(gpp_launch_exec(cu.s, plan->W, el));
-    for (int b = 0; b <= plan->K; ++b) {
-      if (b > 0) HIP_TRY(gpp_launch_exec_gate(cp.s, plan->d_counters, gpp_plan_counter(b, 1), plan->gate_target[b], cm.info, budget));
-      HIP_TRY(launch_panel(h, cp, (int64_t)b * NB, NB, h->panel_cus));
-      if (h->inv_nblocks < 128) {
-        h->inv_o[h->inv_nblocks] = (int64_t)b * NB;
-        h->inv_n[h->inv_nblocks] = NB;
-        ++h->inv_nblocks;
-      }
-      if (b < plan->K) HIP_TRY(gpp_launch_exec_signal(cp.s, plan->d_counters, gpp_plan_counter(b, 0)));
-      if (b >= 1 && plan->fill_workers[b - 1] > 0) {
+    for (const PotrfExecPlan::Op& op : plan->stream_ops) {
+      if (op.kind == 0) {
+        HIP_TRY(gpp_launch_exec_gate(cp.s, plan->d_counters, gpp_plan_counter(op.arg, 1), plan->gate_target[op.arg], cm.info, budget));
+      } else if (op.kind == 1) {
+        HIP_TRY(launch_panel(h, cp, (int64_t)op.arg * NB, NB, h->panel_cus));
+        if (h->inv_nblocks < 128) {
+          h->inv_o[h->inv_nblocks] = (int64_t)op.arg * NB;
+          h->inv_n[h->inv_nblocks] = NB;
+          ++h->inv_nblocks;
+        }
+      } else if (op.kind == 2) {
+        HIP_TRY(gpp_launch_exec_signal(cp.s, plan->d_counters, gpp_plan_counter(op.arg, 0)));
+      } else {
         ExecLaunch fl = el;
-        fl.worker_base = plan->W + (b - 1) * std::max(plan->F, 1);
-        HIP_TRY(gpp_launch_exec(cp.s, plan->fill_workers[b - 1], fl));
+        fl.worker_base = plan->W + op.arg * std::max(plan->F, 1);
+        HIP_TRY(gpp_launch_exec(cp.s, plan->fill_workers[op.arg], fl));
       }
     }
     o_begin = (int64_t)plan->K * NB;  // the launches below continue with block row K, whose diagonal block is already enqueued
@@ -655,6 +661,42 @@ int gpp_debug_panel_flags(gpp_handle_t h, int* out, int nints, int* next_slot) {
   return (int)hipMemcpy(out, h->panel_flags, (size_t)nints * sizeof(int), hipMemcpyDeviceToHost);
 }
 #endif
+
+// Debug access to the plan of the statically scheduled steps and to its per-task time stamps (tools/exec_trace.py): not part of gpp.h.
+// info6 = {tasks, offsets, K, W, F, counters}; fetch copies the task array (32 B each), the offsets (int32) and — when tracing is
+// on — 3 stamps of the 100 MHz clock per task into host buffers (null: skip).
+int gpp_debug_exec_info(gpp_handle_t h, int64_t* info6) {
+  if (!h || !h->exec_plan) return -1;
+  const PotrfExecPlan* P = h->exec_plan;
+  info6[0] = (int64_t)P->tasks.size(); info6[1] = (int64_t)P->offsets.size(); info6[2] = P->K; info6[3] = P->W; info6[4] = P->F;
+  info6[5] = P->ncounters;
+  return 0;
+}
+int gpp_debug_exec_trace(gpp_handle_t h, int on) {
+  if (!h || !h->exec_plan) return -1;
+  PotrfExecPlan* P = h->exec_plan;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (on && !P->d_trace) {
+    if (hipMalloc(&P->d_trace, 3 * P->tasks.size() * sizeof(unsigned long long)) != hipSuccess) return 2;
+    (void)hipMemset(P->d_trace, 0, 3 * P->tasks.size() * sizeof(unsigned long long));
+  } else if (!on && P->d_trace) {
+    (void)hipFree(P->d_trace);
+    P->d_trace = nullptr;
+  }
+  return 0;
+}
+int gpp_debug_exec_fetch(gpp_handle_t h, void* tasks, void* offsets, void* trace) {
+  if (!h || !h->exec_plan) return -1;
+  const PotrfExecPlan* P = h->exec_plan;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (tasks) memcpy(tasks, P->tasks.data(), P->tasks.size() * sizeof(ExecTask));
+  if (offsets) memcpy(offsets, P->offsets.data(), P->offsets.size() * sizeof(int32_t));
+  if (trace) {
+    if (!P->d_trace) return 2;
+    if (hipMemcpy(trace, P->d_trace, 3 * P->tasks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 3;
+  }
+  return 0;
+}
 
 int gpp_create(gpp_handle_t* out, int device) {
   if (!out) return -1;

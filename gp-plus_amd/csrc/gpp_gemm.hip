@@ -238,6 +238,9 @@ __device__ __forceinline__ void gemm_tile(const P& p, const int tm, const int tn
   const double* __restrict__ ubaseB = B_KC ? B + (int64_t)col0 * p.ldb : B + col0;
   const int64_t stepA = A_KC ? 1 : p.lda, stepB = B_KC ? 1 : p.ldb;  // elements per unit of k
 
+  // extents for the LOADS (see GemmArgs::pad_ok); the stores below always use the true M and N
+  const int Mld = (VAR == 2 && p.pad_ok) ? ((p.M + TM - 1) / TM) * TM : p.M;
+  const int Nld = (VAR == 2 && p.pad_ok) ? ((p.N + TN - 1) / TN) * TN : p.N;
   // Per operand and chunk, work-group uniform: 0 = edge (predicated loads, select on store), 1 = interior (lean loads,
   // plain stores), 2 = in range but cut by the triangular mask (lean loads, select on store).  The lean paths exist for
   // the row-contiguous TN variant only: with a k-contiguous operand the extra live registers push hipcc over the
@@ -246,8 +249,8 @@ __device__ __forceinline__ void gemm_tile(const P& p, const int tm, const int tn
   auto stage_load = [&](int kb) {
     pa = pb = 0;
     if constexpr (VAR == 2) {
-      if (chunk_in_range<TM, BK>(row0, p.M, kb, khi)) pa = chunk_is_interior<TM, BK>(row0, p.M, kb, khi, p.a_mask) ? 1 : 2;
-      if (chunk_in_range<TN, BK>(col0, p.N, kb, khi)) pb = chunk_is_interior<TN, BK>(col0, p.N, kb, khi, p.b_mask) ? 1 : 2;
+      if (chunk_in_range<TM, BK>(row0, Mld, kb, khi)) pa = chunk_is_interior<TM, BK>(row0, Mld, kb, khi, p.a_mask) ? 1 : 2;
+      if (chunk_in_range<TN, BK>(col0, Nld, kb, khi)) pb = chunk_is_interior<TN, BK>(col0, Nld, kb, khi, p.b_mask) ? 1 : 2;
     }
     if (pa) {
       load_fast<NVA>(ubaseA + (int64_t)kb * stepA, offa, ra);
@@ -315,7 +318,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const int tm, const int tn
   // (big tile only: the small tiles run a handful of chunks per launch and lose more to the second loop's code)
   constexpr bool SPLIT = (VAR == 2 && RB == 16 && CB == 4 && BK == 16);
   if constexpr (SPLIT) {
-    if (row0 + TM <= p.M && col0 + TN <= p.N && nch > 1) {
+    if (row0 + TM <= Mld && col0 + TN <= Nld && nch > 1) {
       int k_lo = klo, k_hi = khi;  // chunk [kb, kb+BK) is interior iff k_lo <= kb and kb + BK <= k_hi
       if (p.a_mask == 1) k_hi = min(k_hi, row0 + 1);
       if (p.a_mask == 2) k_lo = max(k_lo, row0 + TM - 1);
@@ -558,12 +561,14 @@ __global__ __launch_bounds__(256, 2) void gpp_exec_f64(ExecLaunch e) {
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Wold-style-cast"
   CInt32* offsets = (CInt32*)e.offsets;
-  CExecTask* tasks = (CExecTask*)e.tasks + offsets[e.worker_base + (int)blockIdx.x];
+  const int first = offsets[e.worker_base + (int)blockIdx.x];
+  CExecTask* tasks = (CExecTask*)e.tasks + first;
   CGemmArgs* groups = (CGemmArgs*)e.groups;
 #pragma clang diagnostic pop
   for (int idx = 0;; ++idx) {
     const int g = tasks[idx].group;
     if (g < 0) break;
+    if (e.trace && tid == 0) e.trace[3 * (size_t)(first + idx)] = wall_clock64();
     const int w0 = tasks[idx].wait_id[0], w1 = tasks[idx].wait_id[1];
     if (w0 >= 0 || w1 >= 0) {
       if (tid == 0) s_ok = exec_poll(e.counters, w0, tasks[idx].wait_val[0], w1, tasks[idx].wait_val[1], e.budget, e.info) ? 1 : 0;
@@ -573,6 +578,16 @@ __global__ __launch_bounds__(256, 2) void gpp_exec_f64(ExecLaunch e) {
       __syncthreads();
       if (!ok) break;
     }
+    if (e.trace && tid == 0) e.trace[3 * (size_t)(first + idx) + 1] = wall_clock64();
+    // The two work-groups of a CU live as long as the launch, and the SIMD's arbiter favours the OLDER wave at equal priority: the
+    // work-group dispatched first ran its K = 1024 tiles in 236 us, its younger partner in 273 (measured, std 2-4 us inside each
+    // half of the grid) — with equal static shares the younger half fell behind by 14 % and every counter waited for it.  Wave
+    // priorities without ties: the younger half of the grid (work-groups b and b + grid/2 share a CU in dispatch order) runs at
+    // priority 1 throughout, the older half alternates between 2 and 0 from task to task — whatever the phase between the two, each
+    // is the favoured one half of the time.  (Both halves toggling 1 / 0 leaves ties half of the time, which the older wins: 246 / 269.)
+    if ((unsigned)blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(1);
+    else if (idx & 1) __builtin_amdgcn_s_setprio(2);
+    else __builtin_amdgcn_s_setprio(0);
     const CGemmArgs& p = groups[g];
     const int tm = tasks[idx].tm, tn = tasks[idx].tn;
     if (p.op == 0) {
@@ -614,6 +629,10 @@ __global__ __launch_bounds__(256, 2) void gpp_exec_f64(ExecLaunch e) {
         if (i0 >= 0) __hip_atomic_fetch_add(e.counters + i0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (i1 >= 0) __hip_atomic_fetch_add(e.counters + i1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
+    }
+    if (e.trace) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid == 0) e.trace[3 * (size_t)(first + idx) + 2] = wall_clock64();
     }
   }
 }

@@ -127,6 +127,10 @@ struct GemmArgs {
   int row_mod, row_off;    // c_lower == 1 only: produce the tile rows tm with tm % row_mod == row_off (row_mod <= 1: all);
                            // the sharded LAUUM, one launch per rank over its cyclic share of the 128-row tile rows
   int op;                  // executor only (gpp_exec_f64): 0 = the product above, 1 = copy the M x 128 strip `tn` of B into C
+  int pad_ok;              // TN variant, big tile: the operands may be READ up to the next multiple of 128 past M / N along their rows
+                           // (the bytes belong to the same allocation: never set for an operand's last row of a buffer) — what
+                           // is read there only reaches output entries that are not stored, and a ragged edge tile then runs the
+                           // lean staging path instead of the predicated one (measured 367 -> ~250 us per K = 1024 tile)
 };
 // variant: 0 = NT (A[m][k], B[n][k]), 1 = NN (A[m][k], B[k][n]), 2 = TN (A[k][m], B[k][n])
 // tile_m = 0: choose a square tile from the grid size; else force the work-group tile (128x128, 64x64, 32x32, 128x32)
@@ -155,6 +159,7 @@ struct ExecLaunch {
   int32_t* info;
   long long budget;        // ticks of the 100 MHz constant clock a single wait may take
   int worker_base;
+  unsigned long long* trace;  // debug (tools/exec_trace.py): 3 stamps of the 100 MHz clock per task — fetched, waits over, done — or null
 };
 hipError_t gpp_launch_exec(hipStream_t s, int nworkers, const ExecLaunch& e);
 // one-wave kernels on a stream: wait until counters[id] >= target (same budget / abort rules), and counters[id] += 1
@@ -166,7 +171,9 @@ hipError_t gpp_launch_exec_signal(hipStream_t s, int* counters, int id);
 struct PotrfExecTuning {
   double t_tile;    // us a worker needs for one K = nb update tile
   double t_block;   // us of a step during which the panel's CUs are NOT available to the filler (gate, panel, hand-offs)
-  int solve_pos;    // update tiles of step k a worker runs before its share of block row k+1's solve
+  int solve_pos;    // bulk tiles of phase 0 a worker runs before its share of block row 1's solve (the first panel is not hidden)
+  int solve_pos_later;  // the same for the later phases (their diagonal block was factored during the previous phase)
+  double la_frac;   // fraction of a phase's bulk tiles a worker runs before its look-ahead tasks (step k+1 on block row k+2)
   int fill;         // 0: no filler launches
 };
 struct PotrfExecPlan {
@@ -179,12 +186,15 @@ struct PotrfExecPlan {
   std::vector<ExecTask> tasks;
   std::vector<int32_t> offsets;       // [W] main workers, then [K][max(F,1)] filler work-groups
   std::vector<int> fill_workers;      // per step: work-groups of the filler launch (0: none)
+  struct Op { int kind, arg; };       // the panel stream's launches in order: 0 gate(b) 1 panel(b) 2 signal(b) 3 filler launch(step)
+  std::vector<Op> stream_ops;
   std::vector<int> gate_target;       // per diagonal block b >= 1: update tiles of step b-1 inside it (the panel's gate)
   int ncounters = 0;
   GemmArgs* d_groups = nullptr;
   ExecTask* d_tasks = nullptr;
   int32_t* d_offsets = nullptr;
   int* d_counters = nullptr;
+  unsigned long long* d_trace = nullptr;  // 3 * tasks.size() stamps when tracing is switched on (gpp_debug_exec_trace)
 };
 PotrfExecPlan* gpp_plan_potrf_exec(int64_t N, int64_t nb, int K, int W, int F, const PotrfExecTuning& tune);
 void gpp_plan_bind(PotrfExecPlan* P, double* A, int64_t ld, double* Li, int64_t ldi, double* T, int64_t ldt);

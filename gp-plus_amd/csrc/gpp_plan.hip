@@ -82,6 +82,7 @@ void gpp_plan_bind(PotrfExecPlan* P, double* A, int64_t ld, double* Li, int64_t 
     s.M = (int)nb; s.N = (int)rem; s.K = (int)nb;
     s.alpha = 1.0; s.beta = 0.0;
     s.a_mask = 1; s.khi_mode = 1;
+    s.pad_ok = 1;  // (rows o .. o+nb-1 of A with o + nb < N: reading past column N stays inside the buffer)
     P->groups[3 * k] = s;
     GemmArgs u{};  // U(k): A[c0.., c0..) -= T[o.., c0..)^T T[o.., c0..), upper triangle
     u.A = T + o * ldt + c0; u.lda = ldt;
@@ -90,6 +91,7 @@ void gpp_plan_bind(PotrfExecPlan* P, double* A, int64_t ld, double* Li, int64_t 
     u.M = u.N = (int)rem; u.K = (int)nb;
     u.alpha = -1.0; u.beta = 1.0;
     u.c_lower = 2;
+    u.pad_ok = 1;  // (rows o .. o+nb-1 of T, never the buffer's last row)
     P->groups[3 * k + 1] = u;
     GemmArgs c{};  // CP(k): A[o.., c0..) = T[o.., c0..)
     c.B = T + o * ldt + c0; c.ldb = ldt;
@@ -107,10 +109,23 @@ void gpp_plan_free(PotrfExecPlan* P) {
   if (P->d_tasks) (void)hipFree(P->d_tasks);
   if (P->d_offsets) (void)hipFree(P->d_offsets);
   if (P->d_counters) (void)hipFree(P->d_counters);
+  if (P->d_trace) (void)hipFree(P->d_trace);
   delete P;
 }
 
 // Builds the task lists (pointer independent).  W main workers, F filler work-groups per step (0: no filler), K steps.
+//
+// Order of a main worker's list — ONE step of look-ahead, as in the launch-per-product driver: while the bulk of step k's update
+// (rows below block row k+2) runs, the worker also (1) solves its share of block row k+1 — whose diagonal block the panel stream
+// factored during the PREVIOUS phase —, (2) applies step k+1's update to its tiles of block row k+2, which completes that block
+// row and releases the panel of diagonal block k+2.  Every counter a task waits for is therefore raised about half a phase before
+// it is needed, and a worker that runs ahead or behind by less than that never stalls:
+//   prologue : S(0) share, U(0) on block row 1
+//   phase k  : bulk[0, ps) | S(k+1) share | bulk[ps, pl) | U(k+1) on block row k+2 | bulk[pl, ...) | CP(k) share
+// (bulk = the worker's U(k) tiles in rows >= block row k+2 in row-major order, so its tiles of block row k+2 come first: they
+// precede the look-ahead tasks on the same tiles.)  Panel stream: panel(0), signal, gate(1), panel(1), signal, gate(2), panel(2),
+// signal, F(0), gate(3), panel(3), signal, F(1), ...: the filler launch F(k) — step k's update of the bottom rows — follows the
+// diagonal block k+2 and ends before block k+3 is due.
 PotrfExecPlan* gpp_plan_potrf_exec(int64_t N, int64_t nb, int K, int W, int F, const PotrfExecTuning& tune) {
   if (nb % GPP_TILE != 0 || K < 1 || W < 1 || (int64_t)K * nb >= N) return nullptr;
   const int bt = (int)(nb / GPP_TILE);
@@ -118,6 +133,7 @@ PotrfExecPlan* gpp_plan_potrf_exec(int64_t N, int64_t nb, int K, int W, int F, c
   if (nt >= 32000) return nullptr;  // tile coordinates are 16-bit
   auto tix = [&](int64_t i, int64_t j) -> int64_t { return i * nt - i * (i - 1) / 2 + (j - i); };
   const int64_t total = (int64_t)nt * (nt + 1) / 2;
+  const int Fs = std::max(F, 1);
 
   PotrfExecPlan* P = new PotrfExecPlan();
   P->N = N; P->nb = nb; P->K = K; P->W = W; P->F = F;
@@ -125,117 +141,120 @@ PotrfExecPlan* gpp_plan_potrf_exec(int64_t N, int64_t nb, int K, int W, int F, c
   P->gate_target.assign(K + 2, 0);
   P->fill_workers.assign(K, 0);
 
-  std::vector<Builder> main(W);
-  std::vector<Builder> fill((size_t)K * std::max(F, 1));
+  struct Proto { int group, tm, tn, w0, v0, w1, v1, i0, i1, row; };
+  std::vector<std::vector<std::vector<Proto>>> pS(K), pLA(K), pBulk(K), pCP(K);  // [step][worker]
+  std::vector<Builder> fill((size_t)K * Fs);
   std::vector<int> hr(K + 2, 0), rr(K + 2, 0), sh(K + 2, 0), sa(K + 2, 0), fd(K + 2, 0);
   std::vector<int64_t> endk(K + 1, total);
   int next_s = 0, next_c = 0;
 
-  // S(b) tasks, dealt round-robin: head columns (those of diagonal block b+1) first, longest K (last row tile) first
-  struct STask { int r, c; bool head; };
-  auto solve_tasks = [&](int b) {
-    std::vector<STask> v;
-    const int c_lo = bt * (b + 1);
-    for (int pass = 0; pass < 2; ++pass)
-      for (int r = bt - 1; r >= 0; --r)
-        for (int c = c_lo; c < nt; ++c) {
-          const bool head = c < c_lo + bt;
-          if (head == (pass == 0)) v.push_back({r, c, head});
-        }
-    return v;
-  };
-  auto emit_solves = [&](int b, std::vector<std::vector<ExecTask>>* into /* per worker, or null: append */) {
-    const auto v = solve_tasks(b);
-    for (auto& s : v) {
-      sa[b] += 1;
-      if (s.head) sh[b] += 1;
-    }
-    for (auto& s : v) {
-      Builder& wk = main[next_s];
-      const size_t before = wk.list.size();
-      wk.add(3 * b, s.r, s.c - bt * (b + 1), cid(b, C_PD), 1, b > 0 ? cid(b, s.head ? C_HR : C_RR) : -1,
-             b > 0 ? (s.head ? hr[b] : rr[b]) : 0, cid(b, C_SA), s.head ? cid(b, C_SH) : -1);
-      if (into) {  // the caller places the task inside the worker's step list
-        (*into)[next_s].push_back(wk.list.back());
-        wk.list.resize(before);
-      }
-      next_s = (next_s + 1) % W;
-    }
-  };
-
-  emit_solves(0, nullptr);
   for (int k = 0; k < K; ++k) {
     const int lo = bt * (k + 1);
+    pS[k].assign(W, {});
+    pLA[k].assign(W, {});
+    pBulk[k].assign(W, {});
+    pCP[k].assign(W, {});
+    // the classes of step k's tiles inside block row k+1 (targets of the counters that release block k+1's solve and panel)
+    int g1 = 0, h = 0, r = 0;
+    for (int i = lo; i < std::min(lo + bt, nt); ++i)
+      for (int j = i; j < nt; ++j) {
+        if (j < lo + bt) ++g1; else if (j < lo + 2 * bt) ++h; else ++r;
+      }
+    P->gate_target[k + 1] = g1;
+    hr[k + 1] = h;
+    rr[k + 1] = r;
+    // S(k): head columns (those of diagonal block k+1) first, longest K (last row tile) first, dealt round-robin
+    for (int pass = 0; pass < 2; ++pass)
+      for (int rt = bt - 1; rt >= 0; --rt)
+        for (int c = lo; c < nt; ++c) {
+          const bool head = c < lo + bt;
+          if (head != (pass == 0)) continue;
+          sa[k] += 1;
+          if (head) sh[k] += 1;
+          pS[k][next_s].push_back({3 * k, rt, c - lo, cid(k, C_PD), 1, k > 0 ? cid(k, head ? C_HR : C_RR) : -1,
+                                   k > 0 ? (head ? hr[k] : rr[k]) : 0, cid(k, C_SA), head ? cid(k, C_SH) : -1, 0});
+          next_s = (next_s + 1) % W;
+        }
+    // filler share of this step: m tiles per filler work-group, taken from the END of the row-major order (the bottom rows)
     const int64_t start = tix(lo, lo), n_act = total - start;
-    // filler share of this step (see the header comment): m tiles per filler work-group
-    int64_t e = k > 0 ? endk[k - 1] : total;
+    int64_t e = total;
     if (F > 0 && tune.fill) {
       const double t_main = (double)n_act * tune.t_tile / W;
       int64_t m = (int64_t)((t_main - tune.t_block) / (tune.t_tile * (1.0 + (double)F / W)));
       m = std::max<int64_t>(m, 0);
-      const int64_t first_ok = (int64_t)bt * (k + 3) < nt ? tix((int64_t)bt * (k + 3), (int64_t)bt * (k + 3)) : total;
-      int64_t want = std::max(total - (int64_t)F * m, first_ok);
+      // never a tile of the next three block rows: those are on the look-ahead's path within a phase
+      const int64_t first_ok = (int64_t)bt * (k + 4) < nt ? tix((int64_t)bt * (k + 4), (int64_t)bt * (k + 4)) : total;
+      const int64_t want = std::max(total - (int64_t)F * m, first_ok);
       e = k > 0 ? std::max(endk[k - 1], want) : want;
-    } else {
-      e = total;
     }
     endk[k] = e;
     fd[k] = (int)(total - e);
     P->fill_workers[k] = (int)std::min<int64_t>(F, total - e);
-
-    // counts of this step's chain classes (targets of the counters the next block's solves / panel wait for)
-    int g1 = 0, h = 0, r = 0;
-    struct Item { int cls; int64_t t; int i, j; };
-    std::vector<std::vector<Item>> items(W);
     for (int i = lo; i < nt; ++i)
       for (int j = i; j < nt; ++j) {
         const int64_t t = tix(i, j);
         int cls = 3;
         if (i < lo + bt) cls = j < lo + bt ? 0 : (j < lo + 2 * bt ? 1 : 2);
-        if (cls == 0) ++g1; else if (cls == 1) ++h; else if (cls == 2) ++r;
         if (t >= e) {
-          Builder& fw = fill[(size_t)k * std::max(F, 1) + (size_t)((t - e) % F)];
-          fw.add(3 * k + 1, i - lo, j - lo, cid(k, C_SA), sa[k], -1, 0, cid(k, C_FD), -1);
-        } else {
-          items[(size_t)(t % W)].push_back({cls, t, i, j});
+          fill[(size_t)k * Fs + (size_t)((t - e) % F)].add(3 * k + 1, i - lo, j - lo, cid(k, C_SA), sa[k], -1, 0, cid(k, C_FD), -1);
+          continue;
         }
+        const int inc = cls == 0 ? cid(k + 1, C_G1D) : cls == 1 ? cid(k + 1, C_HR) : cls == 2 ? cid(k + 1, C_RR) : -1;
+        const bool handed_back = k > 0 && t >= endk[k - 1] && fd[k - 1] > 0;
+        Proto pr{3 * k + 1, i - lo, j - lo, cid(k, cls == 0 ? C_SH : C_SA), cls == 0 ? sh[k] : sa[k],
+                 handed_back ? cid(k - 1, C_FD) : -1, handed_back ? fd[k - 1] : 0, inc, -1, i};
+        (cls < 3 ? pLA[k] : pBulk[k])[(size_t)(t % W)].push_back(pr);  // (row-major enumeration: already sorted by t; LA by class below)
       }
-    P->gate_target[k + 1] = g1;
-    hr[k + 1] = h;
-    rr[k + 1] = r;
-    // S(k+1) tasks, placed inside each worker's step list (after `ps` update tiles: by then the panel has factored block k+1)
-    std::vector<std::vector<ExecTask>> solves(W);
-    if (k + 1 < K) emit_solves(k + 1, &solves);
-    for (int w = 0; w < W; ++w) {
-      auto& it = items[w];
-      std::sort(it.begin(), it.end(), [](const Item& a, const Item& b) { return a.cls != b.cls ? a.cls < b.cls : a.t < b.t; });
-      Builder& wk = main[w];
-      const size_t ps = std::min<size_t>(it.size(), (size_t)tune.solve_pos);
-      auto put_solves = [&]() {
-        for (auto& s : solves[w]) {
-          // (the waits were chosen against this worker's knowledge when the task was created; learn() has recorded them)
-          wk.list.push_back(s);
-        }
-      };
-      for (size_t q = 0; q < it.size(); ++q) {
-        if (q == ps) put_solves();
-        const Item& x = it[q];
-        const int inc = x.cls == 0 ? cid(k + 1, C_G1D) : x.cls == 1 ? cid(k + 1, C_HR) : x.cls == 2 ? cid(k + 1, C_RR) : -1;
-        const bool handed_back = k > 0 && x.t >= endk[k - 1] && fd[k - 1] > 0;
-        wk.add(3 * k + 1, x.i - lo, x.j - lo, cid(k, x.cls == 0 ? C_SH : C_SA), x.cls == 0 ? sh[k] : sa[k],
-               handed_back ? cid(k - 1, C_FD) : -1, handed_back ? fd[k - 1] : 0, inc, -1);
-      }
-      if (ps >= it.size()) put_solves();
-    }
-    // CP(k): the factor's block row into place, dealt round-robin behind the step's updates
+    for (int w = 0; w < W; ++w)
+      std::stable_sort(pLA[k][w].begin(), pLA[k][w].end(), [&](const Proto& a, const Proto& b) {
+        auto cls = [&](const Proto& x) { return x.tn + lo < lo + bt ? 0 : (x.tn + lo < lo + 2 * bt ? 1 : 2); };
+        return cls(a) < cls(b);
+      });
+    // CP(k): the factor's block row into place, dealt round-robin
     for (int c = lo; c < nt; ++c) {
-      main[next_c].add(3 * k + 2, 0, c - lo, cid(k, C_SA), sa[k], -1, 0, -1, -1);
+      pCP[k][next_c].push_back({3 * k + 2, 0, c - lo, cid(k, C_SA), sa[k], -1, 0, -1, -1, 0});
       next_c = (next_c + 1) % W;
     }
   }
 
+  std::vector<Builder> main(W);
+  auto put = [&](Builder& b, const Proto& p) { b.add(p.group, p.tm, p.tn, p.w0, p.v0, p.w1, p.v1, p.i0, p.i1); };
+  for (int w = 0; w < W; ++w) {
+    Builder& b = main[w];
+    for (auto& p : pS[0][w]) put(b, p);
+    for (auto& p : pLA[0][w]) put(b, p);
+    for (int k = 0; k < K; ++k) {
+      const auto& bulk = pBulk[k][w];
+      const size_t len = bulk.size();
+      size_t n_a0 = 0;  // bulk tiles of block row k+2: the look-ahead tasks on the same tiles come after them
+      while (n_a0 < len && bulk[n_a0].row < bt * (k + 2) + bt) ++n_a0;
+      size_t ps = std::min<size_t>(len, (size_t)(k == 0 ? tune.solve_pos : tune.solve_pos_later));
+      size_t pl = std::max<size_t>(std::max(n_a0, ps), (size_t)(len * tune.la_frac));
+      pl = std::min(pl, len);
+      size_t q = 0;
+      for (; q < ps; ++q) put(b, bulk[q]);
+      if (k + 1 < K)
+        for (auto& p : pS[k + 1][w]) put(b, p);
+      for (; q < pl; ++q) put(b, bulk[q]);
+      if (k + 1 < K)
+        for (auto& p : pLA[k + 1][w]) put(b, p);
+      for (; q < len; ++q) put(b, bulk[q]);
+      for (auto& p : pCP[k][w]) put(b, p);
+    }
+  }
+
+  // the panel stream: diagonal blocks 0 .. K (block K is where the launch-per-product steps take over), each behind its gate,
+  // each but the last followed by its signal; the filler launch of step k follows diagonal block k+2, the last ones close the stream
+  for (int b = 0; b <= K; ++b) {
+    if (b > 0) P->stream_ops.push_back({0, b});
+    P->stream_ops.push_back({1, b});
+    if (b < K) P->stream_ops.push_back({2, b});
+    if (b >= 2 && P->fill_workers[b - 2] > 0) P->stream_ops.push_back({3, b - 2});
+  }
+  if (K >= 1 && P->fill_workers[K - 1] > 0) P->stream_ops.push_back({3, K - 1});
+
   // flatten
-  P->offsets.assign((size_t)W + (size_t)K * std::max(F, 1), 0);
+  P->offsets.assign((size_t)W + (size_t)K * Fs, 0);
   ExecTask endt{};
   endt.group = GPP_EXEC_END;
   endt.wait_id[0] = endt.wait_id[1] = endt.inc_id[0] = endt.inc_id[1] = -1;
@@ -245,9 +264,9 @@ PotrfExecPlan* gpp_plan_potrf_exec(int64_t N, int64_t nb, int K, int W, int F, c
     P->tasks.push_back(endt);
   }
   for (int k = 0; k < K; ++k)
-    for (int f = 0; f < std::max(F, 1); ++f) {
-      P->offsets[(size_t)W + (size_t)k * std::max(F, 1) + f] = (int32_t)P->tasks.size();
-      auto& l = fill[(size_t)k * std::max(F, 1) + f].list;
+    for (int f = 0; f < Fs; ++f) {
+      P->offsets[(size_t)W + (size_t)k * Fs + f] = (int32_t)P->tasks.size();
+      auto& l = fill[(size_t)k * Fs + f].list;
       P->tasks.insert(P->tasks.end(), l.begin(), l.end());
       P->tasks.push_back(endt);
     }
@@ -285,10 +304,23 @@ hipError_t gpp_plan_upload(PotrfExecPlan* P) {
 // of a factored block row, an update reads completely solved strips, a diagonal block is fully updated when its panel starts, and
 // everything is complete at the end.  Returns 0, or a positive code naming the first violation (stats[0..3]: tasks run, waits
 // carried, increments, largest number of tiles a filler work-group runs in one step).
-extern "C" int gpp_debug_plan_check(int64_t N, int64_t nb, int K, int W, int F, int fill, int solve_pos, unsigned seed, int64_t* stats) {
-  PotrfExecTuning tune{275.0, 800.0, solve_pos, fill};
+// `mutate` > 0 removes the mutate-th wait of the plan first: the check must then FAIL (the test of the test).
+extern "C" int gpp_debug_plan_check(int64_t N, int64_t nb, int K, int W, int F, int fill, int solve_pos, unsigned seed, int64_t* stats,
+                                    int mutate) {
+  PotrfExecTuning tune{275.0, 800.0, solve_pos, 0, 0.4, fill};
   PotrfExecPlan* P = gpp_plan_potrf_exec(N, nb, K, W, F, tune);
   if (!P) return 1;
+  int mutated = -1;  // what was removed: 100 * task kind + 10 * (filler list) + counter kind
+  if (mutate > 0) {
+    int seen = 0;
+    for (auto& t : P->tasks)
+      for (int q = 0; q < 2 && mutate > 0; ++q)
+        if (t.group >= 0 && t.wait_id[q] >= 0 && ++seen == mutate) {
+          mutated = 100 * (t.group % 3) + (t.wait_id[q] - 1) % 8 + 10 * ((&t - P->tasks.data()) >= P->offsets[W] ? 1 : 0);
+          t.wait_id[q] = -1;
+          mutate = 0;
+        }
+  }
   gpp_plan_bind(P, nullptr, 0, nullptr, 0, nullptr, 0);
   const int bt = (int)(nb / GPP_TILE), nt = (int)((N + GPP_TILE - 1) / GPP_TILE), Fs = std::max(F, 1);
   auto tix = [&](int64_t i, int64_t j) -> int64_t { return i * nt - i * (i - 1) / 2 + (j - i); };
@@ -337,33 +369,44 @@ extern "C" int gpp_debug_plan_check(int64_t N, int64_t nb, int K, int W, int F, 
   };
   std::vector<int64_t> pos(W);  // main workers' positions
   for (int w = 0; w < W; ++w) pos[w] = P->offsets[w];
-  // panel stream: ops in order; a filler launch is a set of positions that all have to reach their end
-  int pb = 0, pstage = 0;  // block b, stage 0 gate, 1 panel+signal, 2 filler of step b-1
+  // panel stream: the plan's launches in order; a filler launch is a set of positions that all have to reach their end
+  size_t op = 0;
+  bool in_fill = false;
   std::vector<int64_t> fpos;
-  bool stream_done = false;
+  bool stream_done = P->stream_ops.empty();
   auto stream_step = [&]() -> bool {  // true when the stream made progress
     if (stream_done) return false;
-    if (pstage == 0) {
-      if (pb > 0 && counters[gpp_plan_counter(pb, 1)] < P->gate_target[pb]) return false;
-      pstage = 1;
+    const PotrfExecPlan::Op o = P->stream_ops[op];
+    auto next = [&]() {
+      if (++op == P->stream_ops.size()) stream_done = true;
       return true;
+    };
+    if (o.kind == 0) {
+      if (counters[gpp_plan_counter(o.arg, 1)] < P->gate_target[o.arg]) return false;
+      return next();
     }
-    if (pstage == 1) {
+    if (o.kind == 1) {
+      const int pb = o.arg;
       for (int i = bt * pb; i < std::min(bt * (pb + 1), nt); ++i)
         for (int j = i; j < std::min(bt * (pb + 1), nt); ++j)
           if (version[tix(i, j)] != pb) rc = rc ? rc : 40;
       panel_done[pb] = 1;
-      if (pb < K) ++counters[gpp_plan_counter(pb, 0)];
-      pstage = 2;
+      return next();
+    }
+    if (o.kind == 2) {
+      if (!panel_done[o.arg]) rc = rc ? rc : 41;
+      ++counters[gpp_plan_counter(o.arg, 0)];
+      return next();
+    }
+    if (!in_fill) {
+      in_fill = true;
       fpos.clear();
-      if (pb >= 1 && P->fill_workers[pb - 1] > 0)
-        for (int f = 0; f < P->fill_workers[pb - 1]; ++f) fpos.push_back(P->offsets[(size_t)W + (size_t)(pb - 1) * Fs + f]);
+      for (int f = 0; f < P->fill_workers[o.arg]; ++f) fpos.push_back(P->offsets[(size_t)W + (size_t)o.arg * Fs + f]);
       for (auto q : fpos) {
         int64_t n = 0;
         while (P->tasks[q + n].group >= 0) ++n;
         fill_max = std::max(fill_max, n);
       }
-      return true;
     }
     // filler launch: advance a random work-group that can run
     bool any_left = false, progressed = false;
@@ -378,24 +421,26 @@ extern "C" int gpp_debug_plan_check(int64_t N, int64_t nb, int K, int W, int F, 
       }
     }
     if (!any_left) {
-      if (pb == K) stream_done = true;
-      ++pb;
-      pstage = 0;
-      return true;
+      in_fill = false;
+      return next();
     }
     return progressed;
   };
+  // Interleavings by seed & 3: 0 random; 1 random with a LAZY panel stream (it only moves when no worker can: a solve that does not
+  // wait for its panel runs too early); 2 / 3 lazy stream and a fixed worker priority, descending / ascending (the other end of the
+  // grid lags as far behind as the counters allow).
+  const int mode = (int)(seed & 3u);
   int64_t idle_rounds = 0;
   for (;;) {
     bool all_done = stream_done;
     bool progressed = false;
-    if (rnd() % 8 == 0) progressed = stream_step();
-    const int w0 = (int)(rnd() % W), burst = 1 + (int)(rnd() % 3);
+    if (mode == 0 && rnd() % 8 == 0) progressed = stream_step();
+    // bursts of 1-3 tasks mostly, now and then a worker runs as far ahead as its waits allow (what exposes a missing wait)
+    const int w0 = mode >= 2 ? 0 : (int)(rnd() % W), burst = (mode >= 2 || rnd() % 16 == 0) ? (1 << 30) : 1 + (int)(rnd() % 3);
     for (int q = 0; q < W; ++q) {
-      const int w = (w0 + q) % W;
+      const int w = mode == 2 ? W - 1 - q : (w0 + q) % W;
       if (P->tasks[pos[w]].group < 0) continue;
       all_done = false;
-      if (progressed && q > 0) break;
       for (int b = 0; b < burst && P->tasks[pos[w]].group >= 0 && try_task(P->tasks[pos[w]]); ++b) {
         ++pos[w];
         progressed = true;
@@ -427,7 +472,7 @@ extern "C" int gpp_debug_plan_check(int64_t N, int64_t nb, int K, int W, int F, 
     stats[0] = ran;
     stats[1] = waits;
     stats[2] = incs;
-    stats[3] = fill_max;
+    stats[3] = mutated >= 0 ? mutated : fill_max;
   }
   gpp_plan_free(P);
   return rc;

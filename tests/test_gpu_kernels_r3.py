@@ -357,6 +357,48 @@ def test_panel_inside_the_lookahead_reports_the_failing_minor(gpu_ctx):
     assert int(info.item()) == 1301
 
 
+def test_static_schedule_matches_the_launch_per_product_driver(gpu_ctx):
+    """gpp_potrf_ws above the bordering range: the throughput-bound steps as ONE statically scheduled persistent launch (gpp_exec_f64,
+    planned by gpp_plan.hip) against the same steps as launches per product (GPP_OPT_EXEC_SCHED = 0): same factor and inverse to
+    rounding, both against scipy; and a bad pivot inside the scheduled steps is reported as the failing leading minor (the launch
+    runs to its end on whatever the panel left: no counter waits on a value)."""
+    import scipy.linalg as sla
+
+    from gpplus_amd.backend import OPT_EXEC_SCHED
+
+    n = 13500
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((n, 6)) * np.sqrt(0.3)
+    G = X @ X.T
+    sq = np.diag(G)
+    K = np.exp(-np.maximum(sq[:, None] + sq[None, :] - 2 * G, 0.0)) + 2e-3 * np.eye(n)
+    del G
+    Kd = _dev(np.triu(K))
+    A, Li, T = _sq(n), _sq(n, 0.0), _sq(n)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    res = {}
+    try:
+        for on in (0, 1):
+            gpu_ctx.set_option(OPT_EXEC_SCHED, on)
+            A.copy_(Kd); Li.zero_()
+            gpu_ctx.potrf(A, Li, info, T)
+            gpu_ctx.trtri(A, Li, T)
+            assert int(info.item()) == 0
+            res[on] = (torch.triu(A).clone(), torch.tril(Li).clone())
+        scale = float(res[0][0].abs().max())
+        assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-12 * scale
+        assert float((res[0][1] - res[1][1]).abs().max()) <= 1e-10 * float(res[0][1].abs().max())
+        Lref = sla.cholesky(K, lower=True)
+        np.testing.assert_allclose(res[1][0].cpu().numpy().T, Lref, rtol=0, atol=1e-11 * scale)
+        del Lref
+        K[2500, 2500] = -5.0  # third diagonal block, inside the scheduled steps
+        A.copy_(_dev(np.triu(K)))
+        gpu_ctx.potrf(A, Li, info, T)
+        assert int(info.item()) == 2501
+    finally:
+        gpu_ctx.set_option(OPT_EXEC_SCHED, 1)
+
+
 def test_panel_timeout_is_recovered_by_the_host(gpu_ctx):
     """GPP_OPT_PANEL_FAULT makes the next panel launch report the time-out status (what a wait inside the kernel reports after ~1 s
     when another tenant of the GPU holds part of its CUs).  The C ABI returns it in ``info``; ``linalg`` switches the panel off for
