@@ -362,7 +362,7 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   {
     static const bool exec_env = !(getenv("GPP_EXEC_SCHED") && atoi(getenv("GPP_EXEC_SCHED")) == 0);                 // knobs
     static const int64_t exec_min_rem = getenv("GPP_EXEC_MIN_REM") ? atol(getenv("GPP_EXEC_MIN_REM")) : 5500;
-    static const int64_t exec_max_n = getenv("GPP_EXEC_MAX_N") ? atol(getenv("GPP_EXEC_MAX_N")) : 66000;
+    static const int64_t exec_max_n = getenv("GPP_EXEC_MAX_N") ? atol(getenv("GPP_EXEC_MAX_N")) : 40000;  // (N = 60000: 1154 vs 1143 ms — the unmasked bulk of long launches wins there)
     const int K = (int)((N - exec_min_rem) / NB);
     if (exec_env && h->exec_sched && h->coop_panel && T && N > border_max_x && N <= exec_max_n && !env_nb && h->cu_split == 1 &&
         NB % NBLK == 0 && panel_fits(h, NB) && K >= 2) {
