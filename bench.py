@@ -445,6 +445,20 @@ def run_sharded(args, dist, dev, rank, world, n, steps, warmup):
     elapsed, loss = _bracket(dist, dev, lambda: run_steps(steps))
     events, linalg.STAGE_EVENTS = (linalg.STAGE_EVENTS or []), None
     out = None
+    # what a reader needs to see that the collective backend really formed `world` ranks on `world` devices, and what each holds
+    from gpplus_amd import sharded as _sh0
+    mine = {"rank": rank, "device": int(torch.cuda.current_device()),
+            "matrix_gb": round(sum(w.nbytes() for w in _sh0._workspaces.values()) / 1e9, 3)}
+    ranks = [mine]
+    rccl = None
+    if dist is not None and dist.is_initialized():
+        ranks = [None] * dist.get_world_size()
+        dist.all_gather_object(ranks, mine)
+        if dist.get_backend() == "nccl":
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception as e:  # (reported, not fatal: the line still says which backend ran)
+                rccl = f"unknown ({type(e).__name__})"
     if rank == 0:
         stage_ms, stage_rate = _stage_table(events, n, share=world)
         per_gpu_tf = n ** 3 / (elapsed / steps) / 1e12 / world
@@ -455,7 +469,9 @@ def run_sharded(args, dist, dev, rank, world, n, steps, warmup):
                "config": {"workload": f"{cfg_name}: synthetic N={n} d={D} fp64 exact GP, kernel build + blocked Cholesky + "
                                       f"inverse + gradient sharded block-cyclically (nb={args.nb}) over {world} GPU(s), "
                                       "RCCL broadcasts of factor / inverse slabs", "N": n, "d": D, "nb": args.nb,
-                          "loss": float(loss.item()), "backend": "none" if dist is None else dist.get_backend()},
+                          "loss": float(loss.item()), "backend": "none" if dist is None else dist.get_backend(),
+                          "world": 1 if dist is None else dist.get_world_size(), "rccl_version": rccl, "ranks": ranks,
+                          "full_matrix_gb": round(8e-9 * n * n, 3)},
                "roofline": {"bound": "mfma", "kernel": "whole sharded evaluation, N^3 flop / (time x GPUs)",
                             "achieved": per_gpu_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
                             "frac": per_gpu_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": None},

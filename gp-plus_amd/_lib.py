@@ -40,12 +40,12 @@ _SIGNATURES = {
     "gpp_lauum": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64]),
     "gpp_syrk_rows": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_int64, c_int64, c_int, c_int]),
     "gpp_gemm_lower_cols": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int64, c_double,
-                                    c_double, c_int64, c_int64, c_int, c_int, c_int64, c_int64]),
-    "gpp_trmv_lower_cols": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int]),
+                                    c_double, c_int64, c_int64, c_int, c_int, c_int64, c_int64, c_int]),
+    "gpp_trmv_lower_cols": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int]),
     "gpp_mll_scalars": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "gpp_grad_reduce_cols": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                      c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_int, c_void_p, c_void_p, c_void_p,
-                                     c_void_p]),
+                                     c_void_p, c_int]),
     "gpp_lauum_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int]),
     "gpp_lauum_rows_range": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_int64]),
     "gpp_transpose": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p, c_int64]),

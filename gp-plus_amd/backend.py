@@ -232,27 +232,32 @@ class GppContext:
                                      first_block, rank, nranks), "gpp_syrk_rows")
 
     @_on_own_device
-    def gemm_lower_cols(self, A, B, C, alpha, beta, nb, first_block, rank, nranks, row0=0, row1=None):
+    def gemm_lower_cols(self, A, B, C, alpha, beta, nb, first_block, rank, nranks, row0=0, row1=None, compact=False):
         """C(lower, owned column blocks of width nb) = beta C + alpha A^T B;  A, B: K x M row-contiguous, C: M x M; rows
-        [row0, row1) of C only."""
-        if A.shape != B.shape or C.shape[0] != C.shape[1] or C.shape[0] != A.shape[1]:
+        [row0, row1) of C only.  ``compact``: B (K rows) and C (M rows) hold only the owned column blocks, side by side."""
+        M, K = A.shape[1], A.shape[0]
+        if compact:
+            if B.shape[0] != K or C.shape[0] != M:
+                raise GppError("gemm_lower_cols: shapes do not match")
+        elif A.shape != B.shape or C.shape[0] != C.shape[1] or C.shape[0] != M:
             raise GppError("gemm_lower_cols: shapes do not match")
         self._stream()
-        check(self.lib.gpp_gemm_lower_cols(self.h, A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), C.data_ptr(), _ld(C), C.shape[0],
-                                           A.shape[0], float(alpha), float(beta), nb, first_block, rank, nranks, row0,
-                                           C.shape[0] if row1 is None else row1),
+        check(self.lib.gpp_gemm_lower_cols(self.h, A.data_ptr(), _ld(A), B.data_ptr(), _ld(B), C.data_ptr(), _ld(C), M,
+                                           K, float(alpha), float(beta), nb, first_block, rank, nranks, row0,
+                                           M if row1 is None else row1, 1 if compact else 0),
               "gpp_gemm_lower_cols")
 
     @_on_own_device
-    def trmv_lower_cols(self, T, x, y, nb, rank, nranks, trans=False):
-        """y = (owned column blocks of lower T) x, or their transpose times x on the owned entries (0 elsewhere)."""
+    def trmv_lower_cols(self, T, x, y, nb, rank, nranks, trans=False, compact=False):
+        """y = (owned column blocks of lower T) x, or their transpose times x on the owned entries (0 elsewhere).
+        ``compact``: T (N rows) holds only the owned column blocks, side by side."""
         for t, n in ((x, "x"), (y, "y")):
             _need(t, torch.float64, n)
         if trans:
             self.ensure_workspace(OP_MLL_EVAL, T.shape[0], 0, 1, 1)
         self._stream()
         check(self.lib.gpp_trmv_lower_cols(self.h, T.data_ptr(), _ld(T), T.shape[0], x.data_ptr(), y.data_ptr(), nb, rank, nranks,
-                                           1 if trans else 0), "gpp_trmv_lower_cols")
+                                           1 if trans else 0, 1 if compact else 0), "gpp_trmv_lower_cols")
 
     @_on_own_device
     def mll_scalars(self, U, z, out3):
@@ -324,8 +329,9 @@ class GppContext:
 
     @_on_own_device
     def grad_reduce_cols(self, U, w, sf2, grp, S, alpha, Kinv, dU, nb, rank, nranks, g_w, g_sf2, g_tau, g_U, *,
-                         kind=KIND_RBF, d_split=0):
-        """Partial sums over the COLUMN blocks of Kinv's lower triangle owned by ``rank`` (block-cyclic, width ``nb``)."""
+                         kind=KIND_RBF, d_split=0, compact=False):
+        """Partial sums over the COLUMN blocks of Kinv's lower triangle owned by ``rank`` (block-cyclic, width ``nb``).
+        ``compact``: Kinv (N rows) holds only the owned column blocks, side by side."""
         N, D = U.shape
         if grp is not None:
             self._check_groups(grp, N, S)
@@ -333,7 +339,7 @@ class GppContext:
         self._stream()
         check(self.lib.gpp_grad_reduce_cols(self.h, U.data_ptr(), N, D, w.data_ptr(), sf2.data_ptr(), _ptr(grp), S, kind,
                                             d_split, alpha.data_ptr(), Kinv.data_ptr(), _ld(Kinv), dU, nb, rank, nranks,
-                                            g_w.data_ptr(), g_sf2.data_ptr(), g_tau.data_ptr(), _ptr(g_U)),
+                                            g_w.data_ptr(), g_sf2.data_ptr(), g_tau.data_ptr(), _ptr(g_U), 1 if compact else 0),
               "gpp_grad_reduce_cols")
 
     @_on_own_device

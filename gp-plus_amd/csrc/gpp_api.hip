@@ -639,6 +639,14 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   return hipSuccess;
 }
 
+// columns of a buffer that holds only the block-cyclically owned column blocks of an N x N matrix, side by side
+inline int64_t owned_cols(int64_t N, int64_t nb, int rank, int nranks) {
+  const int64_t nblk = (N + nb - 1) / nb;
+  int64_t cols = 0;
+  for (int64_t b = rank; b < nblk; b += nranks) cols += std::min(nb, N - b * nb);
+  return cols;
+}
+
 int check_mat(const void* p, int64_t ld, int64_t n, int argi) {
   if (!p) return -argi;
   if (!aligned16(p) || (ld & 1) || ld < n) return -(argi + 1);
@@ -988,7 +996,7 @@ int gpp_syrk_rows(gpp_handle_t h, const double* Urow, int64_t ldu, double* C, in
 
 int gpp_gemm_lower_cols(gpp_handle_t h, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                         int64_t M, int64_t K, double alpha, double beta, int64_t nb, int64_t first_block, int rank, int nranks,
-                        int64_t row0, int64_t row1) {
+                        int64_t row0, int64_t row1, int compact) {
   if (!h) return -1;
   if (!A || !aligned16(A) || (lda & 1)) return -2;
   if (!B || !aligned16(B) || (ldb & 1)) return -4;
@@ -1006,22 +1014,24 @@ int gpp_gemm_lower_cols(gpp_handle_t h, const double* A, int64_t lda, const doub
   g.own_mod = nranks;
   g.own_bt = (int)(nb / NBLK);
   g.own_off = (int)(((first_block - rank) % nranks + nranks) % nranks);
+  g.compact_bc = compact ? 1 : 0;
   GPP_TRY(gpp_launch_gemm(h->stream, 2, g, 1, NBLK, NBLK));
   return 0;
 }
 
 int gpp_trmv_lower_cols(gpp_handle_t h, const double* T, int64_t ldt, int64_t N, const double* x, double* y, int64_t nb, int rank,
-                        int nranks, int trans) {
+                        int nranks, int trans, int compact) {
   if (!h) return -1;
   if (N < 0) return -4;
-  if (int q = check_mat(T, ldt, N, 2)) return q;
+  if (int q = check_mat(T, ldt, compact ? std::min<int64_t>(N, ldt) : N, 2)) return q;
   if (!x || !aligned16(x)) return -5;
   if (!y) return -6;
   if (nb < 64 || nb % 64 != 0) return -7;
   if (nranks < 1 || rank < 0 || rank >= nranks) return -8;
   if (trans != 0 && trans != 1) return -10;
   if (trans && (!h->ws || h->ws_bytes < gpp_trmv_t_ws_bytes(N))) return -1;  // workspace of GPP_OP_MLL_EVAL (gpp_set_workspace)
-  GPP_TRY(gpp_launch_trmv_lower_cols(h->stream, T, ldt, N, x, y, nb, rank, nranks, trans, h->ws, h->ws_bytes));
+  if (compact && nranks >= 1 && rank >= 0 && ldt < owned_cols(N, nb, rank, nranks)) return -3;
+  GPP_TRY(gpp_launch_trmv_lower_cols(h->stream, T, ldt, N, x, y, nb, rank, nranks, trans, h->ws, h->ws_bytes, compact));
   return 0;
 }
 
@@ -1116,7 +1126,7 @@ int gpp_grad_reduce_rows(gpp_handle_t h, const double* U, int64_t N, int D, cons
 int gpp_grad_reduce_cols(gpp_handle_t h, const double* U, int64_t N, int D, const double* w, const double* sf2,
                          const int32_t* grp, int S, int kind, int d_split, const double* alpha, const double* Kinv,
                          int64_t ldk, int dU, int64_t nb, int rank, int nranks, double* g_w, double* g_sf2, double* g_tau,
-                         double* g_U) {
+                         double* g_U, int compact) {
   if (!h) return -1;
   if (!U) return -2;
   if (N < 0) return -3;
@@ -1127,17 +1137,18 @@ int gpp_grad_reduce_cols(gpp_handle_t h, const double* U, int64_t N, int D, cons
   if (kind < 0 || kind > 2) return -9;
   if (d_split < 0 || d_split > D) return -10;
   if (!alpha) return -11;
-  if (int q = check_mat(Kinv, ldk, N, 12)) return q;
+  if (int q = check_mat(Kinv, ldk, compact ? std::min<int64_t>(N, ldk) : N, 12)) return q;
   if (dU < 0 || dU > D) return -14;
   if (nb < 64 || nb % 64 != 0 || nb > (1 << 30)) return -15;
   if (nranks < 1 || rank < 0 || rank >= nranks) return -16;
+  if (compact && ldk < owned_cols(N, nb, rank, nranks)) return -13;
   if (!g_w) return -18;
   if (!g_sf2) return -19;
   if (!g_tau) return -20;
   if (dU > 0 && !g_U) return -21;
   if (!h->ws || h->ws_bytes < gpp_grad_ws_bytes(N, D, S, dU)) return -1;
   GPP_TRY(gpp_launch_grad_reduce(h->stream, U, N, D, w, sf2, grp, S, kind, d_split, alpha, Kinv, ldk, dU, g_w, g_sf2, g_tau,
-                                 g_U, h->ws, h->ws_bytes, (int)nb, rank, nranks, 1, 0, 0, 0, /*shard_cols=*/1));
+                                 g_U, h->ws, h->ws_bytes, (int)nb, rank, nranks, 1, 0, 0, 0, /*shard_cols=*/compact ? 2 : 1));
   return 0;
 }
 

@@ -87,9 +87,11 @@ __device__ __forceinline__ void store_kc(double* __restrict__ s, int tid, const 
 }
 
 // Operand stored [k][row] (row contiguous): BK k x T rows per chunk, BK * T / 512 16-byte vectors per thread.
+// (`dummy`: where the lanes of out-of-range elements read instead — any readable address; P itself unless P is a biased base,
+//  see GemmArgs::compact_bc)
 template <int T, int BK, int NTH = 256>
 __device__ __forceinline__ unsigned load_mc(const double* __restrict__ P, int64_t ld, int R, int r0, int kb, int kend,
-                                            int mask, int tid, v2d (&reg)[BK * T / (2 * NTH)]) {
+                                            int mask, int tid, v2d (&reg)[BK * T / (2 * NTH)], const double* __restrict__ dummy) {
   constexpr int NV = BK * T / (2 * NTH);
   unsigned keep = 0;
   const double* ptr[NV];
@@ -103,7 +105,7 @@ __device__ __forceinline__ unsigned load_mc(const double* __restrict__ P, int64_
     const bool k1 = v0 & (gr + 1 < R) & keep_elem(mask, gk, gr + 1);
     keep |= (k0 ? 1u : 0u) << (2 * i);
     keep |= (k1 ? 1u : 0u) << (2 * i + 1);
-    ptr[i] = v0 ? P + (int64_t)gk * ld + gr : P;
+    ptr[i] = v0 ? P + (int64_t)gk * ld + gr : dummy;
   }
 #pragma unroll
   for (int i = 0; i < NV; ++i) reg[i] = *reinterpret_cast<const v2d*>(ptr[i]);  // all requests back to back
@@ -209,6 +211,16 @@ __device__ __forceinline__ void gemm_tile(const P& p, const int tm, const int tn
   const int wm = (wave >> 1) * WTM, wn = (wave & 1) * WTN;
   const int li = lane & 15, lk = lane >> 4;
   const int row0 = tm * TM, col0 = tn * TN;
+  const double* __restrict__ Bd = B;  // readable addresses for the lanes that must not touch memory (the biased bases below may
+  double* __restrict__ Cd = C;        // lie in front of their buffers)
+  if (p.compact_bc) {
+    // B and C store only the owned column blocks, side by side: shift their bases by (physical - logical) first column of this
+    // tile's block (a tile never straddles two blocks: the block width is a multiple of the tile)
+    const int b = tn / p.own_bt, q = (b + p.own_off) / p.own_mod;
+    const int64_t bias = (int64_t)(q - b) * p.own_bt * TN;
+    B += bias;
+    C += bias;
+  }
 
   int klo = 0;
   if (p.klo_mode == 1) klo = row0;
@@ -257,14 +269,14 @@ __device__ __forceinline__ void gemm_tile(const P& p, const int tm, const int tn
       if (pa == 2) ka = mask_bits_mc<TM, BK, NTH>(row0, kb, p.a_mask, tid);
     } else {
       if constexpr (A_KC) ka = load_kc<TM>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra);
-      else ka = load_mc<TM, BK, NTH>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra);
+      else ka = load_mc<TM, BK, NTH>(A, p.lda, p.M, row0, kb, khi, p.a_mask, tid, ra, A);
     }
     if (pb) {
       load_fast<NVB>(ubaseB + (int64_t)kb * stepB, offb, rb);
       if (pb == 2) kb_ = mask_bits_mc<TN, BK, NTH>(col0, kb, p.b_mask, tid);
     } else {
       if constexpr (B_KC) kb_ = load_kc<TN>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb);
-      else kb_ = load_mc<TN, BK, NTH>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb);
+      else kb_ = load_mc<TN, BK, NTH>(B, p.ldb, p.N, col0, kb, khi, p.b_mask, tid, rb, Bd);
     }
   };
   auto stage_store = [&](double* da, double* db) {
@@ -384,7 +396,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const int tm, const int tn
         for (int b = 0; b < CB; ++b) {
           const int n = col0 + wn + 16 * b + li;
           const bool ok = (m < p.M) && (n < p.N) && (p.c_lower == 0 || (p.c_lower == 1 ? n <= m : n >= m));
-          const double* src = ok ? C + (int64_t)m * p.ldc + n : C;
+          const double* src = ok ? C + (int64_t)m * p.ldc + n : Cd;
           cold[a][b] = *src;
         }
       }

@@ -127,6 +127,9 @@ struct GemmArgs {
   int row_mod, row_off;    // c_lower == 1 only: produce the tile rows tm with tm % row_mod == row_off (row_mod <= 1: all);
                            // the sharded LAUUM, one launch per rank over its cyclic share of the 128-row tile rows
   int op;                  // executor only (gpp_exec_f64): 0 = the product above, 1 = copy the M x 128 strip `tn` of B into C
+  int compact_bc;          // c_lower == 1 with own_mod > 1: B and C hold only the owned column blocks, side by side (the q-th owned
+                           // block in columns [q own_bt 128, (q+1) own_bt 128) of their buffers): the sharded back-substitution
+                           // with N x (N / ranks) storage per rank
   int pad_ok;              // TN variant, big tile: the operands may be READ up to the next multiple of 128 past M / N along their rows
                            // (the bytes belong to the same allocation: never set for an operand's last row of a buffer) — what
                            // is read there only reaches output entries that are not stored, and a ragged edge tile then runs the
@@ -242,11 +245,12 @@ hipError_t gpp_launch_grad_reduce(hipStream_t s, const double* U, int64_t N, int
                                   double* g_U, void* ws, size_t ws_bytes, int shard_nb = 0, int shard_rank = 0,
                                   int shard_nranks = 1, int batch = 1, int64_t sU = 0, int64_t sK = 0, int64_t sv = 0,
                                   int shard_cols = 0);
-// (shard_cols = 1: the rank owns block-cyclic COLUMN blocks of Kinv's lower triangle instead of block rows)
+// (shard_cols = 1: the rank owns block-cyclic COLUMN blocks of Kinv's lower triangle instead of block rows; 2: and Kinv holds
+//  only those blocks, side by side: the q-th owned block in columns [q nb, (q+1) nb))
 // y = sum over the owned column blocks (width nb, block b owned when b % nranks == rank) of T(lower) x  (trans = 0), or
 // y_k = sum_i T[i][k] x_i for the owned columns k and 0 elsewhere (trans = 1)
 hipError_t gpp_launch_trmv_lower_cols(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
-                                      int64_t nb, int rank, int nranks, int trans, void* ws, size_t ws_bytes);
+                                      int64_t nb, int rank, int nranks, int trans, void* ws, size_t ws_bytes, int compact = 0);
 size_t gpp_trmv_t_ws_bytes(int64_t N);  // scratch of the trans = 1 form (partial sums of the row chunks)
 // (batch > 1: U + b*sU, w + b*D, sf2 + b, alpha + b*sv, Kinv + b*sK; outputs g_w + b*D, g_sf2 + b, g_tau + b*S,
 //  g_U + b*N*dU; the workspace holds batch * gpp_grad_ws_bytes)

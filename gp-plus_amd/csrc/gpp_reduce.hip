@@ -76,24 +76,28 @@ __global__ __launch_bounds__(256) void gpp_trmv_upper(const double* __restrict__
 // columns [b*nb, (b+1)*nb) with b % nranks == rank): the sharded evaluation's z = L^-1 r and alpha = L^-T z from the owned
 // column blocks of L^-1 (the caller all-reduces the partial results).
 //   y_i = sum over owned columns k <= i of T[i][k] x_k        (one wave per row; other columns are never read)
+// compact: T holds ONLY the owned column blocks, side by side (the q-th owned block, global block rank + q nranks, in columns
+// [q nb, (q+1) nb)): N x (N / nranks) doubles per rank instead of N x N.
 __global__ __launch_bounds__(256) void gpp_trmv_lower_cols(const double* __restrict__ T, int64_t ldt, int64_t N,
                                                            const double* __restrict__ x, double* __restrict__ y, int64_t nb,
-                                                           int rank, int nranks) {
+                                                           int rank, int nranks, int compact) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t i = (int64_t)blockIdx.x * 4 + wave;
   if (i >= N) return;
   const double* row = T + i * ldt;
   double acc = 0.0;
-  for (int64_t c0 = (int64_t)rank * nb; c0 <= i; c0 += (int64_t)nranks * nb) {
+  int64_t q = 0;
+  for (int64_t c0 = (int64_t)rank * nb; c0 <= i; c0 += (int64_t)nranks * nb, ++q) {
     const int64_t c1 = (c0 + nb < i + 1) ? c0 + nb : i + 1;  // nb is even: c0 is, so the 16-byte loads are aligned
     const int64_t len = c1 - c0, len2 = len & ~(int64_t)1;
+    const double* seg = row + (compact ? q * nb : c0);
     for (int64_t k = 2 * lane; k < len2; k += 128) {
-      const v2d t = *reinterpret_cast<const v2d*>(row + c0 + k);
+      const v2d t = *reinterpret_cast<const v2d*>(seg + k);
       const v2d xx = *reinterpret_cast<const v2d*>(x + c0 + k);
       acc = fma(t.x, xx.x, acc);
       acc = fma(t.y, xx.y, acc);
     }
-    if (lane == 0 && (len & 1)) acc = fma(row[c1 - 1], x[c1 - 1], acc);
+    if (lane == 0 && (len & 1)) acc = fma(seg[len - 1], x[c1 - 1], acc);
   }
   acc = wave_sum(acc);
   if (lane == 0) y[i] = acc;
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void gpp_trmv_lower_cols(const double* __restr
 constexpr int TRT_CHUNKS = 16;
 __global__ __launch_bounds__(256) void gpp_trmv_lower_t_cols(const double* __restrict__ T, int64_t ldt, int64_t N,
                                                              const double* __restrict__ x, double* __restrict__ part, int64_t nb,
-                                                             int rank, int nranks, int64_t chunk) {
+                                                             int rank, int nranks, int64_t chunk, int compact) {
   __shared__ double red[4][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t k0 = (int64_t)blockIdx.x * 64, k = k0 + lane;
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(256) void gpp_trmv_lower_t_cols(const double* __res
   const int64_t r0 = (int64_t)blockIdx.y * chunk, r1 = (r0 + chunk < N) ? r0 + chunk : N;
   if (owned && k < N && r1 > k0) {
     int64_t i = (r0 > k0 ? r0 : k0) + wave;
-    const double* p = T + k;
+    const double* p = T + (compact ? ((k0 / nb) / nranks) * nb + (k0 % nb) + lane : k);
     for (; i + 28 < r1; i += 32) {  // rows i, i+4, ..., i+28 of this wave: eight independent loads
       double t[8], xv[8];
 #pragma unroll
@@ -273,8 +277,10 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
         const int64_t i = i0 + ra + a, jb = j0 + 4 * tx;
-        const double* src = Kinv + (i < N ? i : N - 1) * ldk + jb;
-        if (jb + 4 <= ldk) {  // two 16-byte loads, issued before the arithmetic (entries above the diagonal are never used)
+        // (shard_cols == 2: Kinv holds only the owned column blocks, side by side — see gpp_trmv_lower_cols)
+        const int64_t pjb = (shard_cols == 2) ? ((j0 / shard_nb) / shard_nranks) * shard_nb + (j0 % shard_nb) + 4 * tx : jb;
+        const double* src = Kinv + (i < N ? i : N - 1) * ldk + pjb;
+        if (pjb + 4 <= ldk) {  // two 16-byte loads, issued before the arithmetic (entries above the diagonal are never used)
           const v2d p0 = reinterpret_cast<const v2d*>(src)[0], p1 = reinterpret_cast<const v2d*>(src)[1];
           kin[a][0] = p0.x; kin[a][1] = p0.y; kin[a][2] = p1.x; kin[a][3] = p1.y;
         } else {
@@ -510,7 +516,7 @@ hipError_t gpp_launch_trmv_upper(hipStream_t s, const double* T, int64_t ldt, in
 size_t gpp_trmv_t_ws_bytes(int64_t N) { return (size_t)TRT_CHUNKS * (size_t)N * sizeof(double); }
 
 hipError_t gpp_launch_trmv_lower_cols(hipStream_t s, const double* T, int64_t ldt, int64_t N, const double* x, double* y,
-                                      int64_t nb, int rank, int nranks, int trans, void* ws, size_t ws_bytes) {
+                                      int64_t nb, int rank, int nranks, int trans, void* ws, size_t ws_bytes, int compact) {
   if (N <= 0) return hipSuccess;
   if (nb < 64 || nb % 64 != 0 || nranks < 1 || rank < 0 || rank >= nranks) return hipErrorInvalidValue;
   if (trans) {
@@ -518,10 +524,10 @@ hipError_t gpp_launch_trmv_lower_cols(hipStream_t s, const double* T, int64_t ld
     const int64_t chunk = (((N + TRT_CHUNKS - 1) / TRT_CHUNKS) + 31) / 32 * 32;
     double* part = reinterpret_cast<double*>(ws);
     hipLaunchKernelGGL(gpp_trmv_lower_t_cols, dim3((unsigned)((N + 63) / 64), TRT_CHUNKS), dim3(256), 0, s, T, ldt, N, x, part, nb,
-                       rank, nranks, chunk);
+                       rank, nranks, chunk, compact);
     hipLaunchKernelGGL(gpp_trmv_lower_t_finish, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, s, part, N, TRT_CHUNKS, y);
   } else
-    hipLaunchKernelGGL(gpp_trmv_lower_cols, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, T, ldt, N, x, y, nb, rank, nranks);
+    hipLaunchKernelGGL(gpp_trmv_lower_cols, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, s, T, ldt, N, x, y, nb, rank, nranks, compact);
   return hipGetLastError();
 }
 

@@ -30,7 +30,10 @@ O(N^3) stages split 1-D block-cyclically (block height / width ``nb``, owner of 
 
 Communication per evaluation and GPU: the packed factor slabs (4 N^2 B received) + the diagonal-block inverses (8 N nb B)
 + three small all-reduces — 14.4 GB at C5 for every P; round 2 also moved the inverse's column blocks (another 4 N^2 B).
-Memory per GPU: the same three N x N buffers as the single-GPU path (86 GB at C5 of 288 GB).
+Memory per GPU (round 4): ONE N x N buffer — the replicated factor (upper) and its mirror (strict lower), which the sweeps read —
+plus what the rank OWNS of the other two: its column blocks of L^-1 and of Ky^-1 stored side by side (N x N/P each), the diagonal
+blocks' inverses (N x nb) and an nb x N row of scratch: 28.8 + 2 x 3.6 + 1 GB = 37 GB at C5 on 8 GPUs where three full matrices took
+86 GB on every rank ("28.8 GB (3.6 GB/GPU sharded)") — what grows with N on a rank is the factor alone.
 
 Without RCCL (tests: several processes sharing one GPU over "gloo") the collectives are staged through host memory.
 ``GPP_SHARDED_FORCE_COLLECTIVES=1`` issues every collective (and the packing around it) even in a group of one rank, so that
@@ -93,14 +96,23 @@ class _Comm:
 
 
 class ShardedWorkspace:
-    """Per-rank buffers of an N-point sharded evaluation (reused across evaluations)."""
+    """Per-rank buffers of an N-point sharded evaluation (reused across evaluations).  Only ``A`` is N x N; the inverse factor and
+    Ky^-1 exist as the OWNED column blocks, side by side: owned block q (global block rank + q P) in columns [q nb, (q+1) nb)."""
 
-    def __init__(self, ctx: GppContext, N: int, nb: int):
+    def __init__(self, ctx: GppContext, N: int, nb: int, rank: int, world: int):
         dev = ctx.device
-        self.N, self.nb = N, nb
+        self.N, self.nb, self.rank, self.world = N, nb, rank, world
+        self.offs: List[int] = list(range(0, N, nb)) + [N]
+        nblk = len(self.offs) - 1
+        self.nq = len(range(rank, nblk, world))  # column blocks this rank owns
+        wc = max(self.nq, 1) * nb
         self.A = square_buffer(N, dev)      # upper: Ky block rows (owned) -> the whole factor U; strict lower blocks: its mirror L
-        self.Li = square_buffer(N, dev)     # diagonal blocks: L_kk^-1 (+ mirror); owned column blocks: sums S, then Ky^-1 (lower)
-        self.Ki = square_buffer(N, dev)     # scratch of the factorisation, then the owned column blocks of L^-1 (lower)
+        # owned column blocks, compact: the forward sweep's running sums S, then Ky^-1 (lower) / the owned column blocks of L^-1
+        self.Lc = torch.empty((N, wc), dtype=torch.float64, device=dev)
+        self.Kc = torch.empty((N, wc), dtype=torch.float64, device=dev)
+        self.D = torch.empty((nblk, nb, nb), dtype=torch.float64, device=dev)  # every diagonal block's inverse L_kk^-1 (+ mirror)
+        self.W = torch.empty((nb, self.A.stride(0)), dtype=torch.float64, device=dev)[:, :N]  # scratch of the row solves
+        self.Tk = torch.empty((nb, nb), dtype=torch.float64, device=dev)       # scratch of a diagonal block's factorisation
         self.ld = self.A.stride(0)
         self.pack = torch.empty(N * nb, dtype=torch.float64, device=dev)       # the packed tail of a row slab of the factor
         self.hbuf = torch.empty(3 * nb * nb, dtype=torch.float64, device=dev)  # its packed head: diagonal block, block k+1, inverse
@@ -110,20 +122,33 @@ class ShardedWorkspace:
         self.alpha = torch.empty(N, dtype=torch.float64, device=dev)
         self.r = torch.empty(N, dtype=torch.float64, device=dev)
         self.out3 = torch.empty(3, dtype=torch.float64, device=dev)
-        self.offs: List[int] = list(range(0, N, nb)) + [N]
         self.info = torch.zeros(len(self.offs), dtype=torch.int32, device=dev)
         self.epoch = 0
+
+    def dblk(self, k: int) -> torch.Tensor:
+        """The inverse of diagonal block k (lower) and its mirror (strict upper)."""
+        n = self.offs[k + 1] - self.offs[k]
+        return self.D[k, :n, :n]
+
+    def col(self, c: int) -> slice:
+        """Columns of the compact buffers that hold global column block c (owned by this rank)."""
+        q = (c - self.rank) // self.world
+        return slice(q * self.nb, q * self.nb + self.offs[c + 1] - self.offs[c])
+
+    def nbytes(self) -> int:
+        """Device bytes of the matrices (what grows with N)."""
+        return sum(t.untyped_storage().nbytes() for t in (self.A, self.Lc, self.Kc, self.D, self.W, self.pack))
 
 
 _workspaces = {}
 
 
-def _workspace(ctx: GppContext, N: int, nb: int) -> ShardedWorkspace:
-    key = (ctx.index, N, nb)
+def _workspace(ctx: GppContext, N: int, nb: int, rank: int = 0, world: int = 1) -> ShardedWorkspace:
+    key = (ctx.index, N, nb, rank, world)
     ws = _workspaces.get(key)
     if ws is None:
         _workspaces.clear()
-        ws = ShardedWorkspace(ctx, N, nb)
+        ws = ShardedWorkspace(ctx, N, nb, rank, world)
         _workspaces[key] = ws
     return ws
 
@@ -176,7 +201,7 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
     """
     N, offs, P, me, nb = ws.N, ws.offs, comm.world, comm.rank, ws.nb
     nblk = len(offs) - 1
-    A, Li, Ki = ws.A, ws.Li, ws.Ki
+    A = ws.A
     main = torch.cuda.current_stream(ctx.index)
     side, upd, full = ctx.internal_streams()
     cs = ws.comm_stream
@@ -215,8 +240,8 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
         o, o1 = offs[k], offs[k + 1]
         o2 = offs[k + 2] if k + 2 <= nblk else N  # end of the head's columns (block k+1)
         nbk, own = o1 - o, (k % P == me)
-        Lkk = Li[o:o1, o:o1]
-        W = Ki[o:o1]  # scratch of the row solves (the product cannot run in place)
+        Lkk = ws.dblk(k)
+        W = ws.W[:nbk]  # scratch of the row solves (the product cannot run in place)
         head_solved = tail_solved = None
         if own:
             with torch.cuda.stream(side):
@@ -224,8 +249,8 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
                     side.wait_event(diag_ready)
                 else:
                     rows.needed([k], side)
-                ctx.potrf(A[o:o1, o:o1], Lkk, ws.info[k:k + 1], Ki[o:o1, o:o1])
-                ctx.trtri(A[o:o1, o:o1], Lkk, Ki[o:o1, o:o1])
+                ctx.potrf(A[o:o1, o:o1], Lkk, ws.info[k:k + 1], ws.Tk[:nbk, :nbk])
+                ctx.trtri(A[o:o1, o:o1], Lkk, ws.Tk[:nbk, :nbk])
                 factored = torch.cuda.Event()
                 factored.record(side)
                 # U12 = W_kk^T A12 (W_kk = mirrored inverse of the diagonal block).  The HEAD (the columns of block k+1) is
@@ -327,26 +352,25 @@ def _first_owned(ws: ShardedWorkspace, comm: _Comm) -> Optional[int]:
 
 
 def _forward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
-    """The owned column blocks of L^-1 (rows at and below their diagonal block) into ``Ki``, from the replicated factor and
+    """The owned column blocks of L^-1 (rows at and below their diagonal block) into ``Kc`` (compact), from the replicated factor and
     diagonal-block inverses: forward substitution of all owned column blocks together, one block row j at a time.  The owned
     blocks up to j (c = me, me+P, ... <= j, all nb wide) sit at the regular column spacing P*nb, so each step is ONE batched
     launch per product:
-        Y_j[c] = -X_jj S_j[c]                (X_jj^T = the mirror in the upper part of the diagonal block; finished rows go to ``Ki``;
+        Y_j[c] = -X_jj S_j[c]                (X_jj^T = the mirror in the upper part of the diagonal block; finished rows go to ``Kc``;
                                               the own block of the step is Y_j[j] = X_jj itself)
-        S_k[c] += L[k, j] Y_j[c],  k > j     (L[k, j] = U[j, k]^T, shared by the whole batch; the sums S live in ``Li``)
+        S_k[c] += L[k, j] Y_j[c],  k > j     (L[k, j] = U[j, k]^T, shared by the whole batch; the sums S live in ``Lc``)
     with one step of look-ahead: the update's first block row (k = j+1) is issued on its own, and the small product of step j+1
     then runs on a second stream beside the rest of step j's update instead of alone on the chip."""
     N, offs, P, me, nb = ws.N, ws.offs, comm.world, comm.rank, ws.nb
     nblk = len(offs) - 1
-    A, Li, Ki = ws.A, ws.Li, ws.Ki
+    A, Lc, Kc = ws.A, ws.Lc, ws.Kc
     if _first_owned(ws, comm) is None:
         return
-    oc0 = offs[me]
     main = torch.cuda.current_stream(ctx.index)
     aux = ctx.internal_streams()[2] if _SWEEP_LOOKAHEAD else main
     aux.wait_stream(main)
     for c in range(me, nblk - 1, P):  # the sums of the owned column blocks start from zero
-        Li[offs[c + 1]:N, offs[c]:offs[c + 1]].zero_()
+        Lc[offs[c + 1]:N, ws.col(c)].zero_()
     row_done = torch.cuda.Event()  # block row j of the sums is complete
     row_done.record(main)
     for j in range(me, nblk):
@@ -354,14 +378,15 @@ def _forward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
         nbj = oj1 - oj
         nleft = len(range(me, j, P))
         own = j % P == me
+        Xjj = ws.dblk(j)
         with torch.cuda.stream(aux):
             aux.wait_event(row_done)
-            if nleft > 0:
-                ctx.gemm_batched(1, 0, nbj, nb, nbj, -1.0, Li[oj:oj1, oj:oj1], 0, Li[oj:oj1, oc0:oc0 + nb], P * nb, 0.0,
-                                 Ki[oj:oj1, oc0:oc0 + nb], P * nb, nleft, a_mask=1, khi_mode=1)
-            if own:  # Y_j[j] = X_jj: lower triangle, zeros above (its slot in Li also holds the mirror)
-                Ki[oj:oj1, oj:oj1].copy_(Li[oj:oj1, oj:oj1])
-                Ki[oj:oj1, oj:oj1].tril_()
+            if nleft > 0:  # (the owned blocks left of j are the first nleft compact blocks, at the column spacing nb)
+                ctx.gemm_batched(1, 0, nbj, nb, nbj, -1.0, Xjj, 0, Lc[oj:oj1, 0:nb], nb, 0.0, Kc[oj:oj1, 0:nb], nb, nleft,
+                                 a_mask=1, khi_mode=1)
+            if own:  # Y_j[j] = X_jj: lower triangle, zeros above (the diagonal block's slot also holds the mirror)
+                Kc[oj:oj1, ws.col(j)].copy_(Xjj)
+                Kc[oj:oj1, ws.col(j)].tril_()
             y_done = torch.cuda.Event()
             y_done.record(aux)
         nb_all = nleft + (1 if own else 0)
@@ -370,8 +395,8 @@ def _forward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
             oj2 = offs[j + 2]
             for r0, r1 in (((oj1, oj2), (oj2, N)) if _SWEEP_LOOKAHEAD else ((oj1, N),)):  # block row j+1 first: the next step's small product waits for it only
                 if r1 > r0:
-                    ctx.gemm_batched(1, 0, r1 - r0, nb, nbj, 1.0, A[oj:oj1, r0:r1], 0, Ki[oj:oj1, oc0:oc0 + nb], P * nb, 1.0,
-                                     Li[r0:r1, oc0:oc0 + nb], P * nb, nb_all)
+                    ctx.gemm_batched(1, 0, r1 - r0, nb, nbj, 1.0, A[oj:oj1, r0:r1], 0, Kc[oj:oj1, 0:nb], nb, 1.0,
+                                     Lc[r0:r1, 0:nb], nb, nb_all)
                 if r1 == oj2 and _SWEEP_LOOKAHEAD:
                     row_done = torch.cuda.Event()
                     row_done.record(main)
@@ -381,28 +406,28 @@ def _forward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
 
 
 def _vectors(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, need_alpha: bool) -> None:
-    """z = L^-1 r, the scalars of the MLL, and alpha = L^-T z, from the owned column blocks of L^-1 in ``Ki``: each rank forms its
+    """z = L^-1 r, the scalars of the MLL, and alpha = L^-T z, from the owned column blocks of L^-1 in ``Kc``: each rank forms its
     part (sums over its columns / its entries) and the parts are added by an all-reduce of N doubles."""
     P, me, nb = comm.world, comm.rank, ws.nb
-    ctx.trmv_lower_cols(ws.Ki, ws.r, ws.z, nb, me, P, trans=False)
+    ctx.trmv_lower_cols(ws.Kc, ws.r, ws.z, nb, me, P, trans=False, compact=True)
     comm.allreduce(ws.z)
     ctx.mll_scalars(ws.A, ws.z, ws.out3)
     if need_alpha:
-        ctx.trmv_lower_cols(ws.Ki, ws.z, ws.alpha, nb, me, P, trans=True)
+        ctx.trmv_lower_cols(ws.Kc, ws.z, ws.alpha, nb, me, P, trans=True, compact=True)
         comm.allreduce(ws.alpha)
 
 
 def _backward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
-    """The owned column blocks of Ky^-1 = L^-T L^-1 (rows at and below their diagonal block) into ``Li``, by back-substitution of
-    the owned column blocks Y of L^-1 (in ``Ki``) against the replicated factor:  U[c:, c:] Z = Y, block row j from the last
-    one up:   Z_j = X_jj^T Y_j   (X_jj = L_jj^-1: the lower part of the diagonal block of ``Li``), then the right-looking update
+    """The owned column blocks of Ky^-1 = L^-T L^-1 (rows at and below their diagonal block) into ``Lc``, by back-substitution of
+    the owned column blocks Y of L^-1 (in ``Kc``) against the replicated factor:  U[c:, c:] Z = Y, block row j from the last
+    one up:   Z_j = X_jj^T Y_j   (X_jj = L_jj^-1: the lower part of ``D[j]``), then the right-looking update
     Y_i -= U[i, j] Z_j of every block row c <= i < j — ONE TN GEMM per step over the lower-triangular tiles of the owned
     column blocks, its row-contiguous left operand being the factor's mirror L[j, i] in the strict lower triangle of ``A``.
     One step of look-ahead as in ``_forward``: block row j-1 of the update first, the small products of step j-1 on a second
     stream beside the rest.  No communication (bullet 4)."""
     offs, P, me, nb = ws.offs, comm.world, comm.rank, ws.nb
     nblk = len(offs) - 1
-    A, Li, Ki = ws.A, ws.Li, ws.Ki
+    A, Lc, Kc = ws.A, ws.Lc, ws.Kc
     if _first_owned(ws, comm) is None:
         return
     oc0 = offs[me]
@@ -414,18 +439,18 @@ def _backward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
         oj, oj1 = offs[j], offs[j + 1]
         nbj = oj1 - oj
         nleft = len(range(me, j, P))  # owned column blocks strictly left of j
-        Xjj = Li[oj:oj1, oj:oj1]
+        Xjj = ws.dblk(j)
         with torch.cuda.stream(aux):
             aux.wait_event(row_done)
             if nleft > 0:
-                ctx.gemm_batched(1, 0, nbj, nb, nbj, 1.0, Xjj, 0, Ki[oj:oj1, oc0:oc0 + nb], P * nb, 0.0, Li[oj:oj1, oc0:oc0 + nb],
-                                 P * nb, nleft, a_mask=2, klo_mode=1)
+                ctx.gemm_batched(1, 0, nbj, nb, nbj, 1.0, Xjj, 0, Kc[oj:oj1, 0:nb], nb, 0.0, Lc[oj:oj1, 0:nb], nb, nleft,
+                                 a_mask=2, klo_mode=1)
             if j % P == me:
                 # the diagonal block of Ky^-1: both operands lower triangular, only its lower part is wanted (and only the lower
                 # part of Y_j[j] is kept up to date) — the LAUUM shape; through the scratch, the product cannot run in place
                 d = ws.dscr[:nbj, :nbj]
-                ctx.gemm(1, 0, nbj, nbj, nbj, 1.0, Xjj, Ki[oj:oj1, oj:oj1], 0.0, d, a_mask=2, b_mask=2, klo_mode=3, c_tri=1)
-                Xjj.copy_(d)
+                ctx.gemm(1, 0, nbj, nbj, nbj, 1.0, Xjj, Kc[oj:oj1, ws.col(j)], 0.0, d, a_mask=2, b_mask=2, klo_mode=3, c_tri=1)
+                Lc[oj:oj1, ws.col(j)].copy_(d)
             z_done = torch.cuda.Event()
             z_done.record(aux)
         main.wait_event(z_done)
@@ -434,7 +459,7 @@ def _backward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
             lo = max(offs[j - 1] - oc0, 0)
             for r0, r1 in (((lo, M), (0, lo)) if _SWEEP_LOOKAHEAD else ((0, M),)):  # block row j-1 first
                 if r1 > r0:
-                    ctx.gemm_lower_cols(A[oj:oj1, oc0:oj], Li[oj:oj1, oc0:oj], Ki[oc0:oj, oc0:oj], -1.0, 1.0, nb, me, me, P, r0, r1)
+                    ctx.gemm_lower_cols(A[oj:oj1, oc0:oj], Lc[oj:oj1], Kc[oc0:oj], -1.0, 1.0, nb, me, me, P, r0, r1, compact=True)
                 if r0 == lo and _SWEEP_LOOKAHEAD:
                     row_done = torch.cuda.Event()
                     row_done.record(main)
@@ -454,7 +479,7 @@ class ShardedMLLFunction(torch.autograd.Function):
         Ud, wd, sd, td = f64(U), f64(w), f64(sf2).reshape(1), f64(tau).reshape(-1)
         if grp is not None and grp.dtype != torch.int32:
             grp = grp.to(torch.int32)
-        ws = _workspace(gctx, N, nb)
+        ws = _workspace(gctx, N, nb, comm.rank, comm.world)
         ws.epoch += 1
         jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
         used = None
@@ -515,8 +540,8 @@ class ShardedMLLFunction(torch.autograd.Function):
         flat = torch.zeros(D + 1 + S + nU, dtype=torch.float64, device=dev)
         g_w, g_s, g_t = flat[:D], flat[D:D + 1], flat[D + 1:D + 1 + S]
         g_Ud = flat[D + 1 + S:].view(N, dU) if need_U else None
-        gctx.grad_reduce_cols(Ud, wd, sd, grp, S, ws.alpha, ws.Li, dU if need_U else 0, ws.nb, comm.rank, comm.world, g_w,
-                              g_s, g_t, g_Ud, kind=kind, d_split=d_split)
+        gctx.grad_reduce_cols(Ud, wd, sd, grp, S, ws.alpha, ws.Lc, dU if need_U else 0, ws.nb, comm.rank, comm.world, g_w,
+                              g_s, g_t, g_Ud, kind=kind, d_split=d_split, compact=True)
         comm.allreduce(flat)
         ws.comm_calls = comm.calls
         g_U = None

@@ -138,17 +138,21 @@ int gpp_syrk_rows(gpp_handle_t h, const double* Urow, int64_t ldu, double* C, in
  * (first_block + i) % nranks == rank; other ranks' column blocks are neither read nor written.  A: K x M (rows of the factor's
  * mirror L = U^T), B: K x M (the just-solved block row of Ky^-1), both row-contiguous.  Only the rows [row0, row1) of C are produced
  * (row0 a multiple of 128): the block row the next step depends on is issued first, the rest behind it.  Replaces the broadcast of the inverse's
- * column blocks + the LAUUM share (gpp_lauum_rows_range); reference counterpart: ATen cholesky_backward, optim/mll_torch.py:117. */
+ * column blocks + the LAUUM share (gpp_lauum_rows_range); reference counterpart: ATen cholesky_backward, optim/mll_torch.py:117.
+ * compact != 0 (here, in gpp_trmv_lower_cols and in gpp_grad_reduce_cols): B and C — there T, Kinv — hold ONLY the owned column
+ * blocks, side by side (the q-th owned block, global block rank + q nranks, in columns [q nb, (q+1) nb) of the buffer, ld >= the
+ * owned width): N x (N / nranks) doubles per rank and matrix instead of N x N — what lets 8 GPUs hold a problem one cannot
+ * ("28.8 GB (3.6 GB/GPU sharded)"). */
 int gpp_gemm_lower_cols(gpp_handle_t h, const double* A, int64_t lda, const double* B, int64_t ldb, double* C, int64_t ldc,
                         int64_t M, int64_t K, double alpha, double beta, int64_t nb, int64_t first_block, int rank, int nranks,
-                        int64_t row0, int64_t row1);
+                        int64_t row0, int64_t row1, int compact);
 
 /* Products with a lower-triangular T of which only the block-cyclically owned COLUMN blocks (width nb, a multiple of 64; block
  * b owned when b % nranks == rank) exist on this rank:  trans = 0: y_i = sum over owned columns k <= i of T[i][k] x_k (this
  * rank's part of z = L^-1 r);  trans = 1: y_k = sum_{i >= k} T[i][k] x_i for the owned columns k and 0 for the others (this
  * rank's entries of alpha = L^-T z).  The caller sums the results of all ranks (one all-reduce of N doubles each). */
 int gpp_trmv_lower_cols(gpp_handle_t h, const double* T, int64_t ldt, int64_t N, const double* x, double* y, int64_t nb, int rank,
-                        int nranks, int trans);
+                        int nranks, int trans, int compact);
 
 /* out3 = { quad = z'z, logdet = 2 sum log U_ii, mll = -0.5*(quad + logdet + N log 2pi) } from a z the caller already holds
  * (the second half of gpp_mll_reduce; optim/mll_torch.py:116). */
@@ -205,7 +209,7 @@ int gpp_grad_reduce_rows(gpp_handle_t h, const double* U, int64_t N, int D, cons
 int gpp_grad_reduce_cols(gpp_handle_t h, const double* U, int64_t N, int D, const double* w, const double* sf2,
                          const int32_t* grp, int S, int kind, int d_split, const double* alpha, const double* Kinv,
                          int64_t ldk, int dU, int64_t nb, int rank, int nranks, double* g_w, double* g_sf2, double* g_tau,
-                         double* g_U);
+                         double* g_U, int compact);
 
 /*
  * K8 (models/gpregression.py:122-149 predict): V = Ksn Linv^T (M x N, scratch, may be NULL to skip var),

@@ -47,6 +47,12 @@ def test_sharded_more_ranks_and_block_counts(world, N, D, nb, kind, S, dU):
     out = _run([N, D, nb, kind, S, dU], world=world, port=29560 + (N * 7 + world * 13 + nb) % 400)  # distinct rendezvous ports
     for name, e in out["err"].items():
         assert e < 1e-9, (name, e, out)
+    # storage per rank ("28.8 GB (3.6 GB/GPU sharded)"): only the factor is N x N; L^-1 and Ky^-1 exist as the owned
+    # column blocks — ceil(blocks / P) blocks of nb columns each
+    nblk = -(-N // nb)
+    assert out["owned_cols"] == max(-(-nblk // world), 1) * nb, out
+    if nblk >= 2 * world:
+        assert out["matrix_bytes"] < (1.0 + 2.0 * (-(-nblk // world)) / nblk + 0.35) * out["full_matrix_bytes"], out
 
 
 @pytest.mark.gpu

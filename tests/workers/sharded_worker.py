@@ -176,7 +176,11 @@ def main():
             err[n] = float((a - b).abs().max() / b.abs().max().clamp_min(1e-300))
         from gpplus_amd import sharded as _sh
         calls = sum(getattr(w, "comm_calls", 0) for w in _sh._workspaces.values())
-        emit("RESULT " + json.dumps({"err": err, "mll": float(res["single"][0]), "backend": dist.get_backend(), "collectives": calls}))
+        # storage: ONE N x N matrix per rank (the replicated factor), the inverse and Ky^-1 only as owned column blocks
+        wsx = next(iter(_sh._workspaces.values()))
+        emit("RESULT " + json.dumps({"err": err, "mll": float(res["single"][0]), "backend": dist.get_backend(), "collectives": calls,
+                                     "matrix_bytes": wsx.nbytes(), "full_matrix_bytes": 8 * N * wsx.A.stride(0),
+                                     "owned_cols": wsx.Lc.shape[1], "nb": nb, "world": world}))
     emit(f"RANK{rank} same_as_rank0={same}")
     dist.barrier()
     dist.destroy_process_group()

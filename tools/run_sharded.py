@@ -22,7 +22,9 @@ def main():
     y = (torch.sin(U[:, 0]) + 0.1 * torch.randn(N, generator=g, dtype=torch.float64).to(dev))
     w = torch.full((D,), 0.1, dtype=torch.float64, device=dev); sf2 = torch.tensor([0.85], dtype=torch.float64, device=dev)
     tau = torch.tensor([2.5e-3], dtype=torch.float64, device=dev); mean = torch.zeros(N, dtype=torch.float64, device=dev)
-    ctx = get_context(dev); comm = sharded._Comm(None); ws = sharded._workspace(ctx, N, nb)
+    ctx = get_context(dev); comm = sharded._Comm(None); ws = sharded._workspace(ctx, N, nb, comm.rank, comm.world)
+    if rank == 0:
+        print('matrices per rank: %.2f GB (a full N x N fp64 matrix: %.2f GB)' % (ws.nbytes() / 1e9, 8e-9 * N * N), flush=True)
     def sync():
         torch.cuda.synchronize(); dist.barrier()
     for rep in range(reps + 1):
@@ -33,7 +35,7 @@ def main():
         sharded._backward(ctx, comm, ws)  # this rank's column blocks of Ky^-1 by back-substitution: nothing travels
         sync(); t4 = time.perf_counter()
         flat = torch.zeros(D + 2, dtype=torch.float64, device=dev)
-        ctx.grad_reduce_cols(U, w, sf2, None, 1, ws.alpha, ws.Li, 0, nb, comm.rank, comm.world, flat[:D], flat[D:D + 1], flat[D + 1:], None)
+        ctx.grad_reduce_cols(U, w, sf2, None, 1, ws.alpha, ws.Lc, 0, nb, comm.rank, comm.world, flat[:D], flat[D:D + 1], flat[D + 1:], None, compact=True)
         comm.allreduce(flat); sync(); t5 = time.perf_counter()
         if rank == 0 and rep > 0:
             tot = t5 - t0
