@@ -21,18 +21,51 @@ def _plateaued(history: List[float], j: int, window: int) -> bool:
     return bool((torch.mean(recent) - history[j]) <= 0)
 
 
-def _adam_run(model, mll, params, lr: float, num_iter: int, break_steps: int, verbose: bool) -> List[float]:
+def _graphed_step(model, mll, params, evaluations: int):
+    """The replayed form of one evaluation (gp-plus_amd/graphed.py::GraphedLossAndGrad), or None where it does not apply: a GPU
+    model below the look-ahead factorisation's size (its internal streams do not belong in a graph, and one evaluation hides the
+    host there anyway), enough evaluations to repay three warm-up evaluations and the capture, ``settings.graphed_objective`` on."""
+    from .. import settings
+    from ..linalg import LOOKAHEAD_MIN_N
+
+    plist = [p for p in params if p.requires_grad]
+    if not plist or not settings.graphed_objective.value() or evaluations <= 8:
+        return None
+    dev, n = plist[0].device, int(model.train_targets.shape[0])
+    if dev.type != "cuda" or n >= LOOKAHEAD_MIN_N or settings.sharded_evaluation.value() is not None:
+        return None
+    from ..graphed import GraphedLossAndGrad
+
+    def closure():
+        return -mll(model(*model.train_inputs), model.train_targets)
+
+    try:
+        return GraphedLossAndGrad(closure, plist, n, dev)
+    except RuntimeError as exc:  # a capture this stack refuses: the eager loop is the same computation — but say so, once
+        import warnings
+
+        warnings.warn(f"fit_model_torch: the evaluation could not be captured as a HIP graph ({exc}); running it eagerly",
+                      RuntimeWarning)
+        return None
+
+
+def _adam_run(model, mll, params, lr: float, num_iter: int, break_steps: int, verbose: bool, graphed=None) -> List[float]:
     """One start point: up to ``num_iter`` Adam steps on ``-mll`` (optim/mll_torch.py:99-128).  Returns the losses seen
-    BEFORE each step; the last entry is what the restart is judged by."""
+    BEFORE each step; the last entry is what the restart is judged by.  ``graphed``: the evaluation as a replayed HIP graph
+    (Adam itself stays outside it, so its arithmetic is the eager one); an iteration the graph hands back — factorisation status
+    not zero, a non-finite number — is evaluated eagerly with the jitter policy and the exceptions of the reference."""
     optimizer = torch.optim.Adam(params, lr=lr)
     history: List[float] = []
     bar = tqdm(range(num_iter), desc='Epoch', position=0, leave=True, disable=not verbose)
     for j in bar:
-        optimizer.zero_grad()
-        loss = -mll(model(*model.train_inputs), model.train_targets)
-        loss.backward()
+        value = graphed.step() if graphed is not None else None
+        if value is None:
+            optimizer.zero_grad()
+            loss = -mll(model(*model.train_inputs), model.train_targets)
+            loss.backward()
+            value = None
         optimizer.step()
-        history.append(loss.item())
+        history.append(loss.item() if value is None else value)
         if verbose:
             bar.set_description(f'Epoch {j} - loss {history[-1]:.4f}')
         if _plateaued(history, j, break_steps):
@@ -50,13 +83,23 @@ def fit_model_torch(model, model_param_groups: Optional[List] = None, lr_default
     mll = ExactMarginalLogLikelihood(model.likelihood, model)
     best_loss, best_state = math.inf, model.state_dict()
     histories = []
+    # the evaluation as one replayed HIP graph at the examples' sizes (the reference's notebooks and BO loop call this function
+    # directly): captured once per fit, the restarts only change the parameters' values
+    graphed = _graphed_step(model, mll, list(model.parameters()), (num_restarts + 1) * num_iter) if model_param_groups is None else None
+    fit_model_torch.last_graph = None
     for restart in range(num_restarts + 1):
         params = model.parameters() if model_param_groups is None else model_param_groups
-        history = _adam_run(model, mll, params, lr_default, num_iter, break_steps, verbose)
+        history = _adam_run(model, mll, params, lr_default, num_iter, break_steps, verbose, graphed)
         histories.append(history)
         if history and history[-1] < best_loss:  # strict, as in the reference: ties keep the earlier start
             best_loss, best_state = history[-1], deepcopy(model.state_dict())
         if restart < num_restarts:
             model.reset_parameters()  # next start point: a draw from the priors (models/gpregression.py:168-174)
+    if graphed is not None:  # only the counters outlive the fit: the graph and its memory pool are released here
+        from types import SimpleNamespace
+        fit_model_torch.last_graph = SimpleNamespace(replays=graphed.replays, declined=graphed.declined)
+        for p in model.parameters():
+            p.grad = None  # (they point into the graph's pool)
+        graphed = None
     model.load_state_dict(best_state)
     return best_loss, histories

@@ -174,3 +174,49 @@ def test_large_problems_and_the_switch_leave_the_objective_eager():
 
     with pytest.raises(RuntimeError, match="N <"):
         GraphedObjective(lambda: None, [], 5000, torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("kind", ["plain", "mixed", "multifidelity"])
+def test_fit_model_torch_replayed_graph_equals_the_eager_loop(kind):
+    """The sequential Adam driver as the reference's notebooks and BO loop call it (optim/mll_torch.py:104-137): with the
+    evaluation replayed as one HIP graph (Adam outside it) the loss histories, the winner and the final parameters are bit for bit
+    those of the eager loop — restarts included; the graph serves every iteration."""
+    from gpplus_amd import settings
+    from gpplus_amd.optim.mll_torch import fit_model_torch
+
+    out = {}
+    for on in (True, False):
+        torch.manual_seed(5)  # (the latent map of the categorical inputs is drawn from the global generator at construction)
+        m = _model(kind, n=260)
+        torch.manual_seed(11)
+        with settings.graphed_objective(on):
+            f, hist = fit_model_torch(m, num_iter=14, num_restarts=2, verbose=False)
+        out[on] = (f, hist, {k: v.clone() for k, v in m.state_dict().items()})
+        g = fit_model_torch.last_graph
+        if on:
+            assert g is not None and g.replays == 3 * 14 and g.declined == 0, g
+        else:
+            assert g is None
+    assert out[True][0] == out[False][0]
+    assert out[True][1] == out[False][1]
+    for k, v in out[False][2].items():
+        assert torch.equal(out[True][2][k], v), k
+
+
+def test_fit_model_torch_hands_an_indefinite_step_to_the_eager_path():
+    """A start point whose covariance needs jitter: the replay reports the status, the iteration runs eagerly (jitter warning as
+    without the graph) and the fit goes on."""
+    from gpplus_amd.optim.mll_torch import fit_model_torch
+
+    m = _model("plain", n=200)
+    with torch.no_grad():
+        m.likelihood.noise_covar.raw_noise.fill_(-40.0)  # tau = lb = 1e-8 on duplicated rows' scale: indefinite in fp64 rounding
+        m.covar_module.base_kernel.raw_lengthscale.fill_(-6.0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        f, hist = fit_model_torch(m, num_iter=12, num_restarts=0, verbose=False)
+    g = fit_model_torch.last_graph
+    assert g is not None and g.replays == 12
+    assert np.isfinite(f) and len(hist[0]) == 12
+    if g.declined:
+        assert any("jitter" in str(x.message) for x in w)
