@@ -418,6 +418,8 @@ def run_sharded(args, dist, dev, rank, world, n, steps, warmup):
     from gpplus_amd.test_functions.baseline_configs import apply_theta, make_config
 
     cfg_name = "C5" if n > 30000 else "C2"
+    if not args.nb:
+        args.nb = 2048 if n >= 40000 else 1024
     X, y, kw, theta = make_config(cfg_name, n)
     model = GP_Plus(X, y, dtype=torch.float64, device=dev, **kw)
     apply_theta(model, theta)
@@ -548,7 +550,9 @@ def main():
     ap.add_argument("--mode", choices=["auto", "replicas", "sharded"], default="auto",
                     help="auto (default): the replica leg, plus the sharded C5 leg when N > 1.  replicas / sharded: that "
                          "leg only (sharded with one rank measures the algorithm without communication)")
-    ap.add_argument("--nb", type=int, default=1024, help="block height of the sharded evaluation")
+    ap.add_argument("--nb", type=int, default=0,
+                    help="block height of the sharded evaluation (0 = by size: 2048 from N = 40000 — one rank at C5: 3450 ms "
+                         "against 3554 with 1024 on the round-4 build —, 1024 below: 156.6 ms at N = 20000 against 164 with 2048)")
     ap.add_argument("--sharded-n", type=int, default=60000, help="size of the sharded leg (C5)")
     ap.add_argument("--sharded-steps", type=int, default=2)
     ap.add_argument("--sharded-warmup", type=int, default=1)

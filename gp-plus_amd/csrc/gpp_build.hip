@@ -10,8 +10,11 @@
 // triangle), instead of the reference's ~6 N^2-sized fp64 passes.
 //
 // Tile: 64x64 outputs per 256-thread work-group, 4x4 per thread.  The two 64-row slabs of U are staged in LDS
-// pre-multiplied by sqrt(w_d), stored [d][row] so a thread's 4 rows/cols are one 32-byte LDS read.  Each thread
-// stores 4 consecutive doubles per row: 16 lanes x 32 B = 512 B contiguous per row segment.
+// pre-multiplied by sqrt(w_d), stored [d][row].  A thread's 4 rows are one 32-byte LDS read (a broadcast: 16 lanes share it); its 4
+// COLUMNS are two pairs, {2 tx, 2 tx + 1} and {32 + 2 tx, 32 + 2 tx + 1}: each ds_read_b128 of 16 lanes then covers 256
+// contiguous bytes = every bank once.  (Round 3 read 4 consecutive columns per thread: lanes k and k + 8 of a 16-lane group hit
+// the same banks, and SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.31, profiles/r03_sq_counters.txt.)  Each thread stores two
+// 16-byte pieces per row: 16 lanes x 16 B = 256 B contiguous per piece.
 #include "gpp_internal.h"
 
 #include <atomic>
@@ -101,10 +104,10 @@ __global__ __launch_bounds__(256) void gpp_cov_tile(const double* __restrict__ U
     }
   const int dsp = (!MAT || kind == 0) ? D : d_split;
   for (int d = 0; d < D; ++d) {
-    // the thread's 4 rows / 4 columns of feature d: one 32-byte LDS read each (two ds_read_b128, conflict-free)
+    // the thread's 4 rows (one 32-byte broadcast read) and 2 + 2 columns (two conflict-free ds_read_b128) of feature d
     typedef double v2d __attribute__((ext_vector_type(2)));
     const v2d a01 = reinterpret_cast<const v2d*>(sa + d * TB + 4 * ty)[0], a23 = reinterpret_cast<const v2d*>(sa + d * TB + 4 * ty)[1];
-    const v2d b01 = reinterpret_cast<const v2d*>(sb + d * TB + 4 * tx)[0], b23 = reinterpret_cast<const v2d*>(sb + d * TB + 4 * tx)[1];
+    const v2d b01 = *reinterpret_cast<const v2d*>(sb + d * TB + 2 * tx), b23 = *reinterpret_cast<const v2d*>(sb + d * TB + 32 + 2 * tx);
     const double ua[4] = {a01.x, a01.y, a23.x, a23.y}, ub[4] = {b01.x, b01.y, b23.x, b23.y};
     if (!MAT || d < dsp) {
 #pragma unroll
@@ -133,22 +136,23 @@ __global__ __launch_bounds__(256) void gpp_cov_tile(const double* __restrict__ U
     double v[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
-      const int64_t j = j0 + 4 * tx + b;
+      const int64_t j = j0 + 2 * tx + (b & 1) + ((b >> 1) << 5);
       double x = sf2 * (MAT ? kfun(r2a[a][b], r2b[MAT ? a : 0][MAT ? b : 0], kind, ec) : gpp_exp_nonpos(-r2a[a][b], ec));
       if (add_diag && i == j) x += (tau ? tau[grp ? grp[i] : 0] : 0.0) + jitter;
       v[b] = x;
     }
-    double* out = K + i * ld + j0 + 4 * tx;
-    const int64_t jrem = Nb - (j0 + 4 * tx);
-    if (jrem >= 4 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
-      typedef double v2d __attribute__((ext_vector_type(2)));
-      v2d p0 = {v[0], v[1]}, p1 = {v[2], v[3]};
-      reinterpret_cast<v2d*>(out)[0] = p0;
-      reinterpret_cast<v2d*>(out)[1] = p1;
-    } else {
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
-        if (b < jrem) out[b] = v[b];
+    for (int h = 0; h < 2; ++h) {  // the two column pairs of this thread
+      double* out = K + i * ld + j0 + 2 * tx + 32 * h;
+      const int64_t jrem = Nb - (j0 + 2 * tx + 32 * h);
+      if (jrem >= 2 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        v2d p0 = {v[2 * h], v[2 * h + 1]};
+        *reinterpret_cast<v2d*>(out) = p0;
+      } else {
+        if (jrem >= 1) out[0] = v[2 * h];
+        if (jrem >= 2) out[1] = v[2 * h + 1];
+      }
     }
   }
 }

@@ -235,10 +235,18 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
   const GppExpConsts ec = gpp_exp_consts();
   if (tid < DT) sw[tid] = (tid < D) ? w[tid] : 0.0;
 
+  // per-feature sums of this thread over all its tiles — in registers up to 16 features; beyond that (2 x DT registers, on top of
+  // the 4 x 4 blocks of the feature gradients: <32,true,true> spilled 122 registers, <64,true,true> 645) every half-tile's
+  // per-feature sum is reduced over the wave at once and kept in LDS, one accumulator per wave and feature
+  constexpr bool WACC = (DT >= 32);
+  __shared__ double wacc[WACC ? 4 * DT : 1];
   double my_sf2 = 0.0;
-  double my_w[DT];
+  double my_w[WACC ? 1 : DT];
 #pragma unroll
-  for (int d = 0; d < DT; ++d) my_w[d] = 0.0;
+  for (int d = 0; d < (WACC ? 1 : DT); ++d) my_w[d] = 0.0;
+  if constexpr (WACC) {
+    for (int e = tid; e < 4 * DT; e += 256) wacc[e] = 0.0;
+  }
 
   for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
     int64_t ti, tj;
@@ -269,23 +277,26 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
     double G[4][4], GM[4][4];  // (GM only lives in the Matern instantiation; G / GM feed the g_U part below)
     // Two half-tiles of 2 rows x 4 columns per thread, each with its own two passes over the features: the live set stays
     // at 8 distances + 8 Kinv entries + 8 G values (two waves per SIMD), and every LDS access is a 16-byte read of
-    // consecutive rows / columns of one feature (conflict-free; 16 scalar reads at a 32-byte lane stride were 2-way conflicts).
+    // consecutive rows / columns of one feature.  Round 4: a thread's columns are the PAIRS {2 tx, 2 tx + 1} and {32 + 2 tx, ...}, so
+    // the 16 lanes of a ds_read_b128 cover 256 contiguous bytes (every bank once); with 4 consecutive columns per thread lanes
+    // k and k + 8 met in the same banks (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.36, profiles/r03_sq_counters.txt).
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
       const int ra = 4 * ty + 2 * h;  // first of this half's two rows inside the tile
       double kin[2][4];
 #pragma unroll
       for (int a = 0; a < 2; ++a) {
-        const int64_t i = i0 + ra + a, jb = j0 + 4 * tx;
+        // the thread's columns: the pairs {2 tx, 2 tx + 1} and {32 + 2 tx, 32 + 2 tx + 1} of the tile (see the LDS reads below)
+        const int64_t i = i0 + ra + a, jb = j0 + 2 * tx;
         // (shard_cols == 2: Kinv holds only the owned column blocks, side by side — see gpp_trmv_lower_cols)
-        const int64_t pjb = (shard_cols == 2) ? ((j0 / shard_nb) / shard_nranks) * shard_nb + (j0 % shard_nb) + 4 * tx : jb;
+        const int64_t pjb = (shard_cols == 2) ? ((j0 / shard_nb) / shard_nranks) * shard_nb + (j0 % shard_nb) + 2 * tx : jb;
         const double* src = Kinv + (i < N ? i : N - 1) * ldk + pjb;
-        if (pjb + 4 <= ldk) {  // two 16-byte loads, issued before the arithmetic (entries above the diagonal are never used)
-          const v2d p0 = reinterpret_cast<const v2d*>(src)[0], p1 = reinterpret_cast<const v2d*>(src)[1];
+        if (pjb + 34 <= ldk) {  // two 16-byte loads, issued before the arithmetic (entries above the diagonal are never used)
+          const v2d p0 = *reinterpret_cast<const v2d*>(src), p1 = *reinterpret_cast<const v2d*>(src + 32);
           kin[a][0] = p0.x; kin[a][1] = p0.y; kin[a][2] = p1.x; kin[a][3] = p1.y;
         } else {
 #pragma unroll
-          for (int b = 0; b < 4; ++b) kin[a][b] = (jb + b < N) ? src[b] : 0.0;
+          for (int b = 0; b < 4; ++b) kin[a][b] = (jb + (b & 1) + ((b >> 1) << 5) < N) ? src[(b & 1) + ((b >> 1) << 5)] : 0.0;
         }
       }
       double r2[2][4], r2m[2][4];
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
 #pragma unroll 4
       for (int d = 0; d < DT; ++d) {
         const v2d ua = *reinterpret_cast<const v2d*>(sa + d * GT + ra);
-        const v2d b01 = reinterpret_cast<const v2d*>(sb + d * GT + 4 * tx)[0], b23 = reinterpret_cast<const v2d*>(sb + d * GT + 4 * tx)[1];
+        const v2d b01 = *reinterpret_cast<const v2d*>(sb + d * GT + 2 * tx), b23 = *reinterpret_cast<const v2d*>(sb + d * GT + 32 + 2 * tx);
         const double ub[4] = {b01.x, b01.y, b23.x, b23.y};
         const double wd = sw[d];
 #pragma unroll
@@ -317,7 +328,7 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
         const int64_t i = i0 + ra + a;
 #pragma unroll
         for (int b = 0; b < 4; ++b) {
-          const int64_t j = j0 + 4 * tx + b;
+          const int64_t j = j0 + 2 * tx + (b & 1) + ((b >> 1) << 5);
           double g = 0.0, gm = 0.0;
           if (i < N && j <= i) {
             const double er = gpp_exp_nonpos(-r2[a][b], ec);
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
               kv = er * (1.0 + aa + aa * aa * (1.0 / 3.0)) * ea;
               kd = er * (5.0 / 3.0) * (1.0 + aa) * ea;
             }
-            const double Wij = 0.5 * (sal_a[ra + a] * sal_b[4 * tx + b] - kin[a][b]);
+            const double Wij = 0.5 * (sal_a[ra + a] * sal_b[2 * tx + (b & 1) + ((b >> 1) << 5)] - kin[a][b]);
             const double mult = (i == j) ? 1.0 : 2.0;
             my_sf2 = fma(mult * Wij, kv, my_sf2);
             g = mult * Wij * sf2 * kv;
@@ -345,7 +356,7 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
 #pragma unroll
       for (int d = 0; d < DT; ++d) {
         const v2d ua = *reinterpret_cast<const v2d*>(sa + d * GT + ra);
-        const v2d b01 = reinterpret_cast<const v2d*>(sb + d * GT + 4 * tx)[0], b23 = reinterpret_cast<const v2d*>(sb + d * GT + 4 * tx)[1];
+        const v2d b01 = *reinterpret_cast<const v2d*>(sb + d * GT + 2 * tx), b23 = *reinterpret_cast<const v2d*>(sb + d * GT + 32 + 2 * tx);
         const double ub[4] = {b01.x, b01.y, b23.x, b23.y};
         double s = 0.0;
 #pragma unroll
@@ -355,7 +366,12 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
             const double df = (a ? ua.y : ua.x) - ub[b];
             s = fma(-((!MAT || d < dsp) ? g2[a][b] : gm2[a][b]) * df, df, s);
           }
-        my_w[d] += s;
+        if constexpr (WACC) {
+          const double t = wave_sum(s);
+          if ((tid & 63) == 0) wacc[(tid >> 6) * DT + d] += t;
+        } else {
+          my_w[d] += s;
+        }
       }
       if constexpr (HASU) {  // the manifold-gradient part below wants the whole 4 x 4 block
 #pragma unroll
@@ -376,7 +392,7 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
         double s = 0.0;
 #pragma unroll
         for (int b = 0; b < 4; ++b)
-          s = fma(rbf_dim ? G[a][b] : GM[a][b], sa[d * GT + 4 * ty + a] - sb[d * GT + 4 * tx + b], s);
+          s = fma(rbf_dim ? G[a][b] : GM[a][b], sa[d * GT + 4 * ty + a] - sb[d * GT + 2 * tx + (b & 1) + ((b >> 1) << 5)], s);
         rs[a] = s;
       }
 #pragma unroll
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
         double s = 0.0;
 #pragma unroll
         for (int a = 0; a < 4; ++a)
-          s = fma(rbf_dim ? G[a][b] : GM[a][b], sb[d * GT + 4 * tx + b] - sa[d * GT + 4 * ty + a], s);
+          s = fma(rbf_dim ? G[a][b] : GM[a][b], sb[d * GT + 2 * tx + (b & 1) + ((b >> 1) << 5)] - sa[d * GT + 4 * ty + a], s);
         cs[b] = s;
       }
       __syncthreads();
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
         for (int q = 0; q < 16; ++q) rsum += rowpart[tid * 16 + q];
       __syncthreads();
 #pragma unroll
-      for (int b = 0; b < 4; ++b) rowpart[(4 * tx + b) * 16 + ty] = cs[b];
+      for (int b = 0; b < 4; ++b) rowpart[(2 * tx + (b & 1) + ((b >> 1) << 5)) * 16 + ty] = cs[b];
       __syncthreads();
       if (tid < GT) {
         double csum = 0.0;
@@ -415,9 +431,13 @@ __global__ __launch_bounds__(256) void gpp_grad_tiles(const double* __restrict__
   for (int q = 0; q < nrec; ++q) {
     double v = my_sf2;
     if (q < D) {
+      if constexpr (WACC) {
+        v = ((tid & 63) == 0) ? wacc[(tid >> 6) * DT + q] : 0.0;
+      } else {
 #pragma unroll
-      for (int d = 0; d < DT; ++d)
-        if (q == d) v = my_w[d];
+        for (int d = 0; d < DT; ++d)
+          if (q == d) v = my_w[d];
+      }
     }
     __syncthreads();
     red[tid] = v;
