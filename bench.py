@@ -365,9 +365,9 @@ def run_replicas(args, dist, dev, rank, world, local_rank):
         eval_tf = N ** 3 / (elapsed / args.steps) / 1e12
         # HBM-side bytes come from committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside this
         # process); they only apply to the size they were collected at
-        pmc_l = _pmc_record("r03_lauum_pmc.json") if N == N_C2 else None
-        pmc_p = _pmc_record("r03_potrf_pmc.json") if N == N_C2 else None
-        pmc_t = _pmc_record("r03_trtri_pmc.json") if N == N_C2 else None
+        pmc_l = _pmc_record("r04_lauum_pmc.json") if N == N_C2 else None
+        pmc_p = _pmc_record("r04_potrf_pmc.json") if N == N_C2 else None
+        pmc_t = _pmc_record("r04_trtri_pmc.json") if N == N_C2 else None
         third = N ** 3 / 3
         entries = []
         for name, kernel, pmc in (

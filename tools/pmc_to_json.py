@@ -1,5 +1,5 @@
-"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/collect_r03_profiles.sh) into the per-stage traffic records that
-bench.py reads: profiles/r03_{potrf,trtri,lauum}_pmc.json.  Each record carries the signature of the kernel build it was collected
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/collect_r04_profiles.sh) into the per-stage traffic records that
+bench.py reads: profiles/r04_{potrf,trtri,lauum}_pmc.json.  Each record carries the signature of the kernel build it was collected
 with (gpp_version()), and bench.py refuses a record whose signature differs from the library it runs.
 Bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB — FETCH_SIZE counts 128-byte requests at 64 B on gfx950 (MI355X_MICROARCH.md, HBM) — per
 evaluation (the passes run tools/bench_stages.py N 8 1 = two evaluations).
@@ -42,8 +42,8 @@ def main():
     }
     for name, (kernel, f, w, what) in recs.items():
         rec = {"kernel": kernel, "lib_signature": sig, "fetch_bytes_per_launch": 2 * f * 1024, "write_bytes_per_launch": w * 1024,
-               "traffic_bytes_per_launch": (2 * f + w) * 1024, "note": f"{how}; {what}; kernel build {sig}; profiles/r03_pmc_fetch_write.txt"}
-        with open(os.path.join(out, f"r03_{name}_pmc.json"), "w") as fh:
+               "traffic_bytes_per_launch": (2 * f + w) * 1024, "note": f"{how}; {what}; kernel build {sig}; profiles/r04_pmc_fetch_write.txt"}
+        with open(os.path.join(out, f"r04_{name}_pmc.json"), "w") as fh:
             json.dump(rec, fh, indent=1)
         print(f"{name:6s}: fetch {2 * f * 1024 / 1e9:8.2f} GB  write {w * 1024 / 1e9:7.2f} GB  total {(2 * f + w) * 1024 / 1e9:8.2f} GB per evaluation"
               f"   (algorithmic: 3.2 GB = read + write one triangle)")
