@@ -27,4 +27,8 @@ grep -v "amdgpu\|Warning" $R/configs.txt > $P/r04_configs_C1_C5_single_gpu.txt
  echo "== all 256 CUs"; grep "K=" $R/update_rate_vs_tiles.txt
  echo "== on the CU-masked throughput stream (224 CUs; GPP_GEMM_ON_UPD=1)"; grep "K=" $R/update_rate_vs_tiles_masked.txt) > $P/r04_update_rate_vs_tiles.txt
 (grep -v amdgpu $R/hbm_probe.txt; grep -v amdgpu $R/exp_check.txt; echo; echo "per-stage times at N=20000 (tools/bench_stages.py 20000 8 5):"; grep -v amdgpu $R/stages_20000.txt) > $P/r04_hbm_probe.txt
-true
+(echo "Statically scheduled steps of gpp_potrf_ws (gpp_exec_f64 + gpp_plan.hip), round 4: per-task stamps (tools/exec_trace.py), N = 20000 then 15000"
+ grep -v amdgpu $R/exec_trace_20000.txt; echo; grep -v amdgpu $R/exec_trace_15000.txt
+ echo; echo "== A/B against launches per product and knob sweep on ONE box (tools/sweep_exec.sh; potrf ms at N = 15000 / 20000)"; grep -v amdgpu $R/exec_sweep.txt) > $P/r04_exec_schedule.txt
+(echo "Sequential Adam driver (fit_model_torch) with the evaluation replayed as one HIP graph, tools/bench_adam_seq.py"; grep -v amdgpu $R/adam_seq.txt) > $P/r04_adam_seq_replay.txt
+ls $P | grep r04
