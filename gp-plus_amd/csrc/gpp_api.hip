@@ -384,13 +384,23 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
         P = h->exec_plan = gpp_plan_potrf_exec(N, NB, K, W, F, tune);
       }
       if (P) {
+        bool ok = true;
         if (P->A != cm.A || P->ld != cm.ld || P->Li != cm.Li || P->ldi != cm.ldi || P->T != T || P->ldt != ldt || !P->d_tasks) {
           if (P->d_tasks) HIP_TRY(hipDeviceSynchronize());
           gpp_plan_bind(P, cm.A, cm.ld, cm.Li, cm.ldi, T, ldt);
-          HIP_TRY(gpp_plan_upload(P));
+          if (gpp_plan_upload(P) != hipSuccess) {
+            // no memory for the plan's device copy (a few MB): not an error of the factorisation — this handle keeps to launches
+            (void)hipGetLastError();
+            gpp_plan_free(P);
+            h->exec_plan = nullptr;
+            h->exec_sched = 0;
+            ok = false;
+          }
         }
-        plan = P;
-        HIP_TRY(gpp_launch_fill_i32(cm.s, P->d_counters, P->ncounters, 0));
+        if (ok) {
+          plan = P;
+          HIP_TRY(gpp_launch_fill_i32(cm.s, P->d_counters, P->ncounters, 0));
+        }
       }
     }
   }
@@ -876,6 +886,17 @@ int gpp_potrf_ws(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv,
     int wgs = h->ncu;
     if (h->cu_split == 1 && h->stream == h->panel_stream) wgs = h->panel_cus;
     else if (h->cu_split == 1 && (h->stream == h->upd_stream || h->stream == h->fill_stream)) wgs = h->ncu - h->panel_cus;
+    else if (h->stream) {
+      // a caller's stream may carry a CU mask of its own: the launch must not have more work-groups than that mask has CUs
+      uint32_t mask[32] = {0};
+      if (hipExtStreamGetCUMask(h->stream, 32, mask) == hipSuccess) {
+        int cus = 0;
+        for (int c = 0; c < h->ncu && c < 1024; ++c) cus += (mask[c >> 5] >> (c & 31)) & 1u;
+        if (cus >= 2 && cus < wgs) wgs = cus;
+      } else {
+        (void)hipGetLastError();
+      }
+    }
     GPP_TRY(launch_panel(h, c, 0, N, wgs));
     h->inv_nblocks = 1;
     h->inv_o[0] = 0;

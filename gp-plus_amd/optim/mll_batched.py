@@ -197,7 +197,11 @@ def fit_model_torch_batched(model, lr_default: float = 0.01, num_iter: int = 100
     if settings.graphed_objective.value() and dev.type == "cuda" and num_iter > 8:
         try:
             graphed = _GraphedLossAndGrad(obj, params, active)
-        except RuntimeError:  # (a capture the stack refuses: the eager loop below is the same computation)
+        except RuntimeError as exc:  # a capture the stack refuses: the eager loop below is the same computation — but say so
+            import warnings
+
+            warnings.warn(f"fit_model_torch_batched: the step could not be captured as a HIP graph ({exc}); running it eagerly",
+                          RuntimeWarning)
             graphed = None
     fit_model_torch_batched.last_graph = None  # (for tests and tools: the finished fit's counters, set below)
     for j in range(num_iter):

@@ -83,7 +83,14 @@ class MLLObjective:
                 self._graph = GraphedObjective(
                     lambda: -marginal_log_likelihood(self.model, self.add_prior, self.regularization_parameter), params,
                     n_points, dev)
-            except (NotPSDError, NanError, RuntimeError):  # (an indefinite warm-up point, or a capture the stack refuses)
+            except (NotPSDError, NanError):  # an indefinite warm-up point: the eager path has the jitter policy for it
+                self._graph_failed = True
+                return None
+            except RuntimeError as exc:  # a capture the stack refuses — the eager evaluation is the same computation, but say so
+                import warnings
+
+                warnings.warn(f"fit_model_scipy: the objective could not be captured as a HIP graph ({exc}); evaluating eagerly",
+                              RuntimeWarning)
                 self._graph_failed = True
                 return None
         return getattr(self, "_graph", None)
