@@ -9,6 +9,12 @@ from gpplus_amd.backend import get_context, square_buffer
 args = [int(a) for a in sys.argv[1:]] or [15000, 200, 20000, 200, 30000, 40]
 ctx = get_context("cuda:0")
 info = torch.zeros(1, dtype=torch.int32, device="cuda")
+# STRESS_BG=n: n copies of 1 GB on a side stream beside every factorisation (memory-saturating traffic: what exposed the missing
+# wait behind buffer_wbl2 in round 3; the statically scheduled steps hand data between work-groups the same way)
+BG = int(os.environ.get("STRESS_BG", "0"))
+if BG:
+    bg_stream = torch.cuda.Stream()
+    bg_a = torch.empty(1 << 27, dtype=torch.float64, device="cuda"); bg_b = torch.empty_like(bg_a)
 for N, reps in zip(args[0::2], args[1::2]):
     g = torch.Generator(device="cuda").manual_seed(N)
     U = torch.randn(N, 8, dtype=torch.float64, device="cuda", generator=g)
@@ -19,6 +25,11 @@ for N, reps in zip(args[0::2], args[1::2]):
     t0 = time.time()
     for rep in range(reps):
         ctx.kernel_build(U, w, sf2, tau, None, A, uplo=2)
+        if BG:
+            bg_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(bg_stream):
+                for _ in range(BG):
+                    bg_b.copy_(bg_a)
         ctx.potrf(A, Li, info, T)
         torch.cuda.synchronize()
         assert int(info.item()) == 0, (N, rep, int(info.item()))
