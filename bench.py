@@ -371,8 +371,11 @@ def run_replicas(args, dist, dev, rank, world, local_rank):
         third = N ** 3 / 3
         entries = []
         for name, kernel, pmc in (
-                ("potrf", "gpp_potrf_ws: look-ahead blocked Cholesky; ~500 launches of gpp_gemm_f64<2,64,64,0,16,2> (trailing "
-                          "updates, row solves) + gpp_leaf_potrf_inv on CU-masked streams", pmc_p),
+                ("potrf", "gpp_potrf_ws: look-ahead blocked Cholesky; its throughput-bound steps ONE persistent launch of gpp_exec_f64 "
+                          "(448 work-groups walking host-planned tile lists gated by device counters: row solves, trailing updates) + "
+                          "gpp_panel_potrf_inv on 32 reserved CUs with filler launches between; the chain-bound tail as launches of "
+                          "gpp_gemm_f64<2,64,64,0,16,2>.  Traffic record: the launch-per-product form of the same steps (counter "
+                          "collection serialises dispatches)", pmc_p),
                 ("trtri", "gpp_trtri: batched pair merges, gpp_gemm_f64<2,64,64,0,16,2>", pmc_t),
                 ("lauum", "gpp_gemm_f64<2, 64, 64, 1, 16, 2> (Kinv = Linv^T Linv, ONE lower-triangular TN launch)", pmc_l)):
             if name in stage_rate:
