@@ -943,6 +943,10 @@ int gpp_lauum(gpp_handle_t h, const double* Linv, int64_t N, int64_t ldi, double
   if (int r = check_mat(Kinv, ldk, N, 5)) return r;
   GemmArgs g = mk(Linv, ldi, Linv, ldi, Kinv, ldk, N, N, N, 1.0, 0.0);
   g.a_mask = 2; g.b_mask = 2; g.klo_mode = 3; g.c_lower = 1; g.tag = 1;
+  // experiment knob: walk every tile's K range from the top (k = N) down, so that the tile rows in flight — whose ranges start at
+  // different k but all END at N — sweep the shared operand columns in lockstep
+  static const int krev = getenv("GPP_LAUUM_KREV") ? atoi(getenv("GPP_LAUUM_KREV")) : 0;
+  g.k_reverse = krev;
   // one launch of long-K triangular tiles: small tiles balance it until there are several waves of big ones (measured:
   // N = 1024 0.167 / 0.061 / 0.034 ms with 128 / 64 / 32-wide tiles, 2048 0.312 / 0.130 / 0.098, 3072 0.490 / 0.231 /
   // 0.278, 4096 0.742 / 0.502 / 0.610, 6144 1.38 / 1.55 / 1.94)
