@@ -533,9 +533,38 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
       return trtri_level(cf, cm.A, cm.ld, cm.Li, cm.ldi, T, ldt, 0, o + nb, o, [](int64_t) { return false; }, 1, 0, 0, 0,
                          t128 < border_t128 ? 64 : 0, border_early ? D : nullptr);
     };
-    if (border && o > 0 && border_early) HIP_TRY(border_step());
+    // Experiment knob GPP_BORDER_RL=1 (round 4, measured and NOT adopted): the bordered inverse RIGHT-looking, as rank-nb updates
+    // of running sums kept in the scratch T (what the sharded forward sweep does, gp-plus_amd/sharded.py): with X = L^-1, step k
+    //   A(k): X[k, :k) = -X_kk S_k                 S_k = T[o:o+nb, 0:o): sum over j < k of L[k, j] X[j, :]   (K <= nb, + mirror)
+    //   B(k): S_m += L[m, k] X[k, :k+1), m > k     ONE product with K = nb over (N - o - nb) x (o + nb) entries
+    // instead of the left-looking X[k, :k) = -X_kk (U[:k, k]^T X[:k, :k)) whose K grows to N and whose few long tiles run
+    // 64 wide.  Correct (the kernel tests pass with it) and no faster: potrf + inverse 16.46 vs 16.10 ms at N = 10 000, 9.45 vs 9.21
+    // at 8192, 5.28 vs 5.07 at 6144, 20.7 vs 21.1 at 11 264 — at these sizes the throughput CUs are the shared bottleneck of the
+    // factor's updates and the inverse's products whatever the products' shape (profiles/EXPERIMENTS.md, round 4).
+    static const bool border_rl = getenv("GPP_BORDER_RL") && atoi(getenv("GPP_BORDER_RL")) != 0;
+    auto border_A = [&]() -> hipError_t {
+      HIP_TRY(hipStreamWaitEvent(cf, D, 0));  // this block's inverse (its sums are complete in stream order: B(k-1))
+      GemmArgs g2 = mk(cm.Li + o * cm.ldi + o, cm.ldi, T + o * ldt, ldt, cm.Li + o * cm.ldi, cm.ldi, nb, o, nb, -1.0, 0.0);
+      g2.a_mask = 1; g2.khi_mode = 1; g2.row_reverse = 1;
+      g2.C2 = cm.Li + o; g2.ldc2 = cm.ldi;
+      return gpp_launch_gemm(cf, 2, g2, 1);
+    };
+    auto border_B = [&](hipEvent_t row_solved) -> hipError_t {
+      HIP_TRY(hipStreamWaitEvent(cf, row_solved, 0));  // block row o of U is final
+      const int64_t o1 = o + nb, M = N - o1;
+      if (o > 0) {  // the columns left of this block: X[k, :k) from A(k) above
+        GemmArgs b1 = mk(cm.A + o * cm.ld + o1, cm.ld, cm.Li + o * cm.ldi, cm.ldi, T + o1 * ldt, ldt, M, o, nb, 1.0, 1.0);
+        HIP_TRY(gpp_launch_gemm(cf, 2, b1, 1));
+      }
+      // this block's own columns start the sums (beta = 0: the scratch is never cleared): X_kk, lower triangular
+      GemmArgs b2 = mk(cm.A + o * cm.ld + o1, cm.ld, cm.Li + o * cm.ldi + o, cm.ldi, T + o1 * ldt + o, ldt, M, nb, nb, 1.0, 0.0);
+      b2.b_mask = 2; b2.klo_mode = 2;
+      return gpp_launch_gemm(cf, 2, b2, 1);
+    };
+    if (border && border_rl && o > 0) HIP_TRY(border_A());
+    if (border && !border_rl && o > 0 && border_early) HIP_TRY(border_step());
     if (rem == 0) {
-      if (border && o > 0 && !border_early) HIP_TRY(border_step());
+      if (border && !border_rl && o > 0 && !border_early) HIP_TRY(border_step());
       if (be_wait) HIP_TRY(hipStreamWaitEvent(cu.s, be_wait, 0));
       break;
     }
@@ -570,6 +599,7 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
     if (border) {
       R = next_event(h);
       HIP_TRY(hipEventRecord(R, cu.s));
+      if (border_rl) HIP_TRY(border_B(R));
     }
     if (rest > 0 && !merge_upd) {  // the part of the next block row to the right of its diagonal block
       GemmArgs g2 = mk(Urow + (o + nb), cm.ld, Urow + (o + nb + nb2), cm.ld, cm.A + (o + nb) * cm.ld + (o + nb + nb2), cm.ld,
@@ -578,7 +608,7 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
     }
     if (!split_chain) HIP_TRY(hipEventRecord(S, cu.s));
     HIP_TRY(hipStreamWaitEvent(cp.s, S, 0));  // the next diagonal block may be factored
-    if (border && o > 0 && !border_early) {
+    if (border && !border_rl && o > 0 && !border_early) {
       HIP_TRY(hipStreamWaitEvent(cf, S, 0));  // behind the strip: the chain's own launches get the CUs first
       HIP_TRY(border_step());
     }
