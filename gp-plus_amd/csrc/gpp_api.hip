@@ -450,7 +450,12 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   // (measured: potrf 58.2 -> 56.4 ms at N = 20000, 28.4 -> 27.3 at 15000, 17.0 -> 16.4 at 10000)
   static const bool merge_upd_on = !(getenv("GPP_MERGE_UPD") && atoi(getenv("GPP_MERGE_UPD")) == 0);  // experiment knob
   static const bool split_chain = !(getenv("GPP_SPLIT_CHAIN") && atoi(getenv("GPP_SPLIT_CHAIN")) == 0);  // experiment knob
-  hipStream_t cf = h->fill_stream;
+  // Round 4: from N = 9216 the inverse's bordering products run on the stream WITHOUT a CU mask, i.e. also on the panel's 32 CUs
+  // while those idle (60 % of the time at N = 10 000, profiles/r04_timeline_n10000.txt).  Measured A/B on one box, potrf + inverse:
+  // 16.08 -> 15.68 ms at N = 10 000, 21.03 -> 20.54 at 11 264, even at 8192, a LOSS at 6144 (4.99 -> 5.23: the chain matters more
+  // there and a long bordering tile on a panel CU holds the next diagonal block up).  GPP_BORDER_FULL_MIN moves the threshold.
+  static const int64_t border_full_min = getenv("GPP_BORDER_FULL_MIN") ? atol(getenv("GPP_BORDER_FULL_MIN")) : 9216;
+  hipStream_t cf = (T != nullptr && N <= border_max_x && N >= border_full_min) ? h->full_stream : h->fill_stream;
   static const int64_t border_t128 = getenv("GPP_BORDER_T128") ? atol(getenv("GPP_BORDER_T128")) : 640;  // experiment knob
   hipEvent_t R_prev = nullptr;  // row solves of the steps before the current one are complete
   // The CU mask costs the throughput stream 12.5 % (see ensure_streams) although the panel needs its CUs only while it
