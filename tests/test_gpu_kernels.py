@@ -422,12 +422,12 @@ def test_batched_mll_function_matches_single(gpu_ctx):
         assert float(g.abs().max()) == 0.0
 
 
-@pytest.mark.parametrize("n", [4224, 6700, 12000, 13500, 16384])
+@pytest.mark.parametrize("n", [4224, 6700, 9984, 12000, 13500, 16384])
 def test_lookahead_driver_is_bitwise_repeatable(gpu_ctx, n):
     """Race screen for the look-ahead factorisation's internal streams (panel, throughput, fill, unmasked): every tile
     product accumulates in a fixed order, so repeating the same factorisation + inverse + Ky^-1 must reproduce the
-    first result bit for bit; a missing event between two streams shows up as a difference.  4224 and 6700 take the
-    bordered-inverse path, 12000 and above the pair-merging one whose first steps run as the statically scheduled persistent
+    first result bit for bit; a missing event between two streams shows up as a difference.  4224, 6700 and 9984 take the
+    bordered-inverse path (9984 with the bordering products on the stream without a CU mask), 12000 and above the pair-merging one whose first steps run as the statically scheduled persistent
     launch (gpp_exec_f64: counters between work-groups instead of events; 13500 is ragged, 16384 a multiple of the block height)."""
     U, w, K = _spd(n, seed=n)
     Kd = _dev(np.triu(K))
