@@ -376,10 +376,13 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
       if (!P) {
         PotrfExecTuning tune;
         tune.t_tile = getenv("GPP_EXEC_TTILE") ? atof(getenv("GPP_EXEC_TTILE")) : 275.0;
-        tune.t_block = getenv("GPP_EXEC_TBLOCK") ? atof(getenv("GPP_EXEC_TBLOCK")) : 800.0;
+        tune.t_block = getenv("GPP_EXEC_TBLOCK") ? atof(getenv("GPP_EXEC_TBLOCK")) : 600.0;
         tune.solve_pos = getenv("GPP_EXEC_PS") ? atoi(getenv("GPP_EXEC_PS")) : 4;
         tune.solve_pos_later = getenv("GPP_EXEC_PS2") ? atoi(getenv("GPP_EXEC_PS2")) : 0;
-        tune.la_frac = getenv("GPP_EXEC_LAF") ? atof(getenv("GPP_EXEC_LAF")) : 0.4;
+        // (sweep on one box, potrf at N = 20 000 / 15 000: 0.4 / 0.4 / 800 us 49.7 / 24.15 ms; 0.15 / 0.5 / 600 us 49.33 / 23.68 —
+        //  the tiles inside the next diagonal block early, the others past the middle of the phase; profiles/r04_exec_schedule.txt)
+        tune.la_frac = getenv("GPP_EXEC_LAF") ? atof(getenv("GPP_EXEC_LAF")) : 0.15;
+        tune.la_frac2 = getenv("GPP_EXEC_LAF2") ? atof(getenv("GPP_EXEC_LAF2")) : std::max(0.5, tune.la_frac);
         tune.fill = getenv("GPP_EXEC_FILL") ? atoi(getenv("GPP_EXEC_FILL")) : 1;
         P = h->exec_plan = gpp_plan_potrf_exec(N, NB, K, W, F, tune);
       }

@@ -177,6 +177,7 @@ struct PotrfExecTuning {
   int solve_pos;    // bulk tiles of phase 0 a worker runs before its share of block row 1's solve (the first panel is not hidden)
   int solve_pos_later;  // the same for the later phases (their diagonal block was factored during the previous phase)
   double la_frac;   // fraction of a phase's bulk tiles a worker runs before its look-ahead tasks (step k+1 on block row k+2)
+  double la_frac2;  // the same for the look-ahead tasks outside the next diagonal block (>= la_frac)
   int fill;         // 0: no filler launches
 };
 struct PotrfExecPlan {

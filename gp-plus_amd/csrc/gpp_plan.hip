@@ -231,13 +231,22 @@ PotrfExecPlan* gpp_plan_potrf_exec(int64_t N, int64_t nb, int K, int W, int F, c
       size_t ps = std::min<size_t>(len, (size_t)(k == 0 ? tune.solve_pos : tune.solve_pos_later));
       size_t pl = std::max<size_t>(std::max(n_a0, ps), (size_t)(len * tune.la_frac));
       pl = std::min(pl, len);
+      // (la_frac2 > la_frac: the look-ahead tasks OUTSIDE the next diagonal block — they wait for ALL of block row k+1's solves,
+      //  the diagonal block's only for the head's — run later in the phase than those inside it, which release the panel)
+      size_t pl2 = std::max<size_t>(pl, (size_t)(len * tune.la_frac2));
+      pl2 = std::min(pl2, len);
       size_t q = 0;
       for (; q < ps; ++q) put(b, bulk[q]);
       if (k + 1 < K)
         for (auto& p : pS[k + 1][w]) put(b, p);
       for (; q < pl; ++q) put(b, bulk[q]);
       if (k + 1 < K)
-        for (auto& p : pLA[k + 1][w]) put(b, p);
+        for (auto& p : pLA[k + 1][w])
+          if (p.i0 == cid(k + 2, C_G1D)) put(b, p);
+      for (; q < pl2; ++q) put(b, bulk[q]);
+      if (k + 1 < K)
+        for (auto& p : pLA[k + 1][w])
+          if (p.i0 != cid(k + 2, C_G1D)) put(b, p);
       for (; q < len; ++q) put(b, bulk[q]);
       for (auto& p : pCP[k][w]) put(b, p);
     }
@@ -307,7 +316,7 @@ hipError_t gpp_plan_upload(PotrfExecPlan* P) {
 // `mutate` > 0 removes the mutate-th wait of the plan first: the check must then FAIL (the test of the test).
 extern "C" int gpp_debug_plan_check(int64_t N, int64_t nb, int K, int W, int F, int fill, int solve_pos, unsigned seed, int64_t* stats,
                                     int mutate) {
-  PotrfExecTuning tune{275.0, 800.0, solve_pos, 0, 0.4, fill};
+  PotrfExecTuning tune{275.0, 600.0, solve_pos, 0, 0.15, 0.5, fill};
   PotrfExecPlan* P = gpp_plan_potrf_exec(N, nb, K, W, F, tune);
   if (!P) return 1;
   int mutated = -1;  // what was removed: 100 * task kind + 10 * (filler list) + counter kind
