@@ -14,6 +14,7 @@ Jitter policy restates gpytorch.utils.cholesky.psd_safe_cholesky [3P]: 1e-8 * 10
 from __future__ import annotations
 
 import threading
+import os
 import warnings
 from contextlib import contextmanager
 from dataclasses import dataclass
@@ -122,6 +123,10 @@ def _as_f64(t: torch.Tensor, device) -> torch.Tensor:
     return t.to(device=device, dtype=torch.float64).contiguous()
 
 
+_NO_PRESYNC = os.environ.get("GPP_NO_PRESYNC", "0") not in ("", "0")  # experiment knob (see _factor): measured +1 ms at C2 and C4
+_SPIN_SYNC = os.environ.get("GPP_SPIN_SYNC", "0") not in ("", "0")
+
+
 def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_split, after=None) -> float:
     """Build Ky (upper) and factor it, with gpytorch's jitter-retry policy.  Returns the jitter that was needed.
     ``after()`` enqueues whatever follows the factorisation BEFORE ``info`` is read back, so the GPU keeps working while
@@ -150,8 +155,14 @@ def _factor(ctx: GppContext, ws: EvalWorkspace, U, w, sf2, tau, grp, kind, d_spl
         # Python between two evaluations has overlapped the previous one's inverse stages by now and nothing is exposed.
         # bench.py at N = 20000 on one box: 151-153 ms per evaluation without this wait, 143-144 with it; C3 (N = 10000)
         # 25.4-26.0 -> 24.3-24.8 ms.
-        if ws.N >= LOOKAHEAD_MIN_N:  # (below, the factorisation is a single-stream chain and the host is the bottleneck)
-            torch.cuda.current_stream(ctx.index).synchronize()
+        if ws.N >= LOOKAHEAD_MIN_N and not _NO_PRESYNC:  # (below, the factorisation is a single-stream chain and the host is the bottleneck)
+            if _SPIN_SYNC:  # experiment knob: poll an event instead of the runtime's blocking wait (wake-up latency)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(ctx.index))
+                while not ev.query():
+                    pass
+            else:
+                torch.cuda.current_stream(ctx.index).synchronize()
         # (Measured and NOT adopted: building the first diagonal block's columns first and handing them to the panel stream
         #  while the rest of Ky is written — the build is an unmasked launch that floods every CU, the panel's 32 included,
         #  so the first leaf waits for it anyway: 53.6 ms against 0.64 + 52.4.)
