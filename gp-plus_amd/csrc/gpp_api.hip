@@ -754,6 +754,33 @@ int gpp_debug_exec_fetch(gpp_handle_t h, void* tasks, void* offsets, void* trace
   return 0;
 }
 
+// Debug / profiling: ONE trailing update  A[nb:, nb:] (upper) -= T[0:nb, nb:]^T T[0:nb, nb:]  run by the executor's kernel alone
+// (a wait-free task list on the throughput stream's 2 work-groups per CU; reps launches back to back, the caller's stream waits).
+// No gate, no panel, no counter: the launch can be profiled under a counter collection that serialises dispatches
+// (tools/exec_update_probe.py).  Not part of gpp.h.
+int gpp_debug_exec_update(gpp_handle_t h, double* A, int64_t ld, double* T, int64_t ldt, int64_t N, int64_t nb, int reps) {
+  if (!h || !A || !T) return -1;
+  if (ensure_streams(h) != hipSuccess) return 1;
+  if (h->cu_split != 1) return 2;
+  const int W = 2 * (h->ncu - h->panel_cus);
+  PotrfExecPlan* P = gpp_plan_single_update(N, nb, W);
+  if (!P) return 3;
+  gpp_plan_bind(P, A, ld, A, ld, T, ldt);  // (the solve group is never used: any valid pointer)
+  int rc_ = 0;
+  if (gpp_plan_upload(P) != hipSuccess) rc_ = 4;
+  hipEvent_t ev = next_event(h);
+  if (!rc_ && (hipEventRecord(ev, h->stream) != hipSuccess || hipStreamWaitEvent(h->upd_stream, ev, 0) != hipSuccess)) rc_ = 5;
+  if (!rc_ && gpp_launch_fill_i32(h->upd_stream, P->d_counters, P->ncounters, 0) != hipSuccess) rc_ = 6;
+  ExecLaunch el{P->d_groups, P->d_tasks, P->d_offsets, P->d_counters, P->d_counters + 1, 200000000LL, 0, nullptr};
+  for (int r = 0; r < reps && !rc_; ++r)
+    if (gpp_launch_exec(h->upd_stream, W, el) != hipSuccess) rc_ = 7;
+  hipEvent_t done = next_event(h);
+  if (!rc_ && (hipEventRecord(done, h->upd_stream) != hipSuccess || hipStreamWaitEvent(h->stream, done, 0) != hipSuccess)) rc_ = 8;
+  (void)hipStreamSynchronize(h->upd_stream);
+  gpp_plan_free(P);
+  return rc_;
+}
+
 int gpp_create(gpp_handle_t* out, int device) {
   if (!out) return -1;
   int ndev = 0;

@@ -201,6 +201,7 @@ struct PotrfExecPlan {
   unsigned long long* d_trace = nullptr;  // 3 * tasks.size() stamps when tracing is switched on (gpp_debug_exec_trace)
 };
 PotrfExecPlan* gpp_plan_potrf_exec(int64_t N, int64_t nb, int K, int W, int F, const PotrfExecTuning& tune);
+PotrfExecPlan* gpp_plan_single_update(int64_t N, int64_t nb, int W);
 void gpp_plan_bind(PotrfExecPlan* P, double* A, int64_t ld, double* Li, int64_t ldi, double* T, int64_t ldt);
 hipError_t gpp_plan_upload(PotrfExecPlan* P);
 void gpp_plan_free(PotrfExecPlan* P);

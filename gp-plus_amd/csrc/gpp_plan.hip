@@ -292,6 +292,34 @@ PotrfExecPlan* gpp_plan_potrf_exec(int64_t N, int64_t nb, int K, int W, int F, c
   return P;
 }
 
+// ONE trailing update as a wait-free task list (debug / profiling: the executor's kernel can then run alone, e.g. under a counter
+// collection that serialises dispatches): step 0's update tiles dealt cyclically to W workers, nothing else.
+PotrfExecPlan* gpp_plan_single_update(int64_t N, int64_t nb, int W) {
+  if (nb % GPP_TILE != 0 || W < 1 || nb >= N) return nullptr;
+  const int bt = (int)(nb / GPP_TILE), nt = (int)((N + GPP_TILE - 1) / GPP_TILE);
+  PotrfExecPlan* P = new PotrfExecPlan();
+  P->N = N; P->nb = nb; P->K = 1; P->W = W; P->F = 0;
+  P->ncounters = 1 + 8 * 3;
+  P->gate_target.assign(3, 0);
+  P->fill_workers.assign(1, 0);
+  std::vector<Builder> main(W);
+  int64_t t = 0;
+  for (int i = bt; i < nt; ++i)
+    for (int j = i; j < nt; ++j, ++t) main[(size_t)(t % W)].add(1, i - bt, j - bt, -1, 0, -1, 0, -1, -1);
+  P->offsets.assign((size_t)W + 1, 0);
+  ExecTask endt{};
+  endt.group = GPP_EXEC_END;
+  endt.wait_id[0] = endt.wait_id[1] = endt.inc_id[0] = endt.inc_id[1] = -1;
+  for (int w = 0; w < W; ++w) {
+    P->offsets[w] = (int32_t)P->tasks.size();
+    P->tasks.insert(P->tasks.end(), main[w].list.begin(), main[w].list.end());
+    P->tasks.push_back(endt);
+  }
+  P->offsets[W] = (int32_t)P->tasks.size();
+  P->tasks.push_back(endt);
+  return P;
+}
+
 // Device copies of the plan (synchronous; once per plan, and again when the operands' addresses change).
 hipError_t gpp_plan_upload(PotrfExecPlan* P) {
   hipError_t e;
