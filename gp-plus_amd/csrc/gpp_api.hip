@@ -687,6 +687,124 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   return hipSuccess;
 }
 
+// ---- DAG executor (round 5, gpp_dag.hip / gpp_dag_f64) ---------------------------------------------------------------------------
+// The factorisation — and for N <= GPP_DAG_INV_MAX the whole inverse beside it, right-looking — as ONE ticket list of tile tasks on
+// the throughput CUs, the diagonal blocks as cooperative panel launches on the panel CUs behind one-wave gate kernels.  Replaces
+// the launch-per-product look-ahead with bordering in 3840 <= N <= 11264, where the factorisation is bound by its chain of
+// diagonal blocks: there every launch boundary (head solve -> diagonal update -> rest solve -> trailing update, in stream order)
+// and every bordering product's few long tiles cost idle CUs (profiles/r04_timeline_n10000.txt: 16.3 ms for 10 ms of tile work).
+// Plans depend on (N, nb, leading dimensions, flags) only — the operands' addresses are kernel arguments — and live in a small LRU
+// per handle; nothing here synchronises the device.  *used = false: not applicable, the caller continues with the older paths.
+hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64_t ldt, bool* used) {
+  *used = false;
+  static const bool dag_env = !(getenv("GPP_DAG_SCHED") && atoi(getenv("GPP_DAG_SCHED")) == 0);
+  // Measured on one box, potrf + inverse (tools/sweep_dag.sh, profiles/r05_dag_sweep.txt): launches win below ~6700 rows, where the
+  // chain of diagonal blocks is all there is (4.99 vs 5.39 ms at 6144), the ticket list from there (6.35 vs 6.82 at 7168, 8.05 vs
+  // 9.16 at 8192, 13.45 vs 15.68 at 10 000, 18.14 vs 20.46 at 11 264).  With the inverse inside the list up to ~16 000 rows (22.64 vs
+  // 24.73 at 12 288, 40.19 vs 41.97 at 15 000); above, the inverse's K = 1024 tiles on 503 slots lose to gpp_trtri's long-K launches on
+  // 256 CUs and only the factorisation runs here (88.23 vs 89.51 at 20 000 with the round-4 executor, 284.8 vs 287.1 at 30 000).
+  static const int64_t dag_min = getenv("GPP_DAG_MIN_N") ? atol(getenv("GPP_DAG_MIN_N")) : 6656;
+  static const int64_t dag_max = getenv("GPP_DAG_MAX_N") ? atol(getenv("GPP_DAG_MAX_N")) : 40000;
+  static const int64_t dag_inv_max = getenv("GPP_DAG_INV_MAX") ? atol(getenv("GPP_DAG_INV_MAX")) : 16384;
+  static const int64_t dag_nb_env = getenv("GPP_DAG_NB") ? atol(getenv("GPP_DAG_NB")) : 0;
+  static const int64_t dag_nb_small = getenv("GPP_DAG_NB_SMALL_N") ? atol(getenv("GPP_DAG_NB_SMALL_N")) : 0;
+  if (!dag_env || !h->dag_sched || !h->coop_panel || !T || N < dag_min || N > dag_max) return hipSuccess;
+  HIP_TRY(ensure_streams(h));
+  if (h->cu_split != 1) return hipSuccess;
+  const int64_t nb = dag_nb_env ? dag_nb_env : (N <= dag_nb_small ? 512 : 1024);
+  if (nb % NBLK != 0 || !panel_fits(h, nb) || !panel_fits(h, nb + 256)) return hipSuccess;
+  const int flags = N <= dag_inv_max ? DAG_INV : 0;
+  // the plan: a hit in the handle's LRU, or planned now (host only) and uploaded (a few MB, once per shape)
+  DagPlan* P = nullptr;
+  int slot = -1, lru = 0;
+  for (int i = 0; i < 4; ++i) {
+    DagPlan* q = h->dag_plans[i];
+    if (q && q->N == N && q->nb == nb && q->ld == cm.ld && q->ldi == cm.ldi && q->ldt == ldt && q->flags == flags) slot = i;
+    if (!q) lru = i;
+    else if (h->dag_plans[lru] && q->stamp < h->dag_plans[lru]->stamp) lru = i;
+  }
+  if (slot >= 0) P = h->dag_plans[slot];
+  else {
+    DagTuning tune = gpp_dag_default_tuning();
+    tune.workers = 2 * (h->ncu - h->panel_cus);
+    if (tune.fill > 0) tune.fill = 2 * h->panel_cus;
+    P = gpp_dag_plan(N, nb, cm.ld, cm.ldi, ldt, 0, flags, tune);
+    if (!P) return hipSuccess;
+    for (int b = 0; b < P->B; ++b) {
+      const int64_t rows = std::min<int64_t>((int64_t)P->tb[b + 1] * NBLK, N) - (int64_t)P->tb[b] * NBLK;
+      if (!panel_fits(h, rows)) {
+        gpp_dag_free(P);
+        return hipSuccess;
+      }
+    }
+    if (gpp_dag_upload(P) != hipSuccess) {  // no memory for the device copy: not an error of the factorisation
+      (void)hipGetLastError();
+      gpp_dag_free(P);
+      h->dag_sched = 0;
+      return hipSuccess;
+    }
+    if (h->dag_plans[lru]) gpp_dag_free(h->dag_plans[lru]);  // (waits for that plan's own last launch only)
+    h->dag_plans[lru] = P;
+  }
+  P->stamp = ++h->dag_clock;
+  Ctx cp = cm, cu = cm;
+  cp.s = h->panel_stream;
+  cu.s = h->upd_stream;
+  HIP_TRY(gpp_launch_fill_i32(cm.s, P->d_counters, P->ncounters, 0));
+  DagBases bases{{reinterpret_cast<char*>(cm.A), reinterpret_cast<char*>(cm.Li), reinterpret_cast<char*>(T), nullptr}};
+  HIP_TRY(gpp_launch_dag_bind(cm.s, P->d_groups, P->d_groups_abs, (int)P->groups.size(), bases));
+  hipEvent_t ev = next_event(h);
+  HIP_TRY(hipEventRecord(ev, cm.s));  // inputs (kernel build), cleared counters and bound groups are ready
+  HIP_TRY(hipStreamWaitEvent(cp.s, ev, 0));
+  HIP_TRY(hipStreamWaitEvent(cu.s, ev, 0));
+  const long long budget = (long long)(h->panel_timeout_ms > 0 ? h->panel_timeout_ms : 500) * 100000 * 4;
+  DagLaunch dl{};
+  dl.groups = P->d_groups_abs; dl.tasks = P->d_tasks; dl.ntasks = (int)P->tasks.size();
+  dl.counters = P->d_counters; dl.info = cm.info; dl.budget = budget;
+  dl.max_tasks = 0; dl.quit_id = -1; dl.quit_val = 0; dl.ticket_limit = 0;
+  dl.trace = P->d_trace; dl.tag = 0;
+  static const int dag_workers = getenv("GPP_DAG_WORKERS") ? atoi(getenv("GPP_DAG_WORKERS")) : 0;
+  HIP_TRY(gpp_launch_dag(cu.s, dag_workers > 0 ? dag_workers : 2 * (h->ncu - h->panel_cus), dl));
+  for (const DagPlan::Op& op : P->stream_ops) {
+    const int64_t o = op.kind < 3 ? (int64_t)P->tb[op.arg] * NBLK : 0;
+    if (op.kind == 0) {
+      HIP_TRY(gpp_launch_exec_gate(cp.s, P->d_counters, P->c_g1d + op.arg, P->gate_target[op.arg], cm.info, budget));
+    } else if (op.kind == 1) {
+      const int64_t rows = std::min<int64_t>((int64_t)P->tb[op.arg + 1] * NBLK, N) - o;
+      HIP_TRY(launch_panel(h, cp, o, rows, h->panel_cus));
+      if (!(flags & DAG_INV) && h->inv_nblocks < 128) {
+        h->inv_o[h->inv_nblocks] = o;
+        h->inv_n[h->inv_nblocks] = rows;
+        ++h->inv_nblocks;
+      }
+    } else if (op.kind == 2) {
+      HIP_TRY(gpp_launch_exec_signal(cp.s, P->d_counters, P->c_pd + op.arg));
+    } else {
+      // filler: two work-groups per panel CU take tasks from the same list until the next diagonal block's update has begun
+      DagLaunch fl = dl;
+      fl.max_tasks = op.arg;  // (0 behind the last panel: until the list is exhausted)
+      fl.quit_id = op.n >= 0 ? P->c_g1d + op.n : -1;
+      fl.quit_val = 1;
+      fl.ticket_limit = op.lim;
+      fl.tag = op.n >= 0 ? op.n : P->B;
+      HIP_TRY(gpp_launch_dag(cp.s, 2 * h->panel_cus, fl));
+    }
+  }
+  hipEvent_t E = next_event(h), F = next_event(h);
+  HIP_TRY(hipEventRecord(E, cu.s));
+  HIP_TRY(hipEventRecord(F, cp.s));
+  HIP_TRY(hipStreamWaitEvent(cm.s, E, 0));
+  HIP_TRY(hipStreamWaitEvent(cm.s, F, 0));
+  HIP_TRY(hipEventRecord(P->last_use, cm.s));
+  if (flags & DAG_INV) {
+    h->inv_nblocks = 1;  // the inverse is complete: gpp_trtri has nothing left to merge
+    h->inv_o[0] = 0;
+    h->inv_n[0] = N;
+  }
+  *used = true;
+  return hipSuccess;
+}
+
 // columns of a buffer that holds only the block-cyclically owned column blocks of an N x N matrix, side by side
 inline int64_t owned_cols(int64_t N, int64_t nb, int rank, int nranks) {
   const int64_t nblk = (N + nb - 1) / nb;
@@ -754,6 +872,46 @@ int gpp_debug_exec_fetch(gpp_handle_t h, void* tasks, void* offsets, void* trace
   return 0;
 }
 
+// Debug access to the DAG executor's most recently used plan (tools/dag_trace.py): not part of gpp.h.
+static DagPlan* dag_mru(gpp_handle_t h) {
+  DagPlan* P = nullptr;
+  if (h)
+    for (int i = 0; i < 4; ++i)
+      if (h->dag_plans[i] && (!P || h->dag_plans[i]->stamp > P->stamp)) P = h->dag_plans[i];
+  return P;
+}
+int gpp_debug_dag_info(gpp_handle_t h, int64_t* info8) {
+  const DagPlan* P = dag_mru(h);
+  if (!P) return -1;
+  info8[0] = (int64_t)P->tasks.size(); info8[1] = (int64_t)P->groups.size(); info8[2] = P->B; info8[3] = P->nt;
+  info8[4] = P->ncounters; info8[5] = (int64_t)(P->sim_ms * 1000.0); info8[6] = (int64_t)(P->sim_busy * 1000.0); info8[7] = P->flags;
+  return 0;
+}
+int gpp_debug_dag_trace(gpp_handle_t h, int on) {
+  DagPlan* P = dag_mru(h);
+  if (!P) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (on && !P->d_trace) {
+    if (hipMalloc(&P->d_trace, 4 * P->tasks.size() * sizeof(unsigned long long)) != hipSuccess) return 2;
+    (void)hipMemset(P->d_trace, 0, 4 * P->tasks.size() * sizeof(unsigned long long));
+  } else if (!on && P->d_trace) {
+    (void)hipFree(P->d_trace);
+    P->d_trace = nullptr;
+  }
+  return 0;
+}
+int gpp_debug_dag_fetch(gpp_handle_t h, void* tasks, void* trace) {
+  const DagPlan* P = dag_mru(h);
+  if (!P) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  if (tasks) memcpy(tasks, P->tasks.data(), P->tasks.size() * sizeof(DagTask));
+  if (trace) {
+    if (!P->d_trace) return 2;
+    if (hipMemcpy(trace, P->d_trace, 4 * P->tasks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 3;
+  }
+  return 0;
+}
+
 // Debug / profiling: ONE trailing update  A[nb:, nb:] (upper) -= T[0:nb, nb:]^T T[0:nb, nb:]  run by the executor's kernel alone
 // (a wait-free task list on the throughput stream's 2 work-groups per CU; reps launches back to back, the caller's stream waits).
 // No gate, no panel, no counter: the launch can be profiled under a counter collection that serialises dispatches
@@ -812,6 +970,9 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->panel_timeout_ms = 500;
   h->exec_plan = nullptr;
   h->exec_sched = 1;
+  for (int i = 0; i < 4; ++i) h->dag_plans[i] = nullptr;
+  h->dag_clock = 0;
+  h->dag_sched = 1;
   h->ncu = 0;
   if (hipDeviceGetAttribute(&h->ncu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || h->ncu < 2) {
     (void)hipGetLastError();
@@ -837,6 +998,8 @@ int gpp_destroy(gpp_handle_t h) {
   for (int i = 0; i < h->n_events; ++i) (void)hipEventDestroy(h->events[i]);
   if (h->panel_flags) (void)hipFree(h->panel_flags);
   if (h->exec_plan) gpp_plan_free(h->exec_plan);
+  for (int i = 0; i < 4; ++i)
+    if (h->dag_plans[i]) gpp_dag_free(h->dag_plans[i]);
   delete h;
   return 0;
 }
@@ -852,6 +1015,7 @@ int gpp_set_option(gpp_handle_t h, int option, int value) {
   if (option == GPP_OPT_COOP_PANEL) h->coop_panel = value ? 1 : 0;
   else if (option == GPP_OPT_PANEL_FAULT) h->panel_fault = value ? 1 : 0;
   else if (option == GPP_OPT_EXEC_SCHED) h->exec_sched = value ? 1 : 0;
+  else if (option == GPP_OPT_DAG_SCHED) h->dag_sched = value ? 1 : 0;
   else if (option == GPP_OPT_PANEL_TIMEOUT_MS) {
     if (value < 1 || value > 60000) return -3;
     h->panel_timeout_ms = value;
@@ -943,6 +1107,9 @@ int gpp_potrf_ws(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv,
   // (measured: the leaf-step factorisation on one stream wins up to ~6000 rows — 2.99 vs 3.46 ms at 4096, 4.25 vs 4.53 at
   //  5120, a tie at 6144; the look-ahead wins from there: 8.6 vs 10.1 ms at 8192)
   static const int64_t la_min_b = getenv("GPP_BORDER_MIN") ? atol(getenv("GPP_BORDER_MIN")) : BORDER_MIN_N;  // knob
+  bool dag_used = false;
+  GPP_TRY(potrf_dag(h, c, N, T, ldt, &dag_used));
+  if (dag_used) return 0;
   if (N >= (T ? std::min(la_min, la_min_b) : la_min)) {
     GPP_TRY(potrf_lookahead(h, c, N, LOOKAHEAD_NB, T, ldt));
   } else if (panel_fits(h, N)) {

@@ -1,0 +1,946 @@
+// gpp_dag.hip — host-side planner of the DAG executor (gpp_dag_f64, gpp_gemm.hip): the blocked Cholesky factorisation and,
+// beside it, the triangular inverse built right-looking, as ONE list of tile tasks in a topological order of the whole task graph.
+// No reference counterpart: the reference's factorisation and its backward are torch.linalg.cholesky_ex / ATen cholesky_backward
+// behind gpytorch (call sites optim/mll_torch.py:116-117).
+//
+// Storage (gpp.h): A keeps the upper factor U (A = U^T U), Linv keeps X = L^-1 lower and its mirror upper, T is an N x N scratch.
+// Blocks of nb rows (a multiple of 128; block b = tiles [tb[b], tb[b+1]) of 128).  Per block k, with "k rows" = the rows of block k:
+//   P(k)          panel: factor AND invert the diagonal block (a cooperative launch on the panel stream, gpp_leaf.hip)
+//   S(k; r, c)    row solve      T[k rows, c] = W_kk^T A[k rows, c]              c right of block k   (K <= nb, triangular)
+//   U(k; i, j)    update         A[i, j] -= T[k rows, i]^T T[k rows, j]           i <= j right of block k   (K = nb)
+//   CP(k; c)      copy           A[k rows, c] = T[k rows, c]                      (the factor's block row into place)
+//   XB(k; i, j)   inverse, sums  T[i, j] (+)= T[k rows, i]^T X[k rows, j]         i below block k, j up to block k   (K = nb)
+//   XA(m; r, j)   inverse, rows  X[m rows, j] = -X_mm T[m rows, j] (+ mirror)     j left of block m   (K <= nb, triangular)
+// (XB / XA: with S_m = sum_{k<m} L[m,k] X[k,:] accumulated in the lower-left part of T, X[m,:m) = -X_mm S_m — the sharded forward
+// sweep's recurrence; the solved block rows live in the upper-right part of T, so the two uses of the scratch never meet.)
+// Every dependency is a monotone counter: strip counters (all tasks of a strip done) and per-tile version counters (the k-th
+// contribution to a tile follows the (k-1)-th).  The ORDER of the list is that of a list-scheduling simulation (priority = longest
+// path to the end of the graph, cost model in DagTuning): with it a work-group that takes the next ticket finds its task ready or
+// nearly so, chain tasks (head solve, next diagonal block's update) are taken the moment they can run, and the inverse's tasks fill
+// whatever the factorisation's chain leaves idle.  Any topological order is CORRECT; the simulation only decides how good it is.
+#include "gpp_internal.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <queue>
+#include <vector>
+
+namespace {
+
+constexpr int ALL = -7;  // wait value: "every task that increments this counter"
+
+struct Node {
+  int group = -1, tm = 0, tn = 0, kind = 0;  // kind < 0: panel of block `tm`
+  int lvl = 0;                               // the last block whose panel the task (transitively) needs
+  int w[3] = {-1, -1, -1}, v[3] = {0, 0, 0};
+  int inc[2] = {-1, -1};
+  float cost = 0;
+  double bl = 0;  // bottom level
+};
+
+struct Planner {
+  int64_t N, nb, ld, ldi, ldt, ldk;
+  int flags;
+  DagTuning tune;
+  int nt = 0, B = 0;
+  std::vector<int> tb;
+  std::vector<GemmArgs> groups;
+  std::vector<std::pair<int, int>> gmeta;  // per group: (kind, block)
+  std::vector<Node> nodes;
+  int ncounters = 2;                      // 0 abort, 1 ticket
+  std::vector<char> chain;                // per counter: version counter (the v-th increment follows the (v-1)-th)
+  std::vector<std::vector<int>> incs;     // per counter: incrementing nodes in generation order
+  int c_pd = 0, c_g1d = 0, c_ur = 0, c_ss = 0, c_xr = 0, c_xs = 0, c_va = 0, c_vt = 0;
+  int cur_lvl = 0;
+
+  int blk_of(int tile) const { return (int)(std::upper_bound(tb.begin(), tb.end(), tile) - tb.begin()) - 1; }
+  int64_t rows_of(int b) const { return std::min<int64_t>((int64_t)tb[b + 1] * 128, N) - (int64_t)tb[b] * 128; }
+  int PD(int b) const { return c_pd + b; }
+  int G1D(int b) const { return c_g1d + b; }
+  int UR(int b, int c) const { return c_ur + b * nt + c; }
+  int SS(int b, int c) const { return c_ss + b * nt + c; }
+  int XR(int b, int c) const { return c_xr + b * nt + c; }
+  int XS(int b, int c) const { return c_xs + b * nt + c; }
+  int VA(int i, int j) const { return c_va + (int)((int64_t)i * nt - (int64_t)i * (i - 1) / 2 + (j - i)); }  // i <= j
+  int VT(int i, int j) const { return c_vt + (int)((int64_t)i * (i - 1) / 2 + j); }                          // i > j
+
+  static const double* off(int64_t elems) { return reinterpret_cast<const double*>(static_cast<uintptr_t>(elems * 8)); }
+  static double* offw(int64_t elems) { return reinterpret_cast<double*>(static_cast<uintptr_t>(elems * 8)); }
+
+  int add_group(const GemmArgs& g, int kind, int b) {
+    cur_lvl = b;
+    groups.push_back(g);
+    gmeta.emplace_back(kind, b);
+    return (int)groups.size() - 1;
+  }
+  double tile_cost(int etile, int64_t K) const {
+    const double ch = (double)((K + 15) / 16);
+    if (etile == 64) return tune.t0_64 + tune.tc_64 * ch;
+    if (etile == 32) return tune.t0_32 + tune.tc_32 * ch;
+    return tune.t0_big + tune.tc_big * ch;
+  }
+  int add_node(int group, int tm, int tn, int kind, double cost) {
+    Node n;
+    n.group = group; n.tm = tm; n.tn = tn; n.kind = kind; n.cost = (float)cost;
+    n.lvl = cur_lvl;  // (every task of a group of block b needs the panel of block b and none after it)
+    nodes.push_back(n);
+    return (int)nodes.size() - 1;
+  }
+  void wait(int node, int c, int v) {
+    if (c < 0 || v == 0) return;
+    Node& n = nodes[node];
+    for (int q = 0; q < 3; ++q)
+      if (n.w[q] < 0) {
+        n.w[q] = c;
+        n.v[q] = v;
+        return;
+      }
+    fprintf(stderr, "libgpp_hip: dag planner: more than three waits on a task\n");
+    abort();
+  }
+  void inc(int node, int c) {
+    if (c < 0) return;
+    Node& n = nodes[node];
+    for (int q = 0; q < 2; ++q)
+      if (n.inc[q] < 0) {
+        n.inc[q] = c;
+        incs[c].push_back(node);
+        return;
+      }
+    fprintf(stderr, "libgpp_hip: dag planner: more than two increments on a task\n");
+    abort();
+  }
+
+  bool layout() {
+    if (nb % GPP_TILE != 0 || nb < GPP_TILE || N < 2 * GPP_TILE) return false;
+    nt = (int)((N + GPP_TILE - 1) / GPP_TILE);
+    if (nt >= 32000) return false;
+    const int bt = (int)(nb / GPP_TILE);
+    tb.clear();
+    // (measured and dropped: a shorter first block — nothing runs beside the first panel — 13.60 vs 13.45 ms at N = 10 000 with 512 rows)
+    for (int t = 0; t < nt; t += bt) tb.push_back(t);
+    // a last block too short for the cooperative panel (<= 256 rows) joins its neighbour
+    if (tb.size() >= 2 && N - (int64_t)tb.back() * 128 <= 256) tb.pop_back();
+    tb.push_back(nt);
+    B = (int)tb.size() - 1;
+    if (B < 2) return false;
+    c_pd = ncounters; ncounters += B;
+    c_g1d = ncounters; ncounters += B;
+    c_ur = ncounters; ncounters += B * nt;
+    c_ss = ncounters; ncounters += B * nt;
+    if (flags & DAG_INV) {
+      c_xr = ncounters; ncounters += B * nt;
+      c_xs = ncounters; ncounters += B * nt;
+    }
+    c_va = ncounters; ncounters += (int)((int64_t)nt * (nt + 1) / 2);
+    if (flags & DAG_INV) {
+      c_vt = ncounters; ncounters += (int)((int64_t)nt * (nt - 1) / 2);
+    }
+    chain.assign(ncounters, 0);
+    for (int c = c_va; c < ncounters; ++c) chain[c] = 1;  // VA, VT
+    incs.assign(ncounters, {});
+    return true;
+  }
+
+  void generate() {
+    const int ct = tune.chain_tile == 64 ? 64 : 128;  // (a 32 x 32 body beside the two others made the kernel spill 26 VGPRs)
+    for (int k = 0; k < B; ++k) {
+      const int lo = tb[k + 1], btk = tb[k + 1] - tb[k];
+      const int64_t o = (int64_t)tb[k] * 128, nbk = rows_of(k), c0 = (int64_t)lo * 128, rem = N - c0;
+      // the panel of block k
+      {
+        const int p = add_node(-1, k, 0, -1, tune.t_gate + tune.t_panel0 + tune.t_panel_leaf * (double)((nbk + 127) / 128));
+        if (k > 0) wait(p, G1D(k), ALL);
+        inc(p, PD(k));
+      }
+      if ((flags & DAG_INV) && k > 0) {
+        // XA(k; r, j): X[k rows, j] = -W_kk^T T[k rows, j] (+ mirror), j left of block k
+        GemmArgs g{};
+        g.A = off(o * ldi + o); g.lda = ldi; g.buf[0] = 1;
+        g.B = off(o * ldt); g.ldb = ldt; g.buf[1] = 2;
+        g.C = offw(o * ldi); g.ldc = ldi; g.buf[2] = 1;
+        g.C2 = offw(o); g.ldc2 = ldi; g.buf[3] = 1;
+        g.M = (int)nbk; g.N = (int)o; g.K = (int)nbk;
+        g.alpha = -1.0; g.beta = 0.0;
+        g.a_mask = 1; g.khi_mode = 1;
+        g.pad_ok = (k < B - 1) ? 1 : 0;  // (the last block's rows end the buffer)
+        const int gi = add_group(g, DK_XA, k);
+        for (int r = btk - 1; r >= 0; --r)
+          for (int j = 0; j < tb[k]; ++j) {
+            const int n = add_node(gi, r, j, DK_XA, tile_cost(128, std::min<int64_t>(nbk, (int64_t)(r + 1) * 128)));
+            wait(n, PD(k), 1);
+            wait(n, XR(k, j), ALL);
+            inc(n, XS(k, j));
+          }
+      }
+      if (rem <= 0) continue;
+      const int nbk1 = (int)rows_of(k + 1), hi = tb[k + 2];  // next block: rows, end tile
+      // ---- S(k): row solve ----------------------------------------------------------------------------------------------------
+      GemmArgs s{};
+      s.A = off(o * ldi + o); s.lda = ldi; s.buf[0] = 1;
+      s.B = off(o * ld + c0); s.ldb = ld; s.buf[1] = 0;
+      s.C = offw(o * ldt + c0); s.ldc = ldt; s.buf[2] = 2;
+      s.buf[3] = -1;
+      s.M = (int)nbk; s.N = (int)rem; s.K = (int)nbk;
+      s.alpha = 1.0; s.beta = 0.0;
+      s.a_mask = 1; s.khi_mode = 1;
+      s.pad_ok = 1;  // (rows of block k with further rows below them: reading past column N stays inside the buffers)
+      const int gS = add_group(s, DK_S, k);
+      int gSh = -1;
+      if (ct != 128) {
+        GemmArgs sh = s;
+        sh.N = nbk1;
+        sh.etile = ct;
+        gSh = add_group(sh, DK_SH, k);
+      }
+      for (int pass = 0; pass < 2; ++pass) {  // head columns (those of diagonal block k+1) first
+        if (pass == 0 && gSh >= 0) {
+          const int rt = (int)((nbk + ct - 1) / ct), ctiles = (nbk1 + ct - 1) / ct;
+          for (int r = rt - 1; r >= 0; --r)
+            for (int c = 0; c < ctiles; ++c) {
+              const int c128 = lo + c * ct / 128;
+              const int n = add_node(gSh, r, c, DK_SH, tile_cost(ct, std::min<int64_t>(nbk, (int64_t)(r + 1) * ct)));
+              wait(n, PD(k), 1);
+              if (k > 0) wait(n, UR(k, c128), ALL);
+              inc(n, SS(k, c128));
+            }
+          continue;
+        }
+        for (int r = btk - 1; r >= 0; --r)
+          for (int c = lo; c < nt; ++c) {
+            const bool head = c < hi;
+            if (head != (pass == 0)) continue;
+            const int n = add_node(gS, r, c - lo, DK_S, tile_cost(128, std::min<int64_t>(nbk, (int64_t)(r + 1) * 128)));
+            wait(n, PD(k), 1);
+            if (k > 0) wait(n, UR(k, c), ALL);
+            inc(n, SS(k, c));
+          }
+      }
+      // ---- U(k): trailing update ----------------------------------------------------------------------------------------------
+      GemmArgs u{};
+      u.A = off(o * ldt + c0); u.lda = ldt; u.buf[0] = 2;
+      u.B = u.A; u.ldb = ldt; u.buf[1] = 2;
+      u.C = offw(c0 * ld + c0); u.ldc = ld; u.buf[2] = 0;
+      u.buf[3] = -1;
+      u.M = u.N = (int)rem; u.K = (int)nbk;
+      u.alpha = -1.0; u.beta = 1.0;
+      u.c_lower = 2;
+      u.pad_ok = 1;
+      const int gU = add_group(u, DK_U, k);
+      int gUd = -1;
+      if (ct != 128) {
+        GemmArgs ud = u;
+        ud.M = ud.N = nbk1;
+        ud.etile = ct;
+        gUd = add_group(ud, DK_UD, k);
+        const int rt = (nbk1 + ct - 1) / ct;
+        for (int a = 0; a < rt; ++a)
+          for (int b = a; b < rt; ++b) {
+            const int i = lo + a * ct / 128, j = lo + b * ct / 128;
+            const int n = add_node(gUd, a, b, DK_UD, tile_cost(ct, nbk));
+            if (k > 0) wait(n, VA(i, j), k);
+            wait(n, SS(k, i), ALL);
+            if (j != i) wait(n, SS(k, j), ALL);
+            inc(n, G1D(k + 1));
+          }
+      }
+      for (int i = lo; i < nt; ++i)
+        for (int j = i; j < nt; ++j) {
+          const bool in_next = i < hi;          // block row k+1: this is the tile's LAST update
+          const bool diag = in_next && j < hi;  // inside diagonal block k+1
+          if (diag && gUd >= 0) continue;
+          const int n = add_node(gU, i - lo, j - lo, DK_U, tile_cost(128, nbk));
+          if (k > 0) wait(n, VA(i, j), k);
+          wait(n, SS(k, i), ALL);
+          if (j != i) wait(n, SS(k, j), ALL);
+          if (diag) inc(n, G1D(k + 1));
+          else if (in_next) inc(n, UR(k + 1, j));
+          else inc(n, VA(i, j));
+        }
+      // ---- CP(k): the factor's block row into place -----------------------------------------------------------------------------
+      GemmArgs c{};
+      c.A = off(0); c.buf[0] = 2;
+      c.B = off(o * ldt + c0); c.ldb = ldt; c.buf[1] = 2;
+      c.C = offw(o * ld + c0); c.ldc = ld; c.buf[2] = 0;
+      c.buf[3] = -1;
+      c.M = (int)nbk; c.N = (int)rem;
+      c.op = 1;
+      const int gC = add_group(c, DK_CP, k);
+      for (int cc = lo; cc < nt; ++cc) {
+        const int n = add_node(gC, 0, cc - lo, DK_CP, tune.t_copy);
+        wait(n, SS(k, cc), ALL);
+      }
+      // ---- XB(k): the inverse's running sums ------------------------------------------------------------------------------------
+      if (flags & DAG_INV) {
+        GemmArgs x0{};  // columns of block k: the first contribution (beta = 0), X_kk lower triangular
+        x0.A = off(o * ldt + c0); x0.lda = ldt; x0.buf[0] = 2;
+        x0.B = off(o * ldi + o); x0.ldb = ldi; x0.buf[1] = 1;
+        x0.C = offw(c0 * ldt + o); x0.ldc = ldt; x0.buf[2] = 2;
+        x0.buf[3] = -1;
+        x0.M = (int)rem; x0.N = (int)nbk; x0.K = (int)nbk;
+        x0.alpha = 1.0; x0.beta = 0.0;
+        x0.b_mask = 2; x0.klo_mode = 2;
+        x0.pad_ok = 1;
+        const int g0 = add_group(x0, DK_XB, k);
+        int g1 = -1;
+        if (k > 0) {
+          GemmArgs x1 = x0;  // columns left of block k: accumulate
+          x1.B = off(o * ldi);
+          x1.C = offw(c0 * ldt);
+          x1.N = (int)o;
+          x1.beta = 1.0;
+          x1.b_mask = 0; x1.klo_mode = 0;
+          g1 = add_group(x1, DK_XB, k);
+        }
+        for (int i = lo; i < nt; ++i) {
+          const bool fin = i < hi;  // block row k+1: the sums of that block row are complete after this step
+          for (int j = 0; j < lo; ++j) {
+            const bool own = j >= tb[k];
+            const int bj = blk_of(j);
+            const int64_t K = own ? nbk - (int64_t)(j - tb[k]) * 128 : nbk;
+            const int n = add_node(own ? g0 : g1, i - lo, own ? j - tb[k] : j, DK_XB, tile_cost(128, K));
+            wait(n, SS(k, i), ALL);
+            if (own) wait(n, PD(k), 1);
+            else wait(n, XS(k, j), ALL);
+            if (k - bj > 0) wait(n, VT(i, j), k - bj);
+            if (fin) inc(n, XR(k + 1, j));
+            else inc(n, VT(i, j));
+          }
+        }
+      }
+    }
+  }
+
+  // ALL -> the number of incrementers; predecessor lists; bottom levels.  False when the graph is not a DAG (a planner bug).
+  std::vector<std::vector<int>> preds;
+  bool resolve() {
+    for (Node& n : nodes)
+      for (int q = 0; q < 3; ++q)
+        if (n.w[q] >= 0 && n.v[q] == ALL) n.v[q] = (int)incs[n.w[q]].size();
+    const int nn = (int)nodes.size();
+    preds.assign(nn, {});
+    std::vector<int> nsucc(nn, 0);
+    for (int t = 0; t < nn; ++t) {
+      const Node& n = nodes[t];
+      for (int q = 0; q < 3; ++q) {
+        if (n.w[q] < 0) continue;
+        const auto& in = incs[n.w[q]];
+        if (n.v[q] < 1 || n.v[q] > (int)in.size()) return false;  // would never be satisfied
+        if (chain[n.w[q]]) preds[t].push_back(in[n.v[q] - 1]);
+        else {
+          if (n.v[q] != (int)in.size()) return false;  // "any v of n" would depend on the execution order
+          for (int p : in) preds[t].push_back(p);
+        }
+      }
+      for (int p : preds[t]) ++nsucc[p];
+    }
+    // a version counter's v-th increment must itself follow the (v-1)-th: its incrementers wait for it with v-1 (checked here)
+    for (int c = 0; c < ncounters; ++c)
+      if (chain[c])
+        for (size_t q = 1; q < incs[c].size(); ++q) {
+          const Node& n = nodes[incs[c][q]];
+          bool ok = false;
+          for (int z = 0; z < 3; ++z) ok |= (n.w[z] == c && n.v[z] == (int)q);
+          if (!ok) return false;
+        }
+    // bottom levels by reverse topological order (Kahn on the reversed graph)
+    std::vector<int> stack;
+    for (int t = 0; t < nn; ++t) {
+      nodes[t].bl = nodes[t].cost;
+      if (nsucc[t] == 0) stack.push_back(t);
+    }
+    int seen = 0;
+    while (!stack.empty()) {
+      const int t = stack.back();
+      stack.pop_back();
+      ++seen;
+      for (int p : preds[t]) {
+        nodes[p].bl = std::max(nodes[p].bl, nodes[p].cost + nodes[t].bl);
+        if (--nsucc[p] == 0) stack.push_back(p);
+      }
+    }
+    return seen == nn;
+  }
+
+  // List scheduling on `workers` identical workers (panels on their own stream, one at a time): returns the nodes in start order.
+  // fill_m[b] > 0: after the panel of block b a filler launch of tune.fill work-groups on the panel's CUs takes up to fill_m[b] tasks
+  // each from the same list; it stops taking tasks when the next panel's gate opens, and that panel starts when the launch has ended.
+  std::vector<int> order;
+  std::vector<int> fill_m;            // per block (empty: no filler launches)
+  std::vector<double> p_end, g_open;  // per block: end of its panel, time its gate opened (simulated)
+  double makespan = 0, busy = 0;
+  void simulate() {
+    const int nn = (int)nodes.size(), W = std::max(1, tune.workers), F = std::max(0, tune.fill);
+    std::vector<int> value(ncounters, 0), unsat(nn, 0);
+    struct Waiter { int need, node; };
+    std::vector<std::vector<Waiter>> waiters(ncounters);
+    std::vector<int> wpos(ncounters, 0);
+    for (int t = 0; t < nn; ++t)
+      for (int q = 0; q < 3; ++q)
+        if (nodes[t].w[q] >= 0) {
+          ++unsat[t];
+          waiters[nodes[t].w[q]].push_back({nodes[t].v[q], t});
+        }
+    for (auto& wl : waiters) std::sort(wl.begin(), wl.end(), [](const Waiter& a, const Waiter& b) { return a.need < b.need; });
+    auto better = [&](int a, int b) {  // a runs before b
+      if (nodes[a].bl != nodes[b].bl) return nodes[a].bl > nodes[b].bl;
+      return a < b;
+    };
+    auto cmp = [&](int a, int b) { return better(b, a); };
+    std::priority_queue<int, std::vector<int>, decltype(cmp)> ready(cmp);
+    struct Ev {
+      double t;
+      int node, wid;  // node >= 0: completion (wid < 0 main worker, else filler worker); node == -2: the filler launch of block wid starts
+      bool operator>(const Ev& o) const { return t > o.t; }
+    };
+    std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> events;
+    std::vector<int> panel_ready;
+    double now = 0, panel_free = 0;
+    int wfree = W;
+    std::vector<int> fbudget(F, 0), ffree;  // filler workers of the current launch: tasks left, ids of the idle ones
+    int falive = 0;                         // filler workers that have not left yet
+    bool fquit = false;                     // the next gate is open: no filler takes a further task
+    int pending_panel = -1;                 // a panel whose gate is open but whose CUs still run a filler launch
+    order.clear();
+    order.reserve(nn);
+    p_end.assign(B, 0);
+    g_open.assign(B, 0);
+    auto make_ready = [&](int t) {
+      if (nodes[t].kind < 0) panel_ready.push_back(t);
+      else ready.push(t);
+    };
+    auto start_panel = [&](int t) {
+      const double st = std::max(now, panel_free);
+      panel_free = st + nodes[t].cost;
+      events.push({panel_free, t, -1});
+      order.push_back(t);
+    };
+    for (int t = 0; t < nn; ++t)
+      if (unsat[t] == 0) make_ready(t);
+    busy = 0;
+    for (;;) {
+      for (int t : panel_ready) {  // (panels become ready in block order: the stream runs them in that order)
+        g_open[nodes[t].tm] = now;
+        fquit = true;
+        falive -= (int)ffree.size();  // idle filler workers leave at once
+        ffree.clear();
+        if (falive > 0) pending_panel = t;
+        else start_panel(t);
+      }
+      panel_ready.clear();
+      while (!ready.empty() && (wfree > 0 || !ffree.empty())) {
+        const int t = ready.top();
+        ready.pop();
+        int wid = -1;
+        if (wfree > 0) --wfree;
+        else {
+          wid = ffree.back();
+          ffree.pop_back();
+          --fbudget[wid];
+        }
+        order.push_back(t);
+        events.push({now + nodes[t].cost, t, wid});
+        busy += nodes[t].cost;
+      }
+      if (events.empty()) break;
+      const Ev e = events.top();
+      events.pop();
+      now = e.t;
+      if (e.node == -2) {  // filler launch of block e.wid
+        if (!fquit && F > 0) {
+          falive = F;
+          for (int f = 0; f < F; ++f) {
+            fbudget[f] = fill_m[e.wid];
+            ffree.push_back(f);
+          }
+        }
+        continue;
+      }
+      const int t = e.node;
+      if (nodes[t].kind < 0) {
+        const int b = nodes[t].tm;
+        p_end[b] = now;
+        fquit = false;
+        if (F > 0 && !fill_m.empty() && fill_m[b] > 0) events.push({now + 12.0, -2, b});
+      } else if (e.wid < 0) {
+        ++wfree;
+      } else {
+        if (fquit || fbudget[e.wid] <= 0) {
+          if (--falive == 0 && pending_panel >= 0) {
+            start_panel(pending_panel);
+            pending_panel = -1;
+          }
+        } else {
+          ffree.push_back(e.wid);
+        }
+      }
+      for (int q = 0; q < 2; ++q) {
+        const int c = nodes[t].inc[q];
+        if (c < 0) continue;
+        const int v = ++value[c];
+        auto& wl = waiters[c];
+        while (wpos[c] < (int)wl.size() && wl[wpos[c]].need <= v) {
+          const int u = wl[wpos[c]++].node;
+          if (--unsat[u] == 0) make_ready(u);
+        }
+      }
+    }
+    makespan = now;
+    busy = makespan > 0 ? busy / (makespan * W) : 0;
+  }
+  // Two passes: without filler launches first, which tells how long the panel's CUs idle between panel b and the gate of block
+  // b + 1; the filler launches are sized from that (whole tasks of the big tile, a margin of 0.35 of one) and the list re-ordered.
+  void schedule() {
+    fill_m.clear();
+    simulate();
+    if (tune.fill <= 0) return;
+    const double t_tile = tile_cost(128, nb);
+    fill_m.assign(B, 0);
+    bool any = false;
+    for (int b = 0; b + 1 < B; ++b) {
+      const double idle = g_open[b + 1] - p_end[b] - 12.0;
+      const int m = (int)std::floor(idle / t_tile - 0.35);
+      fill_m[b] = std::max(0, std::min(m, 64));
+      any |= fill_m[b] > 0;
+    }
+    // behind the LAST panel its CUs are free for good: a launch without a budget works the list to its end (the inverse's tasks)
+    if (makespan - p_end[B - 1] > 2.0 * t_tile) {
+      fill_m[B - 1] = 1 << 20;
+      any = true;
+    }
+    if (any) simulate();
+    else fill_m.clear();
+  }
+};
+
+// a plan from the planner's state (tasks in `order`, panels as stream operations)
+DagPlan* emit(Planner& pl) {
+  DagPlan* P = new DagPlan();
+  P->N = pl.N; P->nb = pl.nb; P->ld = pl.ld; P->ldi = pl.ldi; P->ldt = pl.ldt; P->ldk = pl.ldk;
+  P->flags = pl.flags;
+  P->B = pl.B; P->nt = pl.nt; P->tb = pl.tb;
+  P->groups = pl.groups;
+  P->ncounters = pl.ncounters;
+  P->c_pd = pl.c_pd; P->c_g1d = pl.c_g1d;
+  P->gate_target.assign(pl.B, 0);
+  P->sim_ms = pl.makespan * 1e-3;
+  P->sim_busy = pl.busy;
+  // first ticket of each level: a filler launch behind panel b stops in front of the first task that needs panel b + 1
+  std::vector<int> first_of(pl.B + 1, 1 << 30);
+  {
+    int pos = 0;
+    for (int t : pl.order) {
+      const Node& n = pl.nodes[t];
+      if (n.kind < 0) continue;
+      first_of[n.lvl] = std::min(first_of[n.lvl], pos);
+      ++pos;
+    }
+    for (int b = pl.B - 1; b >= 0; --b) first_of[b] = std::min(first_of[b], first_of[b + 1]);  // "level >= b"
+  }
+  for (int t : pl.order) {
+    const Node& n = pl.nodes[t];
+    if (n.kind < 0) {
+      const int b = n.tm;
+      if (b > 0) {
+        P->gate_target[b] = n.v[0];
+        P->stream_ops.push_back({0, b, 0, 0});
+      }
+      P->stream_ops.push_back({1, b, 0, 0});
+      P->stream_ops.push_back({2, b, 0, 0});
+      if (!pl.fill_m.empty() && pl.fill_m[b] > 0 && (b + 1 == pl.B || first_of[b + 1] > 0))
+        P->stream_ops.push_back({3, b + 1 < pl.B ? pl.fill_m[b] : 0, b + 1 < pl.B ? b + 1 : -1, b + 1 < pl.B ? first_of[b + 1] : 0});
+      continue;
+    }
+    DagTask d;
+    d.group = n.group;
+    d.tm = (int16_t)n.tm;
+    d.tn = (int16_t)n.tn;
+    for (int q = 0; q < 3; ++q) {
+      d.wait_id[q] = n.w[q];
+      d.wait_val[q] = n.w[q] >= 0 ? n.v[q] : 0;
+    }
+    d.inc_id[0] = n.inc[0];
+    d.inc_id[1] = n.inc[1];
+    d.kind = n.kind;
+    P->tasks.push_back(d);
+  }
+  return P;
+}
+
+}  // namespace
+
+DagTuning gpp_dag_default_tuning() {
+  DagTuning t;
+  // two work-groups per CU, measured per task with tools/dag_trace.py (K = 1024: ~250 us for the big tile)
+  t.t0_big = getenv("GPP_DAG_T0") ? atof(getenv("GPP_DAG_T0")) : 14.0;
+  t.tc_big = getenv("GPP_DAG_TC") ? atof(getenv("GPP_DAG_TC")) : 3.7;
+  t.t0_64 = 8.0; t.tc_64 = 0.75;
+  t.t0_32 = 6.0; t.tc_32 = 0.55;
+  t.t_copy = 12.0;
+  t.t_panel0 = getenv("GPP_DAG_TP0") ? atof(getenv("GPP_DAG_TP0")) : 20.0;
+  t.t_panel_leaf = getenv("GPP_DAG_TPL") ? atof(getenv("GPP_DAG_TPL")) : 70.0;
+  t.t_gate = 15.0;
+  t.chain_tile = getenv("GPP_DAG_CHAIN_TILE") ? atoi(getenv("GPP_DAG_CHAIN_TILE")) : 64;
+  t.workers = 448;
+  t.fill = getenv("GPP_DAG_FILL") ? atoi(getenv("GPP_DAG_FILL")) : 64;
+  return t;
+}
+
+DagPlan* gpp_dag_plan(int64_t N, int64_t nb, int64_t ld, int64_t ldi, int64_t ldt, int64_t ldk, int flags, const DagTuning& tune) {
+  Planner pl;
+  pl.N = N; pl.nb = nb; pl.ld = ld; pl.ldi = ldi; pl.ldt = ldt; pl.ldk = ldk;
+  pl.flags = flags;
+  pl.tune = tune;
+  if (!pl.layout()) return nullptr;
+  pl.generate();
+  if (!pl.resolve()) {
+    fprintf(stderr, "libgpp_hip: dag planner: the task graph of N = %lld, nb = %lld is not a DAG (planner bug); not used\n", (long long)N, (long long)nb);
+    return nullptr;
+  }
+  pl.schedule();
+  if (pl.order.size() != pl.nodes.size()) {
+    fprintf(stderr, "libgpp_hip: dag planner: the simulation of N = %lld left %zu of %zu tasks unscheduled (planner bug); not used\n",
+            (long long)N, pl.nodes.size() - pl.order.size(), pl.nodes.size());
+    return nullptr;
+  }
+  DagPlan* P = emit(pl);
+  if (getenv("GPP_EXEC_VERBOSE"))
+    fprintf(stderr, "libgpp_hip: dag plan N=%lld nb=%lld flags=%d: %d blocks, %zu tasks, %zu groups, %d counters; simulated %.2f ms, "
+                    "%.0f %% busy on %d workers\n", (long long)N, (long long)nb, flags, P->B, P->tasks.size(), P->groups.size(), P->ncounters,
+            P->sim_ms, 100.0 * P->sim_busy, tune.workers);
+  if (getenv("GPP_EXEC_VERBOSE") && !pl.fill_m.empty()) {
+    fprintf(stderr, "libgpp_hip: dag plan filler tasks per work-group and block:");
+    for (int m : pl.fill_m) fprintf(stderr, " %d", m);
+    fprintf(stderr, "\n");
+  }
+  return P;
+}
+
+hipError_t gpp_dag_upload(DagPlan* P) {
+  hipError_t e;
+  if (P->d_tasks) return hipSuccess;
+  if ((e = hipMalloc(&P->d_tasks, P->tasks.size() * sizeof(DagTask))) != hipSuccess) return e;
+  if ((e = hipMemcpy(P->d_tasks, P->tasks.data(), P->tasks.size() * sizeof(DagTask), hipMemcpyHostToDevice)) != hipSuccess) return e;
+  if ((e = hipMalloc(&P->d_groups, P->groups.size() * sizeof(GemmArgs))) != hipSuccess) return e;
+  if ((e = hipMemcpy(P->d_groups, P->groups.data(), P->groups.size() * sizeof(GemmArgs), hipMemcpyHostToDevice)) != hipSuccess) return e;
+  if ((e = hipMalloc(&P->d_groups_abs, P->groups.size() * sizeof(GemmArgs))) != hipSuccess) return e;
+  if ((e = hipMalloc(&P->d_counters, (size_t)P->ncounters * sizeof(int))) != hipSuccess) return e;
+  return hipEventCreateWithFlags(&P->last_use, hipEventDisableTiming);
+}
+
+void gpp_dag_free(DagPlan* P) {
+  if (!P) return;
+  if (P->last_use) {
+    (void)hipEventSynchronize(P->last_use);  // the launches that read the device copies are over (no device-wide wait)
+    (void)hipEventDestroy(P->last_use);
+  }
+  if (P->d_groups) (void)hipFree(P->d_groups);
+  if (P->d_groups_abs) (void)hipFree(P->d_groups_abs);
+  if (P->d_tasks) (void)hipFree(P->d_tasks);
+  if (P->d_counters) (void)hipFree(P->d_counters);
+  if (P->d_trace) (void)hipFree(P->d_trace);
+  delete P;
+}
+
+// ---- host-side verification of a plan (tests/test_host_cpu.py) ---------------------------------------------------------------------
+// Executes the ticket list on the host with W workers in random and adversarial interleavings that respect only what the device
+// respects — tickets are taken in list order, a task runs when its counters allow, the panel stream runs gate / panel / signal in
+// order — and checks what the ARITHMETIC needs, from the tasks' geometry alone (never from their counters): a solve reads a fully
+// updated, not yet overwritten block row and a factored diagonal block; an update reads completely solved strips and is the k-th
+// on its tile; a panel starts on a fully updated block; the inverse's sums take their contributions in order from final rows of X;
+// a row of X is built from complete sums; everything is complete at the end; nothing deadlocks (W = 1 executes the list in order,
+// so the order itself must be topological).  Returns 0 or a code naming the first violation.  stats[0..3]: tasks run, waits,
+// increments, tasks run by filler launches — or, with `mutate` > 0, which removes the mutate-th wait of the plan first (the check
+// must then FAIL), the kind of the task that lost its wait * 10 + which counter family.
+extern "C" int gpp_debug_dag_check(int64_t N, int64_t nb, int flags, int chain_tile, int W, int fill, unsigned seed, int64_t* stats,
+                                   int mutate) {
+  DagTuning tune = gpp_dag_default_tuning();
+  tune.chain_tile = chain_tile;
+  tune.fill = fill;
+  tune.workers = std::max(W, 1);
+  DagPlan* P = gpp_dag_plan(N, nb, N, N, N, N, flags, tune);
+  if (!P) return 1;
+  // geometry, recomputed independently of the planner's counters
+  const int nt = P->nt, B = P->B;
+  const std::vector<int>& tb = P->tb;
+  auto blk_of = [&](int tile) { return (int)(std::upper_bound(tb.begin(), tb.end(), tile) - tb.begin()) - 1; };
+  // which block / kind a group belongs to: from its operands (offsets), not from planner metadata
+  struct GInfo { int kind, k; };
+  std::vector<GInfo> gi(P->groups.size());
+  for (size_t g = 0; g < P->groups.size(); ++g) {
+    const GemmArgs& a = P->groups[g];
+    const int64_t offC = (int64_t)(reinterpret_cast<uintptr_t>(a.C) / 8), offB = (int64_t)(reinterpret_cast<uintptr_t>(a.B) / 8);
+    int kind, k;
+    if (a.op == 1) { kind = DK_CP; k = blk_of((int)(offB / N / 128)); }
+    else if (a.buf[2] == 0) { kind = a.etile && a.etile != 128 ? DK_UD : DK_U; k = blk_of((int)(offB / N / 128)); }          // C in A: update
+    else if (a.buf[2] == 1) { kind = DK_XA; k = blk_of((int)(offC / N / 128)); }                                               // C in Linv
+    else if (a.buf[1] == 0) { kind = a.etile && a.etile != 128 ? DK_SH : DK_S; k = blk_of((int)(offC / N / 128)); }          // B from A: solve
+    else { kind = DK_XB; k = blk_of((int)(offB / N / 128)); }                                                                  // B from Linv
+    gi[g] = {kind, k};
+  }
+  int mutated = -1, lazy_counter = -1;
+  const int mutate_in = mutate;
+  if (mutate > 0) {
+    int seen = 0;
+    for (auto& t : P->tasks)
+      for (int q = 0; q < 3 && mutate > 0; ++q)
+        if (t.wait_id[q] >= 0 && ++seen == mutate) {
+          const int c = t.wait_id[q];
+          const int fam = c < P->c_g1d ? 0 : c < P->c_g1d + B ? 1 : 2 + (int)(((int64_t)c - (P->c_g1d + B)) / ((int64_t)B * nt));
+          mutated = 10 * gi[t.group].kind + std::min(fam, 9);
+          if (getenv("GPP_DAG_CHECK_VERBOSE"))
+            fprintf(stderr, "mutate: task %ld kind %d block %d tile (%d, %d) loses wait %d (counter %d >= %d, family %d)\n",
+                    (long)(&t - P->tasks.data()), gi[t.group].kind, gi[t.group].k, (int)t.tm, (int)t.tn, q, c, t.wait_val[q], fam);
+          t.wait_id[q] = -1;
+          mutate = 0;
+          lazy_counter = c;
+        }
+  }
+  // With a wait removed the adversary is TARGETED: the tasks (and the panel-stream signal) that raise the counter the removed wait
+  // referred to run only when nothing else can — on the device: those work-groups are slow —, so the task that lost its wait runs
+  // before them whenever the remaining waits allow it at all.
+  std::vector<char> lazy(P->tasks.size(), 0);
+  if (lazy_counter >= 0)
+    for (size_t t = 0; t < P->tasks.size(); ++t)
+      lazy[t] = P->tasks[t].inc_id[0] == lazy_counter || P->tasks[t].inc_id[1] == lazy_counter;
+  auto tixU = [&](int i, int j) { return (size_t)((int64_t)i * nt - (int64_t)i * (i - 1) / 2 + (j - i)); };
+  std::vector<int> counters(P->ncounters, 0);
+  std::vector<int> a_upd((size_t)nt * (nt + 1) / 2, 0);              // updates applied to A[i][j], i <= j
+  std::vector<int> ud_done((size_t)nt * (nt + 1) / 2, 0), ud_need((size_t)nt * (nt + 1) / 2, 0);  // small-tile updates of a tile in flight
+  std::vector<int> t_done((size_t)nt * nt, 0), t_need((size_t)nt * nt, 0);  // solve tasks done / covering T[i][c] (upper right)
+  std::vector<int> t_acc((size_t)nt * nt, 0);                        // contributions in T[i][j] (lower left)
+  std::vector<char> x_done((size_t)nt * nt, 0), copied((size_t)B * nt, 0), panel_done(B, 0);
+  // how many solve / small update tasks cover each 128-tile
+  for (const DagTask& t : P->tasks) {
+    const GInfo g = gi[t.group];
+    const int et = P->groups[t.group].etile ? P->groups[t.group].etile : 128;
+    if (g.kind == DK_S || g.kind == DK_SH) {
+      const int lo = tb[g.k + 1];
+      const int i = tb[g.k] + t.tm * et / 128, c = lo + t.tn * et / 128;
+      ++t_need[(size_t)i * nt + c];
+    } else if (g.kind == DK_UD) {
+      const int lo = tb[g.k + 1];
+      ++ud_need[tixU(lo + t.tm * et / 128, lo + t.tn * et / 128)];
+    }
+  }
+  uint64_t rng = 0x9E3779B97F4A7C15ull ^ seed;
+  auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+  int rc = 0;
+  int64_t ran = 0, waits = 0, nincs = 0;
+  auto fail = [&](int code) { if (!rc) rc = code; };
+  auto solved = [&](int k, int c) {  // every tile of T[k rows, c] is completely solved
+    for (int i = tb[k]; i < tb[k + 1]; ++i)
+      if (t_need[(size_t)i * nt + c] == 0 || t_done[(size_t)i * nt + c] != t_need[(size_t)i * nt + c]) return false;
+    return true;
+  };
+  auto try_task = [&](const DagTask& t) -> bool {
+    for (int q = 0; q < 3; ++q)
+      if (t.wait_id[q] >= 0 && counters[t.wait_id[q]] < t.wait_val[q]) return false;
+    const GInfo g = gi[t.group];
+    const GemmArgs& a = P->groups[t.group];
+    const int et = a.etile ? a.etile : 128, k = g.k;
+    if (g.kind == DK_S || g.kind == DK_SH) {
+      const int lo = tb[k + 1];
+      const int i = tb[k] + t.tm * et / 128, c = lo + t.tn * et / 128;
+      if (!panel_done[k]) fail(10);
+      if (copied[(size_t)k * nt + c]) fail(11);
+      const int rmax = std::min(tb[k + 1] - 1, tb[k] + ((t.tm + 1) * et - 1) / 128);  // K range ends with this tile's last row
+      for (int r = tb[k]; r <= rmax; ++r)
+        if (a_upd[tixU(r, c)] != k || ud_done[tixU(r, c)] != 0) fail(12);
+      if (t_done[(size_t)i * nt + c] >= t_need[(size_t)i * nt + c]) fail(13);
+      ++t_done[(size_t)i * nt + c];
+    } else if (g.kind == DK_U || g.kind == DK_UD) {
+      const int lo = tb[k + 1];
+      const int i = lo + t.tm * et / 128, j = lo + t.tn * et / 128;
+      if (i > j || j >= nt) fail(20);
+      if (!solved(k, i) || !solved(k, j)) fail(21);
+      if (a_upd[tixU(i, j)] != k) fail(22);
+      if (g.kind == DK_U) {
+        if (ud_need[tixU(i, j)] != 0 && blk_of(i) == k + 1 && blk_of(j) == k + 1) fail(23);  // tile covered twice
+        a_upd[tixU(i, j)] = k + 1;
+      } else {
+        if (++ud_done[tixU(i, j)] == ud_need[tixU(i, j)]) {
+          ud_done[tixU(i, j)] = 0;
+          a_upd[tixU(i, j)] = k + 1;
+        }
+      }
+    } else if (g.kind == DK_CP) {
+      const int c = tb[k + 1] + t.tn;
+      if (!solved(k, c)) fail(30);
+      if (copied[(size_t)k * nt + c]) fail(31);
+      copied[(size_t)k * nt + c] = 1;
+    } else if (g.kind == DK_XB) {
+      const int lo = tb[k + 1];
+      const int i = lo + t.tm;
+      const bool own = a.beta == 0.0;
+      const int j = own ? tb[k] + t.tn : t.tn;
+      const int bj = blk_of(j);
+      if (!solved(k, i)) fail(40);
+      if (own) {
+        if (!panel_done[k]) fail(41);
+        if (bj != k) fail(42);
+      } else {
+        if (bj >= k) fail(42);
+        for (int r = tb[k]; r < tb[k + 1]; ++r)
+          if (!x_done[(size_t)r * nt + j]) fail(43);
+      }
+      if (t_acc[(size_t)i * nt + j] != k - bj) fail(44);
+      ++t_acc[(size_t)i * nt + j];
+    } else if (g.kind == DK_XA) {
+      const int i = tb[k] + t.tm, j = t.tn, bj = blk_of(j);
+      if (!panel_done[k]) fail(50);
+      if (bj >= k) fail(51);
+      for (int r = tb[k]; r <= i; ++r)
+        if (t_acc[(size_t)r * nt + j] != k - bj) fail(52);
+      if (x_done[(size_t)i * nt + j]) fail(53);
+      x_done[(size_t)i * nt + j] = 1;
+    } else {
+      fail(60);
+    }
+    for (int q = 0; q < 3; ++q)
+      if (t.wait_id[q] >= 0) ++waits;
+    for (int q = 0; q < 2; ++q)
+      if (t.inc_id[q] >= 0) {
+        ++counters[t.inc_id[q]];
+        ++nincs;
+      }
+    ++ran;
+    return true;
+  };
+  size_t op = 0;
+  bool stream_done = P->stream_ops.empty();
+  const int64_t ntasks = (int64_t)P->tasks.size();
+  int64_t head = 0, finished = 0, fill_tasks = 0;
+  // a filler launch in progress: its work-groups' current tickets (-1: none), tasks left, and whether each has left
+  std::vector<int64_t> fcur;
+  std::vector<int> fleft;
+  bool in_fill = false;
+  auto stream_step = [&]() -> bool {
+    if (stream_done) return false;
+    const DagPlan::Op o = P->stream_ops[op];
+    if (o.kind == 0) {
+      if (counters[P->c_g1d + o.arg] < P->gate_target[o.arg]) return false;
+    } else if (o.kind == 1) {
+      const int b = o.arg;
+      for (int i = tb[b]; i < tb[b + 1]; ++i)
+        for (int j = i; j < tb[b + 1]; ++j)
+          if (a_upd[tixU(i, j)] != b || ud_done[tixU(i, j)] != 0) fail(70);
+      if (panel_done[b]) fail(71);
+      panel_done[b] = 1;
+    } else if (o.kind == 2) {
+      if (!panel_done[o.arg]) fail(72);
+      ++counters[P->c_pd + o.arg];
+    } else {
+      // filler launch: `fill` work-groups, each takes up to o.arg tasks and none once the gate counter of block o.n has moved
+      if (!in_fill) {
+        in_fill = true;
+        fcur.assign(std::max(fill, 1), -1);
+        fleft.assign(std::max(fill, 1), o.arg > 0 ? o.arg : 1 << 30);
+      }
+      bool progressed = false, any_alive = false;
+      const size_t nf = fcur.size(), s0 = (size_t)(rnd() % nf);
+      for (size_t q = 0; q < nf; ++q) {
+        const size_t f = (s0 + q) % nf;
+        if (fcur[f] < 0) {
+          if (fleft[f] <= 0) continue;  // has left
+          if ((o.n >= 0 && counters[P->c_g1d + o.n] >= 1) || head >= ntasks || (o.lim > 0 && head >= o.lim)) {
+            fleft[f] = 0;
+            progressed = true;
+            continue;
+          }
+          if (progressed) { any_alive = true; continue; }
+          fcur[f] = head++;
+          --fleft[f];
+          progressed = true;
+        }
+        any_alive = true;
+        if (!progressed || fcur[f] >= 0) {
+          if (try_task(P->tasks[fcur[f]])) {
+            fcur[f] = -1;
+            ++finished;
+            ++fill_tasks;
+            progressed = true;
+          }
+        }
+      }
+      if (any_alive) return progressed;
+      for (size_t f = 0; f < nf; ++f)
+        if (fcur[f] >= 0 || fleft[f] > 0) return progressed;
+      in_fill = false;
+    }
+    if (++op == P->stream_ops.size()) stream_done = true;
+    return true;
+  };
+  const int mode = (lazy_counter >= 0 && (seed & 3u) == 0) ? 1 : (int)(seed & 3u);
+  std::vector<int64_t> cur(W, -1);
+  bool allow_lazy = lazy_counter < 0;
+  while (!rc) {
+    bool progressed = false;
+    if ((mode == 0 && rnd() % 8 == 0) || (in_fill && rnd() % 3 == 0)) progressed = stream_step();
+    const int w0 = mode >= 2 ? 0 : (int)(rnd() % W);
+    for (int q = 0; q < W && !progressed; ++q) {
+      const int w = mode == 2 ? W - 1 - q : (w0 + q) % W;
+      const int burst = (mode >= 2 || rnd() % 16 == 0) ? (1 << 30) : 1 + (int)(rnd() % 3);
+      // taking a ticket and running its task are SEPARATE steps: a work-group may sit on a runnable task for any length of time
+      for (int b = 0; b < burst; ++b) {
+        if (cur[w] < 0) {
+          if (head >= ntasks) break;
+          cur[w] = head++;
+          progressed = true;
+          if (mode < 2 && rnd() % 4 != 0) break;
+          continue;
+        }
+        if (lazy[cur[w]] && !allow_lazy) break;
+        if (!try_task(P->tasks[cur[w]])) break;
+        cur[w] = -1;
+        ++finished;
+        progressed = true;
+      }
+    }
+    if (!progressed) progressed = stream_step();
+    if (finished == ntasks && stream_done) break;
+    if (!progressed && !allow_lazy) {
+      allow_lazy = true;  // nothing else can run: one round with the slow tasks
+      continue;
+    }
+    if (lazy_counter >= 0) allow_lazy = false;
+    if (!progressed) fail(2);  // deadlock
+  }
+  if (!rc) {
+    for (int b = 0; b < B && !rc; ++b) {
+      if (!panel_done[b]) fail(80);
+      for (int c = tb[b + 1]; c < nt && !rc; ++c)
+        if (!copied[(size_t)b * nt + c]) fail(81);
+      if (flags & DAG_INV)
+        for (int i = tb[b]; i < tb[b + 1] && !rc; ++i)
+          for (int j = 0; j < tb[b]; ++j)
+            if (!x_done[(size_t)i * nt + j]) { fail(82); break; }
+    }
+  }
+  if (stats) {
+    stats[0] = ran;
+    stats[1] = waits;
+    stats[2] = nincs;
+    stats[3] = mutate_in > 0 ? mutated : fill_tasks;
+  }
+  gpp_dag_free(P);
+  return rc;
+}
+
+// the planner's own estimate for a size (tools): stats = {tasks, simulated us, busy per mille, blocks}
+extern "C" int gpp_debug_dag_sim(int64_t N, int64_t nb, int flags, int chain_tile, int workers, int64_t* stats) {
+  DagTuning tune = gpp_dag_default_tuning();
+  tune.chain_tile = chain_tile;
+  tune.workers = workers;
+  DagPlan* P = gpp_dag_plan(N, nb, N, N, N, N, flags, tune);
+  if (!P) return 1;
+  stats[0] = (int64_t)P->tasks.size();
+  stats[1] = (int64_t)(P->sim_ms * 1000.0);
+  stats[2] = (int64_t)(P->sim_busy * 1000.0);
+  stats[3] = P->B;
+  gpp_dag_free(P);
+  return 0;
+}

@@ -185,11 +185,11 @@ __device__ __forceinline__ void load_fast(const double* __restrict__ ubase, cons
 // waves, a 256 x 128 tile on ONE work-group per CU: the experiment of DESIGN.md section 3.5 — 25 % fewer operand bytes per flop).
 // One output tile (tm, tn) of the product described by ``p``: the body shared by the launch-per-product kernel (gpp_gemm_f64, p in
 // the kernel arguments) and the static-schedule executor (gpp_exec_f64, p in a device array read through the constant address
-// space: scalar loads, re-materialisable like kernel arguments).  A, B, C: the batch element's operands; c2off: its offset into
-// the mirrored output p.C2.  Ends with a work-group barrier after the last LDS read, so the caller may stage another tile at once.
+// space: scalar loads, re-materialisable like kernel arguments).  A, B, C: the batch element's operands,
+// C2: its mirrored output (or null).  Ends with a work-group barrier after the last LDS read, so the caller may stage another tile at once.
 template <int VAR, int WTM, int WTN, int TAG, int BK, int NBUF, int WR, class P>
 __device__ __forceinline__ void gemm_tile(const P& p, const int tm, const int tn, const double* __restrict__ A,
-                                          const double* __restrict__ B, double* __restrict__ C, const int64_t c2off,
+                                          const double* __restrict__ B, double* __restrict__ C, double* C2,
                                           double* __restrict__ smem) {
   static_assert(BK == 16 || VAR == 2, "wide K chunks are implemented for row-contiguous (TN) operands only");
   static_assert(BK % 16 == 0 && (NBUF == 1 || NBUF == 2), "bad staging parameters");
@@ -412,8 +412,8 @@ __device__ __forceinline__ void gemm_tile(const P& p, const int tm, const int tn
         if (beta != 0.0) v = fma(beta, cold[a][b], v);
         if (ok) {
           C[(int64_t)m * p.ldc + n] = v;
-          if (p.C2)  // mirrored (transposed) copy
-            p.C2[c2off + (int64_t)n * p.ldc2 + m] = v;
+          if (C2)  // mirrored (transposed) copy
+            C2[(int64_t)n * p.ldc2 + m] = v;
         }
       }
     }
@@ -483,7 +483,8 @@ __global__ __launch_bounds__(128 * WR, ((VAR == 2 && !(BK > 16 && WTM >= 64)) ||
   }
   const int64_t bi = p.batch_fast ? (int64_t)(blockIdx.x % (unsigned)p.nbatch) : (int64_t)blockIdx.y;  // batch element
   gemm_tile<VAR, WTM, WTN, TAG, BK, NBUF, WR>(p, tm, tn, p.A + bi * p.sA + (int64_t)blockIdx.z * p.zA, p.B + bi * p.sB + (int64_t)blockIdx.z * p.zB,
-                                             p.C + bi * p.sC + (int64_t)blockIdx.z * p.zC, bi * p.sC2 + (int64_t)blockIdx.z * p.zC2, smem);
+                                             p.C + bi * p.sC + (int64_t)blockIdx.z * p.zC,
+                                             p.C2 ? p.C2 + bi * p.sC2 + (int64_t)blockIdx.z * p.zC2 : nullptr, smem);
 
 }
 
@@ -543,7 +544,8 @@ typedef const int32_t GPP_AS4 CInt32;
 __device__ __forceinline__ int exec_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // thread 0 polls until both counters have reached their values; false: the launch is being abandoned (time-out or abort word)
-__device__ __forceinline__ bool exec_poll(int* counters, int w0, int v0, int w1, int v1, long long budget, int32_t* info) {
+__device__ __forceinline__ bool exec_poll(int* counters, int w0, int v0, int w1, int v1, long long budget, int32_t* info,
+                                          int status = GPP_INFO_EXEC_TIMEOUT) {
   long long t0 = 0;
   bool timed = false;
   for (;;) {
@@ -559,7 +561,7 @@ __device__ __forceinline__ bool exec_poll(int* counters, int w0, int v0, int w1,
     if (waited > budget) {
       const long long ms = waited / 100000;
       __hip_atomic_store(counters, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      atomicCAS(info, 0, GPP_INFO_PANEL_TIMEOUT | (int)(ms > 0xFFFFF ? 0xFFFFF : ms));
+      atomicCAS(info, 0, status | (int)(ms > 0xFFFFF ? 0xFFFFF : ms));
       return false;
     }
     __builtin_amdgcn_s_sleep(2);
@@ -603,7 +605,7 @@ __global__ __launch_bounds__(256, 2) void gpp_exec_f64(ExecLaunch e) {
     const CGemmArgs& p = groups[g];
     const int tm = tasks[idx].tm, tn = tasks[idx].tn;
     if (p.op == 0) {
-      gemm_tile<2, 64, 64, 0, 16, 2, 2>(p, tm, tn, p.A, p.B, p.C, (int64_t)0, smem);
+      gemm_tile<2, 64, 64, 0, 16, 2, 2>(p, tm, tn, p.A, p.B, p.C, p.C2, smem);
     } else {
       // copy the M x 128 strip tn of B into C: 64 16-byte vectors per row, 4 rows per pass, 8 passes in flight
       const int c = tn * 128 + ((tid & 63) << 1), r4 = tid >> 6;
@@ -645,6 +647,122 @@ __global__ __launch_bounds__(256, 2) void gpp_exec_f64(ExecLaunch e) {
     if (e.trace) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (tid == 0) e.trace[3 * (size_t)(first + idx) + 2] = wall_clock64();
+    }
+  }
+}
+
+// ---- DAG executor (round 5; see gpp_internal.h and gpp_dag.hip) ------------------------------------------------------------------
+typedef const DagTask GPP_AS4 CDagTask;
+// Plans are independent of the operands' addresses (GemmArgs::buf + byte offsets); this one-wave-per-64-groups kernel writes the
+// absolute copy the executor reads, stream-ordered in front of it (the tile body then finds its operands as re-loadable scalars of a
+// constant-address-space struct, exactly as in gpp_exec_f64 — computing them per task cost 26 spilled VGPRs).
+__global__ __launch_bounds__(64) void gpp_dag_bind(const GemmArgs* rel, GemmArgs* abs, int n, DagBases bases) {
+  const int g = blockIdx.x * 64 + threadIdx.x;
+  if (g >= n) return;
+  GemmArgs a = rel[g];
+  auto base = [&](int b) { return b == 0 ? bases.p[0] : b == 1 ? bases.p[1] : b == 2 ? bases.p[2] : bases.p[3]; };
+  a.A = reinterpret_cast<const double*>(base(a.buf[0]) + reinterpret_cast<uintptr_t>(a.A));
+  a.B = reinterpret_cast<const double*>(base(a.buf[1]) + reinterpret_cast<uintptr_t>(a.B));
+  a.C = reinterpret_cast<double*>(base(a.buf[2]) + reinterpret_cast<uintptr_t>(a.C));
+  a.C2 = a.buf[3] >= 0 ? reinterpret_cast<double*>(base(a.buf[3]) + reinterpret_cast<uintptr_t>(a.C2)) : nullptr;
+  abs[g] = a;
+}
+__global__ __launch_bounds__(256, 2) void gpp_dag_f64(DagLaunch e) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  __shared__ int s_idx, s_ok;
+  const int tid = threadIdx.x;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+  CDagTask* tasks = (CDagTask*)e.tasks;
+  CGemmArgs* groups = (CGemmArgs*)e.groups;
+#pragma clang diagnostic pop
+  for (int done = 0;; ++done) {
+    if (tid == 0) {
+      int idx = -1;
+      const bool stop = (e.max_tasks > 0 && done >= e.max_tasks) || exec_load(e.counters) != 0 ||
+                        (e.quit_id >= 0 && exec_load(e.counters + e.quit_id) >= e.quit_val);
+      if (!stop) {
+        if (e.ticket_limit <= 0) {
+          idx = __hip_atomic_fetch_add(e.counters + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          // a filler launch in front of a panel never takes a task that needs that panel: the launch could not end (gpp_dag.hip)
+          int old = exec_load(e.counters + 1);
+          while (old < e.ticket_limit &&
+                 !__hip_atomic_compare_exchange_strong(e.counters + 1, &old, old + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+          }
+          if (old < e.ticket_limit) idx = old;
+        }
+      }
+      s_idx = idx;
+    }
+    __syncthreads();
+    const int idx = __builtin_amdgcn_readfirstlane(s_idx);
+    __syncthreads();  // (thread 0 rewrites s_idx at the top of the next iteration; the copy tasks have no barrier of their own)
+    if (idx < 0 || idx >= e.ntasks) break;
+    if (e.trace && tid == 0) {
+      e.trace[4 * (size_t)idx] = wall_clock64();
+      e.trace[4 * (size_t)idx + 3] = (unsigned long long)blockIdx.x | ((unsigned long long)(unsigned)e.tag << 32);
+    }
+    const int w0 = tasks[idx].wait_id[0], w1 = tasks[idx].wait_id[1], w2 = tasks[idx].wait_id[2];
+    if (w0 >= 0 || w1 >= 0 || w2 >= 0) {
+      if (tid == 0) {
+        bool ok = exec_poll(e.counters, w0, tasks[idx].wait_val[0], w1, tasks[idx].wait_val[1], e.budget, e.info, GPP_INFO_EXEC_TIMEOUT);
+        if (ok && w2 >= 0) ok = exec_poll(e.counters, w2, tasks[idx].wait_val[2], -1, 0, e.budget, e.info, GPP_INFO_EXEC_TIMEOUT);
+        s_ok = ok ? 1 : 0;
+      }
+      __syncthreads();
+      const int ok = s_ok;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the publishers wrote before their increments is visible from here
+      __syncthreads();
+      if (!ok) break;
+    }
+    if (e.trace && tid == 0) e.trace[4 * (size_t)idx + 1] = wall_clock64();
+    const CGemmArgs& p = groups[tasks[idx].group];
+    const int tm = tasks[idx].tm, tn = tasks[idx].tn;
+    if (p.op == 0) {
+      if (p.etile == 64) gemm_tile<2, 32, 32, 0, 64, 1, 2>(p, tm, tn, p.A, p.B, p.C, p.C2, smem);
+      else gemm_tile<2, 64, 64, 0, 16, 2, 2>(p, tm, tn, p.A, p.B, p.C, p.C2, smem);
+    } else {
+      // copy the M x 128 strip tn of B into C: 64 16-byte vectors per row, 4 rows per pass, 8 passes in flight
+      const int c = tn * 128 + ((tid & 63) << 1), r4 = tid >> 6;
+      if (c < p.N) {
+        const bool pair = c + 1 < p.N;
+        for (int r0 = 0; r0 < p.M; r0 += 32) {
+          v2d v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = r0 + 4 * q + r4;
+            const double* src = p.B + (int64_t)(r < p.M ? r : 0) * p.ldb + c;
+            if (pair) v[q] = *reinterpret_cast<const v2d*>(src);
+            else v[q] = (v2d){*src, 0.0};
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q) {
+            const int r = r0 + 4 * q + r4;
+            if (r < p.M) {
+              double* dst = p.C + (int64_t)r * p.ldc + c;
+              if (pair) *reinterpret_cast<v2d*>(dst) = v[q];
+              else *dst = v[q].x;
+            }
+          }
+        }
+      }
+    }
+    const int i0 = tasks[idx].inc_id[0], i1 = tasks[idx].inc_id[1];
+    if (i0 >= 0 || i1 >= 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left the CU
+      __syncthreads();
+      if (tid == 0) {
+        // (the explicit wait between the write-back and the increments is REQUIRED: see panel_publish in gpp_leaf.hip)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (i0 >= 0) __hip_atomic_fetch_add(e.counters + i0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i1 >= 0) __hip_atomic_fetch_add(e.counters + i1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (e.trace) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (tid == 0) e.trace[4 * (size_t)idx + 2] = wall_clock64();
     }
   }
 }
@@ -746,6 +864,27 @@ hipError_t gpp_launch_exec(hipStream_t s, int nworkers, const ExecLaunch& e) {
     if (dev >= 0 && dev < 64) attr_set[dev] = true;
   }
   hipLaunchKernelGGL(gpp_exec_f64, dim3((unsigned)nworkers), dim3(256), bytes, s, e);
+  return hipGetLastError();
+}
+hipError_t gpp_launch_dag_bind(hipStream_t s, const GemmArgs* rel, GemmArgs* abs, int n, const DagBases& bases) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(gpp_dag_bind, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, rel, abs, n, bases);
+  return hipGetLastError();
+}
+hipError_t gpp_launch_dag(hipStream_t s, int nworkers, const DagLaunch& e) {
+  if (nworkers <= 0) return hipSuccess;
+  constexpr size_t b128 = gemm_lds_bytes(2, 128, 128, 16, 2), b64 = gemm_lds_bytes(2, 64, 64, 64, 1);
+  constexpr size_t bytes = b128 > b64 ? b128 : b64;
+  static std::atomic<bool> attr_set[64];
+  int dev = 0;
+  hipError_t err = hipGetDevice(&dev);
+  if (err != hipSuccess) return err;
+  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+    err = hipFuncSetAttribute(reinterpret_cast<const void*>(gpp_dag_f64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (err != hipSuccess) return err;
+    if (dev >= 0 && dev < 64) attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL(gpp_dag_f64, dim3((unsigned)nworkers), dim3(256), bytes, s, e);
   return hipGetLastError();
 }
 hipError_t gpp_launch_exec_gate(hipStream_t s, int* counters, int id, int target, int32_t* info, long long budget) {

@@ -36,6 +36,9 @@ struct gpp_handle_s {
   int panel_fault;           // GPP_OPT_PANEL_FAULT: the next panel launch only reports the time-out status (tests)
   int panel_timeout_ms;      // GPP_OPT_PANEL_TIMEOUT_MS: budget of a wait inside the panel kernel (100 MHz constant clock)
   struct PotrfExecPlan* exec_plan;  // cached plan of the static-schedule executor (gpp_plan.hip), rebuilt when N changes
+  struct DagPlan* dag_plans[4];     // small LRU of DAG-executor plans (gpp_dag.hip), keyed by (N, nb, leading dimensions, flags)
+  uint64_t dag_clock;
+  int dag_sched;             // GPP_OPT_DAG_SCHED
   int exec_sched;            // GPP_OPT_EXEC_SCHED: run the throughput-bound steps of the look-ahead as one statically scheduled launch
 };
 constexpr int GPP_PANEL_RING = 8;
@@ -130,6 +133,9 @@ struct GemmArgs {
   int compact_bc;          // c_lower == 1 with own_mod > 1: B and C hold only the owned column blocks, side by side (the q-th owned
                            // block in columns [q own_bt 128, (q+1) own_bt 128) of their buffers): the sharded back-substitution
                            // with N x (N / ranks) storage per rank
+  int etile;               // DAG executor only: work-group tile of this group's tasks — 0 / 128 the big tile, 64 the small one
+  int buf[4];              // DAG executor only (gpp_dag_f64): A, B, C, C2 hold BYTE OFFSETS into the launch's operand bases
+                           // buf[0..3] (C2 unused: buf[3] < 0), so that a plan does not depend on the operands' addresses
   int pad_ok;              // TN variant, big tile: the operands may be READ up to the next multiple of 128 past M / N along their rows
                            // (the bytes belong to the same allocation: never set for an operand's last row of a buffer) — what
                            // is read there only reaches output entries that are not stored, and a ragged edge tile then runs the
@@ -207,6 +213,79 @@ hipError_t gpp_plan_upload(PotrfExecPlan* P);
 void gpp_plan_free(PotrfExecPlan* P);
 // counter ids of block b (gpp_plan.hip): 1 + 8 b + {0: panel done, 1: updates inside diagonal block b done (gate of its panel)}
 inline int gpp_plan_counter(int b, int which) { return 1 + 8 * b + which; }
+
+// ---- DAG executor (gpp_gemm.hip: gpp_dag_f64; planned by gpp_dag.hip) -----------------------------------------------------------
+// Round 5.  ONE list of tile tasks in a topological order of the whole task graph (factorisation, and optionally the triangular
+// inverse built right-looking beside it); work-groups take the next task with an atomic ticket, wait for its (up to three)
+// counters, run the tile and raise its (up to two) counters.  Only RUNNING work-groups hold tasks and each holds one, so the
+// earliest unfinished task is always held by a running work-group whose predecessors are complete: progress needs NO co-residency
+// of the grid (the static lists of gpp_exec_f64 do), faster work-groups simply take more tasks (the older / younger wave asymmetry
+// balances itself), and the same list serves any number of workers — including short filler launches on the panel's CUs.
+// counters[0] is the abort word, counters[1] the ticket.
+struct DagTask {           // 48 bytes
+  int32_t group;           // index into the groups array
+  int16_t tm, tn;          // tile of that group's product (in units of the group's etile), or the strip of a copy
+  int32_t wait_id[3];      // counters to wait for (-1: none) ...
+  int32_t wait_val[3];     // ... until they are >= these values
+  int32_t inc_id[2];       // counters to increment once the task's stores are visible (-1: none)
+  int32_t kind;            // semantic class (gpp_dag.hip: DK_*), for traces and the host-side checker
+};
+struct DagLaunch {
+  const GemmArgs* groups;  // the ABSOLUTE copy of the plan's groups (gpp_launch_dag_bind)
+  const DagTask* tasks;
+  int ntasks;
+  int* counters;
+  int32_t* info;
+  long long budget;        // ticks of the 100 MHz constant clock a single wait may take
+  int max_tasks;           // > 0: a work-group leaves after this many tasks (filler launches between two panels)
+  int quit_id, quit_val;   // quit_id >= 0: a work-group takes no further task once counters[quit_id] >= quit_val
+  int ticket_limit;        // > 0: a work-group takes no ticket >= this (filler launches: the first task that needs the NEXT panel)
+  unsigned long long* trace;  // debug: 4 words per task — ticket taken, waits over, done (100 MHz clock), work-group | launch tag << 32
+  int tag;
+};
+hipError_t gpp_launch_dag(hipStream_t s, int nworkers, const DagLaunch& e);
+struct DagBases { char* p[4]; };  // operand bases the groups' byte offsets refer to: A, Linv, T, Kinv
+hipError_t gpp_launch_dag_bind(hipStream_t s, const GemmArgs* rel, GemmArgs* abs, int n, const DagBases& bases);
+
+enum { DK_S = 0, DK_U = 1, DK_CP = 2, DK_XB = 3, DK_XA = 4, DK_SH = 5, DK_UD = 6, DK_LU = 7, DK_NKINDS = 8 };
+struct DagTuning {
+  double t0_big, tc_big;      // us of a 128 x 128 tile task: t0 + tc * (K / 16)
+  double t0_64, tc_64;        // 64 x 64 tile
+  double t0_32, tc_32;        // 32 x 32 tile
+  double t_copy;              // strip copy
+  double t_panel0, t_panel_leaf;  // panel launch: t_panel0 + t_panel_leaf * leaves, plus
+  double t_gate;              // gate + signal hand-offs around it
+  int chain_tile;             // tile of the chain's tasks (head solve, next diagonal block's update): 128 or 64
+  int workers;                // workers the order is simulated for
+  int fill;                   // filler work-groups per launch (0: no filler launches)
+};
+struct DagPlan {
+  int64_t N = 0, nb = 0, ld = 0, ldi = 0, ldt = 0, ldk = 0;
+  int flags = 0;                       // DAG_INV: also the inverse (right-looking), DAG_LAUUM: and Kinv
+  int B = 0, nt = 0;
+  std::vector<int> tb;                 // first tile of block b (tb[B] = nt)
+  std::vector<GemmArgs> groups;
+  std::vector<DagTask> tasks;          // in ticket order
+  struct Op { int kind, arg, n, lim; };  // panel stream: 0 gate(b) 1 panel(b) 2 signal(b) 3 filler launch (arg = tasks per work-group,
+                                       // n = the block whose gate ends it, lim = first ticket it must not take)
+  std::vector<Op> stream_ops;
+  std::vector<int> gate_target;
+  int ncounters = 0;
+  int c_pd = 0, c_g1d = 0;             // first ids of the panel-done / gate counters (index by block)
+  double sim_ms = 0, sim_busy = 0;     // the planner's own estimate (makespan, mean worker occupancy)
+  GemmArgs* d_groups = nullptr;        // as planned: operands as (buffer, byte offset)
+  GemmArgs* d_groups_abs = nullptr;    // what the executor reads: rewritten by gpp_dag_bind in front of every launch
+  DagTask* d_tasks = nullptr;
+  int* d_counters = nullptr;
+  unsigned long long* d_trace = nullptr;
+  hipEvent_t last_use = nullptr;       // recorded behind the launches that read the device copies
+  uint64_t stamp = 0;                  // LRU
+};
+enum { DAG_INV = 1, DAG_LAUUM = 2 };
+DagPlan* gpp_dag_plan(int64_t N, int64_t nb, int64_t ld, int64_t ldi, int64_t ldt, int64_t ldk, int flags, const DagTuning& tune);
+DagTuning gpp_dag_default_tuning();
+hipError_t gpp_dag_upload(DagPlan* P);
+void gpp_dag_free(DagPlan* P);
 
 // ---- 128x128 diagonal leaf: Cholesky + triangular inverse in LDS (gpp_leaf.hip) ---------------
 // A holds the UPPER factor (A = U^T U, i.e. L = U^T read/written with swapped indices); the n x n diagonal block of
