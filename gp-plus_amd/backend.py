@@ -53,7 +53,7 @@ def _need(t: torch.Tensor, dtype, name: str) -> None:
 #: status word of a factorisation whose cooperative panel kernel gave up waiting for one of its own work-groups (gpp_leaf.hip:
 #: a wait is abandoned after ~1 s instead of hanging the GPU).  NOT "matrix not positive definite": adding jitter cannot help.
 INFO_PANEL_TIMEOUT = 1 << 30
-#: the same for a wait of one of the EXECUTORS' work-groups (gpp_exec_f64 / gpp_dag_f64 and their gate kernels): bit 29 on top
+#: the same for a wait of one of the DAG executor's work-groups (gpp_dag_f64 and its gate kernels): bit 29 on top
 INFO_EXEC_TIMEOUT = (1 << 30) | (1 << 29)
 
 
@@ -63,14 +63,14 @@ def check_status(info: int) -> None:
         what = "an executor launch" if info & (1 << 29) else "the cooperative panel kernel"
         raise GppError(f"gpp_potrf: {what} timed out waiting for one of its work-groups (another kernel holding the stream's CUs "
                        "for seconds, or a caller-supplied CU-masked stream with fewer CUs than the launch assumed); "
-                       "GPP_COOP_PANEL=0 selects the leaf-step factorisation, GPP_EXEC_SCHED=0 GPP_DAG_SCHED=0 the launch-per-product one")
+                       "GPP_COOP_PANEL=0 selects the leaf-step factorisation, GPP_DAG_SCHED=0 the launch-per-product one")
 
 
 def panel_timed_out(ctx: "GppContext", info: int) -> bool:
     """True when ``info`` is a time-out status the context can answer by switching a cooperative path off; the caller then factors
-    again.  An EXECUTOR's time-out (bit 29: its work-groups wait for the panel stream's launches and, for gpp_exec_f64, for each
-    other — under co-tenancy or serialised dispatch they give up first) switches only the executors off: the factorisation falls
-    back to launch-per-product with the cooperative panel, which needs 32 resident work-groups instead of 448.  The PANEL's own
+    again.  The DAG EXECUTOR's time-out (bit 29: its work-groups wait for the panel stream's launches — under co-tenancy or serialised
+    dispatch they give up first) switches only the executor off: the factorisation falls back to launch-per-product with the
+    cooperative panel, which needs 32 resident work-groups.  The PANEL's own
     time-out switches the panel off (and with it everything built on it): leaf-step launches need no co-residency at all."""
     if info < INFO_PANEL_TIMEOUT:
         return False
@@ -78,11 +78,10 @@ def panel_timed_out(ctx: "GppContext", info: int) -> bool:
 
     ms = info & 0xFFFFF
     if info & (1 << 29):
-        if not (ctx.exec_sched or ctx.dag_sched):
-            check_status(info)  # cannot happen without an executor: report it
+        if not ctx.dag_sched:
+            check_status(info)  # cannot happen without the executor: report it
         warnings.warn(f"libgpp_hip: an executor launch timed out after {ms} ms (another tenant of this GPU held part of its CUs, or "
                       "dispatches are serialised); this context now factors with one launch per product", RuntimeWarning)
-        ctx.set_option(OPT_EXEC_SCHED, 0)
         ctx.set_option(OPT_DAG_SCHED, 0)
         return True
     if not ctx.coop_panel:
@@ -135,11 +134,9 @@ class GppContext:
             check(self.lib.gpp_create(ctypes.byref(h), self.index), "gpp_create")
         self.h = h
         self.coop_panel = os.environ.get("GPP_COOP_PANEL", "1") != "0"  # mirrors the handle's GPP_OPT_COOP_PANEL
-        self.exec_sched = os.environ.get("GPP_EXEC_SCHED", "1") != "0"
         self.dag_sched = os.environ.get("GPP_DAG_SCHED", "1") != "0"
         # kernels that wait for each other across launches cannot run when dispatches are serialised: they would only time out
         if any(os.environ.get(v, "0") not in ("", "0") for v in ("HIP_LAUNCH_BLOCKING", "AMD_SERIALIZE_KERNEL", "CUDA_LAUNCH_BLOCKING")):
-            self.set_option(OPT_EXEC_SCHED, 0)
             self.set_option(OPT_DAG_SCHED, 0)
         self._ws: Optional[torch.Tensor] = None
 
@@ -152,9 +149,7 @@ class GppContext:
         check(self.lib.gpp_set_option(self.h, int(option), int(value)), "gpp_set_option")
         if option == OPT_COOP_PANEL:
             self.coop_panel = bool(value)
-        elif option == OPT_EXEC_SCHED:
-            self.exec_sched = bool(value)
-        elif option == OPT_DAG_SCHED:
+        elif option in (OPT_DAG_SCHED, OPT_EXEC_SCHED):
             self.dag_sched = bool(value)
 
     @_on_own_device

@@ -170,8 +170,15 @@ hipError_t launch_panel(gpp_handle_s* h, const Ctx& c, int64_t o, int64_t n, int
     h->panel_fault = 0;
     return gpp_launch_fill_i32(c.s, c.info, 1, GPP_INFO_PANEL_TIMEOUT);
   }
-  int* fl = reinterpret_cast<int*>(h->panel_flags + (size_t)(h->panel_next % GPP_PANEL_RING) * gpp_panel_flag_bytes());
-  ++h->panel_next;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(c.s, &cap) != hipSuccess) {
+    (void)hipGetLastError();
+    cap = hipStreamCaptureStatusNone;
+  }
+  int slot;
+  if (cap == hipStreamCaptureStatusActive) slot = GPP_PANEL_RING + (h->cap_next++ % GPP_PANEL_CAP_RING);  // (see gpp_internal.h)
+  else slot = h->panel_next++ % GPP_PANEL_RING;
+  int* fl = reinterpret_cast<int*>(h->panel_flags + (size_t)slot * gpp_panel_flag_bytes());
   return gpp_launch_panel(c.s, c.A + o * c.ld + o, c.ld, c.Li + o * c.ldi + o, c.ldi, (int)n, c.info, (int)o, fl, max_wgs,
                           h->panel_timeout_ms);
 }
@@ -350,92 +357,11 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
   cu.s = h->upd_stream;
   const char* env_nb = getenv("GPP_LOOKAHEAD_NB");  // experiment knob: "big,small,threshold"
   static const int64_t border_max_x = getenv("GPP_BORDER_MAX") ? atol(getenv("GPP_BORDER_MAX")) : BORDER_MAX_N;
-  // ---- statically scheduled steps (round 4) -----------------------------------------------------------------------------------
-  // While a step's trailing update is longer than its chain (diagonal block -> head solve -> next diagonal block's update), a
-  // launch per product loses to wave quantisation (2-4 waves of 280-us tiles per launch from the middle on), to the gaps between
-  // dependent launches and to masked and unmasked launches competing for CUs (profiles/r03_timeline_potrf.txt: steps 0-12 take
-  // 46.8 ms for 40.0 ms of work at the rate of a long launch).  Those steps run as ONE persistent launch on the throughput
-  // CUs whose work-groups walk host-precomputed tile lists gated by counters (gpp_plan.hip), the diagonal blocks on the panel's CUs
-  // behind one-wave gate kernels, and between two of them a short filler launch gives the panel's CUs a share of the update.
-  // The chain-bound tail (fewer than GPP_EXEC_MIN_REM rows left) continues below with launches, whose chain is shorter.
-  PotrfExecPlan* plan = nullptr;
-  {
-    static const bool exec_env = !(getenv("GPP_EXEC_SCHED") && atoi(getenv("GPP_EXEC_SCHED")) == 0);                 // knobs
-    static const int64_t exec_min_rem = getenv("GPP_EXEC_MIN_REM") ? atol(getenv("GPP_EXEC_MIN_REM")) : 5500;
-    static const int64_t exec_max_n = getenv("GPP_EXEC_MAX_N") ? atol(getenv("GPP_EXEC_MAX_N")) : 40000;  // (N = 60000: 1154 vs 1143 ms — the unmasked bulk of long launches wins there)
-    const int K = (int)((N - exec_min_rem) / NB);
-    if (exec_env && h->exec_sched && h->coop_panel && T && N > border_max_x && N <= exec_max_n && !env_nb && h->cu_split == 1 &&
-        NB % NBLK == 0 && panel_fits(h, NB) && K >= 2) {
-      const int W = 2 * (h->ncu - h->panel_cus), F = 2 * h->panel_cus;
-      PotrfExecPlan* P = h->exec_plan;
-      if (P && (P->N != N || P->nb != NB || P->K != K || P->W != W || P->F != F)) {
-        HIP_TRY(hipDeviceSynchronize());  // (a launch may still be reading the old plan)
-        gpp_plan_free(P);
-        P = h->exec_plan = nullptr;
-      }
-      if (!P) {
-        PotrfExecTuning tune;
-        tune.t_tile = getenv("GPP_EXEC_TTILE") ? atof(getenv("GPP_EXEC_TTILE")) : 275.0;
-        tune.t_block = getenv("GPP_EXEC_TBLOCK") ? atof(getenv("GPP_EXEC_TBLOCK")) : 600.0;
-        tune.solve_pos = getenv("GPP_EXEC_PS") ? atoi(getenv("GPP_EXEC_PS")) : 4;
-        tune.solve_pos_later = getenv("GPP_EXEC_PS2") ? atoi(getenv("GPP_EXEC_PS2")) : 0;
-        // (sweep on one box, potrf at N = 20 000 / 15 000: 0.4 / 0.4 / 800 us 49.7 / 24.15 ms; 0.15 / 0.5 / 600 us 49.33 / 23.68 —
-        //  the tiles inside the next diagonal block early, the others past the middle of the phase; profiles/r04_exec_schedule.txt)
-        tune.la_frac = getenv("GPP_EXEC_LAF") ? atof(getenv("GPP_EXEC_LAF")) : 0.15;
-        tune.la_frac2 = getenv("GPP_EXEC_LAF2") ? atof(getenv("GPP_EXEC_LAF2")) : std::max(0.5, tune.la_frac);
-        tune.fill = getenv("GPP_EXEC_FILL") ? atoi(getenv("GPP_EXEC_FILL")) : 1;
-        P = h->exec_plan = gpp_plan_potrf_exec(N, NB, K, W, F, tune);
-      }
-      if (P) {
-        bool ok = true;
-        if (P->A != cm.A || P->ld != cm.ld || P->Li != cm.Li || P->ldi != cm.ldi || P->T != T || P->ldt != ldt || !P->d_tasks) {
-          if (P->d_tasks) HIP_TRY(hipDeviceSynchronize());
-          gpp_plan_bind(P, cm.A, cm.ld, cm.Li, cm.ldi, T, ldt);
-          if (gpp_plan_upload(P) != hipSuccess) {
-            // no memory for the plan's device copy (a few MB): not an error of the factorisation — this handle keeps to launches
-            (void)hipGetLastError();
-            gpp_plan_free(P);
-            h->exec_plan = nullptr;
-            h->exec_sched = 0;
-            ok = false;
-          }
-        }
-        if (ok) {
-          plan = P;
-          HIP_TRY(gpp_launch_fill_i32(cm.s, P->d_counters, P->ncounters, 0));
-        }
-      }
-    }
-  }
   hipEvent_t ev = next_event(h);
   HIP_TRY(hipEventRecord(ev, cm.s));  // inputs (kernel build) are ready
   HIP_TRY(hipStreamWaitEvent(cp.s, ev, 0));
   HIP_TRY(hipStreamWaitEvent(cu.s, ev, 0));
-  int64_t o_begin = 0;
-  if (plan) {
-    const long long budget = (long long)(h->panel_timeout_ms > 0 ? h->panel_timeout_ms : 500) * 100000 * 4;
-    ExecLaunch el{plan->d_groups, plan->d_tasks, plan->d_offsets, plan->d_counters, cm.info, budget, 0, plan->d_trace};
-    HIP_TRY(gpp_launch_exec(cu.s, plan->W, el));
-    for (const PotrfExecPlan::Op& op : plan->stream_ops) {
-      if (op.kind == 0) {
-        HIP_TRY(gpp_launch_exec_gate(cp.s, plan->d_counters, gpp_plan_counter(op.arg, 1), plan->gate_target[op.arg], cm.info, budget));
-      } else if (op.kind == 1) {
-        HIP_TRY(launch_panel(h, cp, (int64_t)op.arg * NB, NB, h->panel_cus));
-        if (h->inv_nblocks < 128) {
-          h->inv_o[h->inv_nblocks] = (int64_t)op.arg * NB;
-          h->inv_n[h->inv_nblocks] = NB;
-          ++h->inv_nblocks;
-        }
-      } else if (op.kind == 2) {
-        HIP_TRY(gpp_launch_exec_signal(cp.s, plan->d_counters, gpp_plan_counter(op.arg, 0)));
-      } else {
-        ExecLaunch fl = el;
-        fl.worker_base = plan->W + op.arg * std::max(plan->F, 1);
-        HIP_TRY(gpp_launch_exec(cp.s, plan->fill_workers[op.arg], fl));
-      }
-    }
-    o_begin = (int64_t)plan->K * NB;  // the launches below continue with block row K, whose diagonal block is already enqueued
-  }
+  const int64_t o_begin = 0;
   // Round 1 measured 1024 above / 512 below 6144 remaining rows best (70.6 vs 71.7 ms for 1024 flat at N = 20000); with the panel
   // kernel a 1024-row block costs 0.58 ms where two 512-row blocks cost 2 x (0.29 + 0.07 ms hand-off), and 1024 flat wins (means
   // of 3: potrf 15.50 -> 15.22 ms at N = 12288, 25.27 -> 24.87 at 15000, 51.84 -> 51.46 at 20000, 155.3 -> 155.3 at 30000).
@@ -488,9 +414,7 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
     nb = std::min(want, N - o);
     const int64_t rem = N - o - nb;
     const bool coop = T != nullptr && panel_fits(h, nb);
-    if (plan && o == o_begin) {
-      // this diagonal block was enqueued with the statically scheduled steps; the throughput stream continues behind their launch
-    } else if (coop) {
+    if (coop) {
       // factor + complete inverse of the diagonal block in ONE cooperative launch on the panel's CUs
       HIP_TRY(launch_panel(h, cp, o, nb, h->cu_split == 1 ? h->panel_cus : std::min(64, h->ncu)));
       if (h->inv_nblocks < 128) {
@@ -836,42 +760,6 @@ int gpp_debug_panel_flags(gpp_handle_t h, int* out, int nints, int* next_slot) {
 }
 #endif
 
-// Debug access to the plan of the statically scheduled steps and to its per-task time stamps (tools/exec_trace.py): not part of gpp.h.
-// info6 = {tasks, offsets, K, W, F, counters}; fetch copies the task array (32 B each), the offsets (int32) and — when tracing is
-// on — 3 stamps of the 100 MHz clock per task into host buffers (null: skip).
-int gpp_debug_exec_info(gpp_handle_t h, int64_t* info6) {
-  if (!h || !h->exec_plan) return -1;
-  const PotrfExecPlan* P = h->exec_plan;
-  info6[0] = (int64_t)P->tasks.size(); info6[1] = (int64_t)P->offsets.size(); info6[2] = P->K; info6[3] = P->W; info6[4] = P->F;
-  info6[5] = P->ncounters;
-  return 0;
-}
-int gpp_debug_exec_trace(gpp_handle_t h, int on) {
-  if (!h || !h->exec_plan) return -1;
-  PotrfExecPlan* P = h->exec_plan;
-  if (hipDeviceSynchronize() != hipSuccess) return 1;
-  if (on && !P->d_trace) {
-    if (hipMalloc(&P->d_trace, 3 * P->tasks.size() * sizeof(unsigned long long)) != hipSuccess) return 2;
-    (void)hipMemset(P->d_trace, 0, 3 * P->tasks.size() * sizeof(unsigned long long));
-  } else if (!on && P->d_trace) {
-    (void)hipFree(P->d_trace);
-    P->d_trace = nullptr;
-  }
-  return 0;
-}
-int gpp_debug_exec_fetch(gpp_handle_t h, void* tasks, void* offsets, void* trace) {
-  if (!h || !h->exec_plan) return -1;
-  const PotrfExecPlan* P = h->exec_plan;
-  if (hipDeviceSynchronize() != hipSuccess) return 1;
-  if (tasks) memcpy(tasks, P->tasks.data(), P->tasks.size() * sizeof(ExecTask));
-  if (offsets) memcpy(offsets, P->offsets.data(), P->offsets.size() * sizeof(int32_t));
-  if (trace) {
-    if (!P->d_trace) return 2;
-    if (hipMemcpy(trace, P->d_trace, 3 * P->tasks.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return 3;
-  }
-  return 0;
-}
-
 // Debug access to the DAG executor's most recently used plan (tools/dag_trace.py): not part of gpp.h.
 static DagPlan* dag_mru(gpp_handle_t h) {
   DagPlan* P = nullptr;
@@ -912,33 +800,6 @@ int gpp_debug_dag_fetch(gpp_handle_t h, void* tasks, void* trace) {
   return 0;
 }
 
-// Debug / profiling: ONE trailing update  A[nb:, nb:] (upper) -= T[0:nb, nb:]^T T[0:nb, nb:]  run by the executor's kernel alone
-// (a wait-free task list on the throughput stream's 2 work-groups per CU; reps launches back to back, the caller's stream waits).
-// No gate, no panel, no counter: the launch can be profiled under a counter collection that serialises dispatches
-// (tools/exec_update_probe.py).  Not part of gpp.h.
-int gpp_debug_exec_update(gpp_handle_t h, double* A, int64_t ld, double* T, int64_t ldt, int64_t N, int64_t nb, int reps) {
-  if (!h || !A || !T) return -1;
-  if (ensure_streams(h) != hipSuccess) return 1;
-  if (h->cu_split != 1) return 2;
-  const int W = 2 * (h->ncu - h->panel_cus);
-  PotrfExecPlan* P = gpp_plan_single_update(N, nb, W);
-  if (!P) return 3;
-  gpp_plan_bind(P, A, ld, A, ld, T, ldt);  // (the solve group is never used: any valid pointer)
-  int rc_ = 0;
-  if (gpp_plan_upload(P) != hipSuccess) rc_ = 4;
-  hipEvent_t ev = next_event(h);
-  if (!rc_ && (hipEventRecord(ev, h->stream) != hipSuccess || hipStreamWaitEvent(h->upd_stream, ev, 0) != hipSuccess)) rc_ = 5;
-  if (!rc_ && gpp_launch_fill_i32(h->upd_stream, P->d_counters, P->ncounters, 0) != hipSuccess) rc_ = 6;
-  ExecLaunch el{P->d_groups, P->d_tasks, P->d_offsets, P->d_counters, P->d_counters + 1, 200000000LL, 0, nullptr};
-  for (int r = 0; r < reps && !rc_; ++r)
-    if (gpp_launch_exec(h->upd_stream, W, el) != hipSuccess) rc_ = 7;
-  hipEvent_t done = next_event(h);
-  if (!rc_ && (hipEventRecord(done, h->upd_stream) != hipSuccess || hipStreamWaitEvent(h->stream, done, 0) != hipSuccess)) rc_ = 8;
-  (void)hipStreamSynchronize(h->upd_stream);
-  gpp_plan_free(P);
-  return rc_;
-}
-
 int gpp_create(gpp_handle_t* out, int device) {
   if (!out) return -1;
   int ndev = 0;
@@ -968,8 +829,6 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->coop_panel = panel_enabled() ? 1 : 0;
   h->panel_fault = 0;
   h->panel_timeout_ms = 500;
-  h->exec_plan = nullptr;
-  h->exec_sched = 1;
   for (int i = 0; i < 4; ++i) h->dag_plans[i] = nullptr;
   h->dag_clock = 0;
   h->dag_sched = 1;
@@ -979,10 +838,13 @@ int gpp_create(gpp_handle_t* out, int device) {
     h->ncu = 0;
   }
   // (allocated here, not lazily: a first use inside a stream capture could not allocate)
-  if (hipMalloc(reinterpret_cast<void**>(&h->panel_flags), GPP_PANEL_RING * gpp_panel_flag_bytes()) != hipSuccess ||
-      hipMemset(h->panel_flags, 0, GPP_PANEL_RING * gpp_panel_flag_bytes()) != hipSuccess) {
+  h->cap_next = 0;
+  h->handoff = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&h->panel_flags), (GPP_PANEL_RING + GPP_PANEL_CAP_RING) * gpp_panel_flag_bytes()) != hipSuccess ||
+      hipMemset(h->panel_flags, 0, (GPP_PANEL_RING + GPP_PANEL_CAP_RING) * gpp_panel_flag_bytes()) != hipSuccess) {
     (void)hipGetLastError();
     if (h->panel_flags) (void)hipFree(h->panel_flags);
+  if (h->handoff) (void)hipEventDestroy(h->handoff);
     h->panel_flags = nullptr;  // the leaf-step chain is used instead
   }
   *out = h;
@@ -997,7 +859,6 @@ int gpp_destroy(gpp_handle_t h) {
   if (h->full_stream) (void)hipStreamDestroy(h->full_stream);
   for (int i = 0; i < h->n_events; ++i) (void)hipEventDestroy(h->events[i]);
   if (h->panel_flags) (void)hipFree(h->panel_flags);
-  if (h->exec_plan) gpp_plan_free(h->exec_plan);
   for (int i = 0; i < 4; ++i)
     if (h->dag_plans[i]) gpp_dag_free(h->dag_plans[i]);
   delete h;
@@ -1006,7 +867,27 @@ int gpp_destroy(gpp_handle_t h) {
 
 int gpp_set_stream(gpp_handle_t h, void* stream) {
   if (!h) return -1;
-  h->stream = reinterpret_cast<hipStream_t>(stream);
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  if (s != h->stream) {
+    // A handle works on ONE stream at a time (its scratch workspace, the panel flag ring and the executor's counters are shared by
+    // consecutive calls).  Moving it to another stream therefore orders the new stream behind everything enqueued on the old one —
+    // enforced here, not assumed.  (Not while either stream is capturing: a capture may not depend on work outside it, and the
+    // caller of a capture synchronises around it anyway.)
+    hipStreamCaptureStatus a = hipStreamCaptureStatusNone, b = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(h->stream, &a) != hipSuccess || hipStreamIsCapturing(s, &b) != hipSuccess) {
+      (void)hipGetLastError();
+      a = b = hipStreamCaptureStatusActive;  // unknown: leave the streams alone
+    }
+    // (nor for the handle's own CU-masked streams, which a host-side driver that overlaps its own launches — the sharded
+    //  evaluation — obtains through gpp_internal_stream and orders with its own events)
+    auto internal = [&](hipStream_t q) { return q && (q == h->panel_stream || q == h->upd_stream || q == h->fill_stream || q == h->full_stream); };
+    if (a == hipStreamCaptureStatusNone && b == hipStreamCaptureStatusNone && !internal(s) && !internal(h->stream)) {
+      if (!h->handoff) GPP_TRY(hipEventCreateWithFlags(&h->handoff, hipEventDisableTiming));
+      GPP_TRY(hipEventRecord(h->handoff, h->stream));
+      GPP_TRY(hipStreamWaitEvent(s, h->handoff, 0));
+    }
+    h->stream = s;
+  }
   return 0;
 }
 
@@ -1014,8 +895,7 @@ int gpp_set_option(gpp_handle_t h, int option, int value) {
   if (!h) return -1;
   if (option == GPP_OPT_COOP_PANEL) h->coop_panel = value ? 1 : 0;
   else if (option == GPP_OPT_PANEL_FAULT) h->panel_fault = value ? 1 : 0;
-  else if (option == GPP_OPT_EXEC_SCHED) h->exec_sched = value ? 1 : 0;
-  else if (option == GPP_OPT_DAG_SCHED) h->dag_sched = value ? 1 : 0;
+  else if (option == GPP_OPT_DAG_SCHED || option == GPP_OPT_EXEC_SCHED) h->dag_sched = value ? 1 : 0;
   else if (option == GPP_OPT_PANEL_TIMEOUT_MS) {
     if (value < 1 || value > 60000) return -3;
     h->panel_timeout_ms = value;

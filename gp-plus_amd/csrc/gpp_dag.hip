@@ -682,6 +682,7 @@ extern "C" int gpp_debug_dag_check(int64_t N, int64_t nb, int flags, int chain_t
     gi[g] = {kind, k};
   }
   int mutated = -1, lazy_counter = -1;
+  long mut_task = -1;
   const int mutate_in = mutate;
   if (mutate > 0) {
     int seen = 0;
@@ -697,6 +698,7 @@ extern "C" int gpp_debug_dag_check(int64_t N, int64_t nb, int flags, int chain_t
           t.wait_id[q] = -1;
           mutate = 0;
           lazy_counter = c;
+          mut_task = (long)(&t - P->tasks.data());
         }
   }
   // With a wait removed the adversary is TARGETED: the tasks (and the panel-stream signal) that raise the counter the removed wait
@@ -739,6 +741,8 @@ extern "C" int gpp_debug_dag_check(int64_t N, int64_t nb, int flags, int chain_t
   auto try_task = [&](const DagTask& t) -> bool {
     for (int q = 0; q < 3; ++q)
       if (t.wait_id[q] >= 0 && counters[t.wait_id[q]] < t.wait_val[q]) return false;
+    if (getenv("GPP_DAG_CHECK_VERBOSE") && lazy_counter >= 0 && (&t - P->tasks.data()) == mut_task)
+      fprintf(stderr, "mutated task runs: lazy counter %d = %d, tasks run so far %ld\n", lazy_counter, counters[lazy_counter], (long)ran);
     const GInfo g = gi[t.group];
     const GemmArgs& a = P->groups[t.group];
     const int et = a.etile ? a.etile : 128, k = g.k;

@@ -184,7 +184,7 @@ __device__ __forceinline__ void load_fast(const double* __restrict__ ubase, cons
 // WR = rows of waves in the work-group: 2 (256 threads, 2 x 2 waves: every instantiation of the evaluation) or 4 (512 threads, 4 x 2
 // waves, a 256 x 128 tile on ONE work-group per CU: the experiment of DESIGN.md section 3.5 — 25 % fewer operand bytes per flop).
 // One output tile (tm, tn) of the product described by ``p``: the body shared by the launch-per-product kernel (gpp_gemm_f64, p in
-// the kernel arguments) and the static-schedule executor (gpp_exec_f64, p in a device array read through the constant address
+// the kernel arguments) and the DAG executor (gpp_dag_f64, p in a device array read through the constant address
 // space: scalar loads, re-materialisable like kernel arguments).  A, B, C: the batch element's operands,
 // C2: its mirrored output (or null).  Ends with a work-group barrier after the last LDS read, so the caller may stage another tile at once.
 template <int VAR, int WTM, int WTN, int TAG, int BK, int NBUF, int WR, class P>
@@ -533,13 +533,11 @@ hipError_t launch_var(hipStream_t s, int tm, int tn, dim3 grid, const GemmArgs& 
 }
 
 
-// ---- static-schedule executor ---------------------------------------------------------------------------------------------
-// (see gpp_internal.h.)  Task lists and product descriptors are read through the CONSTANT address space: scalar loads the compiler
-// may repeat at will, exactly like kernel arguments — the tile body compiles to the code of the launch-per-product kernel.
+// ---- DAG executor: device side ----------------------------------------------------------------------------------------------
+// (see gpp_internal.h.)  The task list and the product descriptors are read through the CONSTANT address space: scalar loads the
+// compiler may repeat at will, exactly like kernel arguments — the tile body compiles to the code of the launch-per-product kernel.
 #define GPP_AS4 __attribute__((address_space(4)))
 typedef const GemmArgs GPP_AS4 CGemmArgs;
-typedef const ExecTask GPP_AS4 CExecTask;
-typedef const int32_t GPP_AS4 CInt32;
 
 __device__ __forceinline__ int exec_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
@@ -568,94 +566,10 @@ __device__ __forceinline__ bool exec_poll(int* counters, int w0, int v0, int w1,
   }
 }
 
-__global__ __launch_bounds__(256, 2) void gpp_exec_f64(ExecLaunch e) {
-  extern __shared__ __attribute__((aligned(16))) double smem[];
-  __shared__ int s_ok;
-  const int tid = threadIdx.x;
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wold-style-cast"
-  CInt32* offsets = (CInt32*)e.offsets;
-  const int first = offsets[e.worker_base + (int)blockIdx.x];
-  CExecTask* tasks = (CExecTask*)e.tasks + first;
-  CGemmArgs* groups = (CGemmArgs*)e.groups;
-#pragma clang diagnostic pop
-  for (int idx = 0;; ++idx) {
-    const int g = tasks[idx].group;
-    if (g < 0) break;
-    if (e.trace && tid == 0) e.trace[3 * (size_t)(first + idx)] = wall_clock64();
-    const int w0 = tasks[idx].wait_id[0], w1 = tasks[idx].wait_id[1];
-    if (w0 >= 0 || w1 >= 0) {
-      if (tid == 0) s_ok = exec_poll(e.counters, w0, tasks[idx].wait_val[0], w1, tasks[idx].wait_val[1], e.budget, e.info) ? 1 : 0;
-      __syncthreads();
-      const int ok = s_ok;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // what the publishers wrote before their increments is visible from here
-      __syncthreads();
-      if (!ok) break;
-    }
-    if (e.trace && tid == 0) e.trace[3 * (size_t)(first + idx) + 1] = wall_clock64();
-    // The two work-groups of a CU live as long as the launch, and the SIMD's arbiter favours the OLDER wave at equal priority: the
-    // work-group dispatched first ran its K = 1024 tiles in 236 us, its younger partner in 273 (measured, std 2-4 us inside each
-    // half of the grid) — with equal static shares the younger half fell behind by 14 % and every counter waited for it.  Wave
-    // priorities without ties: the younger half of the grid (work-groups b and b + grid/2 share a CU in dispatch order) runs at
-    // priority 1 throughout, the older half alternates between 2 and 0 from task to task — whatever the phase between the two, each
-    // is the favoured one half of the time.  (Both halves toggling 1 / 0 leaves ties half of the time, which the older wins: 246 / 269.)
-    if ((unsigned)blockIdx.x >= (gridDim.x >> 1)) __builtin_amdgcn_s_setprio(1);
-    else if (idx & 1) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(0);
-    const CGemmArgs& p = groups[g];
-    const int tm = tasks[idx].tm, tn = tasks[idx].tn;
-    if (p.op == 0) {
-      gemm_tile<2, 64, 64, 0, 16, 2, 2>(p, tm, tn, p.A, p.B, p.C, p.C2, smem);
-    } else {
-      // copy the M x 128 strip tn of B into C: 64 16-byte vectors per row, 4 rows per pass, 8 passes in flight
-      const int c = tn * 128 + ((tid & 63) << 1), r4 = tid >> 6;
-      if (c < p.N) {
-        const bool pair = c + 1 < p.N;
-        for (int r0 = 0; r0 < p.M; r0 += 32) {
-          v2d v[8];
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int r = r0 + 4 * q + r4;
-            const double* src = p.B + (int64_t)(r < p.M ? r : 0) * p.ldb + c;
-            if (pair) v[q] = *reinterpret_cast<const v2d*>(src);
-            else v[q] = (v2d){*src, 0.0};
-          }
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int r = r0 + 4 * q + r4;
-            if (r < p.M) {
-              double* dst = p.C + (int64_t)r * p.ldc + c;
-              if (pair) *reinterpret_cast<v2d*>(dst) = v[q];
-              else *dst = v[q].x;
-            }
-          }
-        }
-      }
-    }
-    const int i0 = tasks[idx].inc_id[0], i1 = tasks[idx].inc_id[1];
-    if (i0 >= 0 || i1 >= 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have left the CU
-      __syncthreads();
-      if (tid == 0) {
-        // (the explicit wait between the write-back and the increments is REQUIRED: see panel_publish in gpp_leaf.hip)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (i0 >= 0) __hip_atomic_fetch_add(e.counters + i0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (i1 >= 0) __hip_atomic_fetch_add(e.counters + i1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    if (e.trace) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (tid == 0) e.trace[3 * (size_t)(first + idx) + 2] = wall_clock64();
-    }
-  }
-}
-
-// ---- DAG executor (round 5; see gpp_internal.h and gpp_dag.hip) ------------------------------------------------------------------
 typedef const DagTask GPP_AS4 CDagTask;
 // Plans are independent of the operands' addresses (GemmArgs::buf + byte offsets); this one-wave-per-64-groups kernel writes the
 // absolute copy the executor reads, stream-ordered in front of it (the tile body then finds its operands as re-loadable scalars of a
-// constant-address-space struct, exactly as in gpp_exec_f64 — computing them per task cost 26 spilled VGPRs).
+// constant-address-space struct, as kernel arguments would be — computing them per task cost spilled VGPRs).
 __global__ __launch_bounds__(64) void gpp_dag_bind(const GemmArgs* rel, GemmArgs* abs, int n, DagBases bases) {
   const int g = blockIdx.x * 64 + threadIdx.x;
   if (g >= n) return;
@@ -851,21 +765,6 @@ hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a_in, int
   }
 }
 
-hipError_t gpp_launch_exec(hipStream_t s, int nworkers, const ExecLaunch& e) {
-  if (nworkers <= 0) return hipSuccess;
-  constexpr size_t bytes = gemm_lds_bytes(2, 128, 128, 16, 2);
-  static std::atomic<bool> attr_set[64];
-  int dev = 0;
-  hipError_t err = hipGetDevice(&dev);
-  if (err != hipSuccess) return err;
-  if (dev < 0 || dev >= 64 || !attr_set[dev]) {
-    err = hipFuncSetAttribute(reinterpret_cast<const void*>(gpp_exec_f64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (err != hipSuccess) return err;
-    if (dev >= 0 && dev < 64) attr_set[dev] = true;
-  }
-  hipLaunchKernelGGL(gpp_exec_f64, dim3((unsigned)nworkers), dim3(256), bytes, s, e);
-  return hipGetLastError();
-}
 hipError_t gpp_launch_dag_bind(hipStream_t s, const GemmArgs* rel, GemmArgs* abs, int n, const DagBases& bases) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(gpp_dag_bind, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, rel, abs, n, bases);

@@ -28,20 +28,24 @@ struct gpp_handle_s {
   int64_t inv_o[128], inv_n[128];
   // flag blocks of the cooperative panel launches (gpp_leaf.hip), used round-robin: a launch finds its block zeroed and the last
   // work-group to leave zeroes it again; no more than PANEL_RING panels are ever in flight on one handle, and a handle is used from
-  // ONE stream at a time (a captured graph keeps the slot it was captured with: replay it on the stream the handle works on)
+  // ONE stream at a time (gpp_set_stream orders a new stream behind the old one)
   char* panel_flags;
   int panel_next;
+  // Panel launches recorded into a stream CAPTURE take their block from a second ring of GPP_PANEL_CAP_RING blocks that eager
+  // launches never touch: a captured graph keeps its block for life, so two graphs captured on one handle (up to the ring's size
+  // apart) may be replayed on different streams at the same time, and a replay never meets an eager launch's block.
+  int cap_next;
+  hipEvent_t handoff;        // gpp_set_stream: work enqueued on the previous stream is ordered before work on the new one
   int ncu;                   // CUs of the device: a panel launch never has more work-groups than its stream's CUs hold
   int coop_panel;            // GPP_OPT_COOP_PANEL
   int panel_fault;           // GPP_OPT_PANEL_FAULT: the next panel launch only reports the time-out status (tests)
   int panel_timeout_ms;      // GPP_OPT_PANEL_TIMEOUT_MS: budget of a wait inside the panel kernel (100 MHz constant clock)
-  struct PotrfExecPlan* exec_plan;  // cached plan of the static-schedule executor (gpp_plan.hip), rebuilt when N changes
   struct DagPlan* dag_plans[4];     // small LRU of DAG-executor plans (gpp_dag.hip), keyed by (N, nb, leading dimensions, flags)
   uint64_t dag_clock;
   int dag_sched;             // GPP_OPT_DAG_SCHED
-  int exec_sched;            // GPP_OPT_EXEC_SCHED: run the throughput-bound steps of the look-ahead as one statically scheduled launch
 };
 constexpr int GPP_PANEL_RING = 8;
+constexpr int GPP_PANEL_CAP_RING = 16;
 
 // ---- exp for the covariance kernels --------------------------------------------------------------
 // exp(x) for x <= 0 (every argument of the path is -r^2 or -sqrt(.)): k = rint(x log2 e), r = x - k ln 2 in two parts (Cody-Waite,
@@ -129,7 +133,7 @@ struct GemmArgs {
   int cu_hint;             // CUs of the stream the launch goes to (0: all 256): scales the automatic tile choice
   int row_mod, row_off;    // c_lower == 1 only: produce the tile rows tm with tm % row_mod == row_off (row_mod <= 1: all);
                            // the sharded LAUUM, one launch per rank over its cyclic share of the 128-row tile rows
-  int op;                  // executor only (gpp_exec_f64): 0 = the product above, 1 = copy the M x 128 strip `tn` of B into C
+  int op;                  // DAG executor only (gpp_dag_f64): 0 = the product above, 1 = copy the M x 128 strip `tn` of B into C
   int compact_bc;          // c_lower == 1 with own_mod > 1: B and C hold only the owned column blocks, side by side (the q-th owned
                            // block in columns [q own_bt 128, (q+1) own_bt 128) of their buffers): the sharded back-substitution
                            // with N x (N / ranks) storage per rank
@@ -145,74 +149,10 @@ struct GemmArgs {
 // tile_m = 0: choose a square tile from the grid size; else force the work-group tile (128x128, 64x64, 32x32, 128x32)
 hipError_t gpp_launch_gemm(hipStream_t s, int variant, const GemmArgs& a, int batch, int tile_m = 0, int tile_n = 0);
 
-// ---- static-schedule executor (gpp_gemm.hip; planned by gpp_plan.hip) -------------------------
-// A persistent launch whose work-groups ("workers") each walk a HOST-precomputed list of 128 x 128 tile tasks of several products
-// (`groups`), gated by monotone counters in device memory: a task may wait for up to two counters to reach a value and increments up
-// to two when its stores are visible (agent-scope release / acquire).  The lists are subsequences of ONE topological order of the
-// task graph, so the earliest unfinished task is always runnable provided every worker of the launch is resident (grid <= the
-// work-group slots of the stream's CUs).  counters[0] is the abort word: a wait that exceeds `budget` ticks of the 100 MHz clock
-// sets it and *info, and every worker leaves.
-struct ExecTask {          // 32 bytes
-  int32_t group;           // index into the groups array; GPP_EXEC_END ends a worker's list
-  int16_t tm, tn;          // tile of that group's product, or (GemmArgs::op == 1) the 128-column strip tn of a copy
-  int32_t wait_id[2];      // counters to wait for (-1: none) ...
-  int32_t wait_val[2];     // ... until they are >= these values
-  int32_t inc_id[2];       // counters to increment once the task's stores are visible (-1: none)
-};
-constexpr int32_t GPP_EXEC_END = -1;
-struct ExecLaunch {
-  const GemmArgs* groups;
-  const ExecTask* tasks;
-  const int32_t* offsets;  // worker w walks tasks[offsets[worker_base + w]] ... up to GPP_EXEC_END
-  int* counters;
-  int32_t* info;
-  long long budget;        // ticks of the 100 MHz constant clock a single wait may take
-  int worker_base;
-  unsigned long long* trace;  // debug (tools/exec_trace.py): 3 stamps of the 100 MHz clock per task — fetched, waits over, done — or null
-};
-hipError_t gpp_launch_exec(hipStream_t s, int nworkers, const ExecLaunch& e);
-// one-wave kernels on a stream: wait until counters[id] >= target (same budget / abort rules), and counters[id] += 1
+// one-wave kernels on a stream (gpp_gemm.hip): wait until counters[id] >= target — a wait that exceeds `budget` ticks of the 100 MHz
+// clock sets the abort word counters[0] and *info = GPP_INFO_EXEC_TIMEOUT + ms —, and counters[id] += 1 behind a release fence
 hipError_t gpp_launch_exec_gate(hipStream_t s, int* counters, int id, int target, int32_t* info, long long budget);
 hipError_t gpp_launch_exec_signal(hipStream_t s, int* counters, int id);
-
-// The plan of the look-ahead factorisation's throughput-bound steps (gpp_plan.hip): task lists of the W main workers and of the
-// per-step filler launches, the products they refer to, and the counter targets the host-side launches (gates) wait for.
-struct PotrfExecTuning {
-  double t_tile;    // us a worker needs for one K = nb update tile
-  double t_block;   // us of a step during which the panel's CUs are NOT available to the filler (gate, panel, hand-offs)
-  int solve_pos;    // bulk tiles of phase 0 a worker runs before its share of block row 1's solve (the first panel is not hidden)
-  int solve_pos_later;  // the same for the later phases (their diagonal block was factored during the previous phase)
-  double la_frac;   // fraction of a phase's bulk tiles a worker runs before its look-ahead tasks (step k+1 on block row k+2)
-  double la_frac2;  // the same for the look-ahead tasks outside the next diagonal block (>= la_frac)
-  int fill;         // 0: no filler launches
-};
-struct PotrfExecPlan {
-  int64_t N = 0, nb = 0;
-  int K = 0, W = 0, F = 0;
-  const double* A = nullptr; int64_t ld = 0;     // operands the device copy of `groups` was built for
-  const double* Li = nullptr; int64_t ldi = 0;
-  const double* T = nullptr; int64_t ldt = 0;
-  std::vector<GemmArgs> groups;       // 3 per step: solve, update, copy
-  std::vector<ExecTask> tasks;
-  std::vector<int32_t> offsets;       // [W] main workers, then [K][max(F,1)] filler work-groups
-  std::vector<int> fill_workers;      // per step: work-groups of the filler launch (0: none)
-  struct Op { int kind, arg; };       // the panel stream's launches in order: 0 gate(b) 1 panel(b) 2 signal(b) 3 filler launch(step)
-  std::vector<Op> stream_ops;
-  std::vector<int> gate_target;       // per diagonal block b >= 1: update tiles of step b-1 inside it (the panel's gate)
-  int ncounters = 0;
-  GemmArgs* d_groups = nullptr;
-  ExecTask* d_tasks = nullptr;
-  int32_t* d_offsets = nullptr;
-  int* d_counters = nullptr;
-  unsigned long long* d_trace = nullptr;  // 3 * tasks.size() stamps when tracing is switched on (gpp_debug_exec_trace)
-};
-PotrfExecPlan* gpp_plan_potrf_exec(int64_t N, int64_t nb, int K, int W, int F, const PotrfExecTuning& tune);
-PotrfExecPlan* gpp_plan_single_update(int64_t N, int64_t nb, int W);
-void gpp_plan_bind(PotrfExecPlan* P, double* A, int64_t ld, double* Li, int64_t ldi, double* T, int64_t ldt);
-hipError_t gpp_plan_upload(PotrfExecPlan* P);
-void gpp_plan_free(PotrfExecPlan* P);
-// counter ids of block b (gpp_plan.hip): 1 + 8 b + {0: panel done, 1: updates inside diagonal block b done (gate of its panel)}
-inline int gpp_plan_counter(int b, int which) { return 1 + 8 * b + which; }
 
 // ---- DAG executor (gpp_gemm.hip: gpp_dag_f64; planned by gpp_dag.hip) -----------------------------------------------------------
 // Round 5.  ONE list of tile tasks in a topological order of the whole task graph (factorisation, and optionally the triangular

@@ -138,6 +138,8 @@ class GraphedLossAndGrad:
             self.head, self.grads = body()
         self._lib_scratch = self.gctx._ws
         self.replays = self.declined = 0
+        self.last_status = 0  # status word of the last replay (-1: a non-finite number)
+        self.dead = False     # set by the driver when the captured launches must not be replayed any more (a time-out status)
 
     def step(self) -> Optional[float]:
         self.ws.epoch += 1
@@ -147,6 +149,7 @@ class GraphedLossAndGrad:
         self.done.synchronize()
         self.replays += 1
         value, status = float(self.head_host[0]), float(self.head_host[1])
+        self.last_status = int(status)
         if status != 0.0:
             self.declined += 1
             return None

@@ -8,6 +8,7 @@ from typing import List, Optional
 import torch
 from tqdm import tqdm
 
+from ..backend import INFO_PANEL_TIMEOUT
 from ..gpcore.mlls import ExactMarginalLogLikelihood
 
 
@@ -39,8 +40,17 @@ def _graphed_step(model, mll, params, evaluations: int):
     def closure():
         return -mll(model(*model.train_inputs), model.train_targets)
 
+    from .._lib import GppError
+    from ..errors import NanError, NotPSDError
+
     try:
         return GraphedLossAndGrad(closure, plist, n, dev)
+    except (NotPSDError, NanError):
+        # the eager warm-up evaluations failed at THIS start point (indefinite covariance, NaN inputs): not a capture problem — the
+        # eager loop meets the same point and raises the reference's own error with its own message
+        return None
+    except GppError:
+        raise  # a genuine library error is never "could not be captured"
     except RuntimeError as exc:  # a capture this stack refuses: the eager loop is the same computation — but say so, once
         import warnings
 
@@ -58,8 +68,13 @@ def _adam_run(model, mll, params, lr: float, num_iter: int, break_steps: int, ve
     history: List[float] = []
     bar = tqdm(range(num_iter), desc='Epoch', position=0, leave=True, disable=not verbose)
     for j in bar:
-        value = graphed.step() if graphed is not None else None
+        value = graphed.step() if graphed is not None and not graphed.dead else None
         if value is None:
+            if graphed is not None and not graphed.dead and graphed.last_status >= INFO_PANEL_TIMEOUT:
+                # a cooperative launch inside the captured evaluation timed out (another tenant on the GPU): the eager evaluation
+                # below switches that path off for the context, but the CAPTURE still contains it — every replay would pay the
+                # time-out again.  The rest of this start point runs eagerly; the driver re-captures before the next one.
+                graphed.dead = True
             optimizer.zero_grad()
             loss = -mll(model(*model.train_inputs), model.train_targets)
             loss.backward()
@@ -95,6 +110,13 @@ def fit_model_torch(model, model_param_groups: Optional[List] = None, lr_default
             best_loss, best_state = history[-1], deepcopy(model.state_dict())
         if restart < num_restarts:
             model.reset_parameters()  # next start point: a draw from the priors (models/gpregression.py:168-174)
+            if graphed is not None and graphed.dead:  # (see _adam_run) capture again, now without the launch that timed out
+                counts = (graphed.replays, graphed.declined)
+                for p in model.parameters():
+                    p.grad = None
+                graphed = _graphed_step(model, mll, list(model.parameters()), (num_restarts - restart) * num_iter)
+                if graphed is not None:
+                    graphed.replays, graphed.declined = graphed.replays + counts[0], graphed.declined + counts[1]
     if graphed is not None:  # only the counters outlive the fit: the graph and its memory pool are released here
         from types import SimpleNamespace
         fit_model_torch.last_graph = SimpleNamespace(replays=graphed.replays, declined=graphed.declined)

@@ -77,16 +77,14 @@ int gpp_internal_stream(gpp_handle_t h, int which, void** out);
 #define GPP_OPT_COOP_PANEL 1
 #define GPP_OPT_PANEL_FAULT 2
 #define GPP_OPT_PANEL_TIMEOUT_MS 3
-#define GPP_OPT_EXEC_SCHED 4 /* default 1 (0 with GPP_EXEC_SCHED=0): the throughput-bound steps of gpp_potrf_ws's look-ahead run as one
-                              * statically scheduled persistent launch (gpp_plan.hip); needs GPP_OPT_COOP_PANEL and shares its
-                              * time-out / recovery: its work-groups must all be resident on the throughput stream's CUs */
+#define GPP_OPT_EXEC_SCHED 4 /* (round 4's statically scheduled executor, replaced by the DAG executor: an alias of GPP_OPT_DAG_SCHED) */
 #define GPP_OPT_DAG_SCHED 5  /* default 1 (0 with GPP_DAG_SCHED=0): factorisation (and, for 3840 <= N <= GPP_DAG_INV_MAX, the whole inverse
                               * beside it) as ONE list of tile tasks in topological order that persistent work-groups take by atomic
                               * ticket (gpp_dag.hip, gpp_dag_f64) — needs no co-residency of its work-groups; the diagonal blocks still
                               * run as cooperative panel launches (GPP_OPT_COOP_PANEL) */
 #define GPP_INFO_PANEL_TIMEOUT (1 << 30)
-/* a wait of one of the EXECUTORS' work-groups (gpp_exec_f64, gpp_dag_f64, their gate kernels) timed out — status =
- * GPP_INFO_EXEC_TIMEOUT + milliseconds: the caller switches GPP_OPT_EXEC_SCHED / GPP_OPT_DAG_SCHED off and factors again; the
+/* a wait of one of the DAG executor's work-groups (gpp_dag_f64, its gate kernels) timed out — status =
+ * GPP_INFO_EXEC_TIMEOUT + milliseconds: the caller switches GPP_OPT_DAG_SCHED off and factors again; the
  * cooperative panel itself (GPP_INFO_PANEL_TIMEOUT without the second bit) stays on unless it times out on its own */
 #define GPP_INFO_EXEC_TIMEOUT ((1 << 30) | (1 << 29))
 int gpp_set_option(gpp_handle_t h, int option, int value);

@@ -551,3 +551,106 @@ class OracleGP:
         mse = ((y_sc - mean) ** 2).mean() * self.y_std ** 2
         return {"NLL": -log_prob / M, "MSE": mse, "MAE": (y_sc - mean).abs().mean() * self.y_std.abs(),
                 "RRMSE": torch.sqrt(mse / torch.var(ytest)), "IS": score.mean() * self.y_std.abs()}
+
+
+# ---------------------------------------------------------------------------------------------------
+# consumers of predict(): acquisition functions, one step of the pool-based BO loop, Sobol indices
+# ---------------------------------------------------------------------------------------------------
+def _af_parts(mean, std, best_f, cost, maximize: bool, si: float):
+    """bayesian_optimizations/AFs.py:13-26 (the same lines in every function of the file): u, sigma and the cost."""
+    mean = torch.as_tensor(mean, dtype=DT).reshape(-1, 1)
+    view_shape = mean.shape[:-2] if mean.shape[-2] == 1 else mean.shape[:-1]
+    mean = mean.view(view_shape)
+    sigma = torch.as_tensor(std, dtype=DT).view(view_shape)
+    u = (mean - best_f - math.copysign(1.0, best_f) * (0.0 if best_f == 0 else 1.0) * si) / sigma  # np.sign(best_f) * si
+    cost = torch.ones(u.shape, dtype=DT) if cost is None else torch.as_tensor(cost, dtype=DT).view(u.shape)
+    if not maximize:
+        u = -u
+    return u, sigma, cost
+
+
+def _std_normal_pdf_cdf(u: torch.Tensor):
+    """[3P] torch.distributions.Normal(0, 1): exp(log_prob(u)) and cdf(u), written out."""
+    pdf = torch.exp(-0.5 * u * u) / math.sqrt(2.0 * math.pi)
+    cdf = 0.5 * (1.0 + torch.erf(u / math.sqrt(2.0)))
+    return pdf, cdf
+
+
+def oracle_af(kind: str, samples, best_f: float, oracle: "OracleGP", xmean, xstd, cost_fun, maximize: bool = False,
+              si: float = 0.0) -> float:
+    """AF_LF (AFs.py:1-30), AF_HF (:33-64) and AF_EI (:67-100) of ONE raw point ``samples`` = [quantitative coordinates, source]:
+    standardise the coordinates (:5), predict with noise (:8), u = (mean - best_f - sign(best_f) si) / sigma (:16), negated for
+    minimisation (:23-24), then  LF: -sigma pdf(u) / cost,  HF: -sigma u / cost,  EI: -sigma (pdf(u) + u cdf(u)) / cost."""
+    import numpy as np
+
+    samples = np.asarray(samples, dtype=np.float64)
+    x = np.concatenate([((samples[0:-1] - np.asarray(xmean)) / np.asarray(xstd)).reshape(1, -1), samples[-1].reshape(-1, 1)], axis=-1)
+    mean, std = oracle.predict(x.reshape(1, -1), return_std=True, include_noise=True)
+    cost = torch.tensor([float(cost_fun(v)) for v in x[:, -1]], dtype=DT)
+    u, sigma, cost = _af_parts(mean, std, best_f, cost, maximize, si)
+    pdf, cdf = _std_normal_pdf_cdf(u)
+    if kind == "LF":
+        val = sigma * pdf
+    elif kind == "HF":
+        val = sigma * u
+    elif kind == "EI":
+        val = sigma * (pdf + u * cdf)
+    else:
+        raise ValueError(kind)
+    return float(-1 * (val / cost))
+
+
+def oracle_af_engineering(kind: str, best_f: float, mean, std, x_val, cost_fun, maximize: bool = True, si: float = 0.0):
+    """AF_LF_Engineering (AFs.py:103-131: sigma pdf(u) / cost) and AF_HF_Engineering (:134-159: sigma u / cost) on a pool."""
+    x_val = torch.as_tensor(x_val, dtype=DT)
+    cost = torch.tensor([float(cost_fun(v)) for v in x_val[:, -1]], dtype=DT)
+    u, sigma, cost = _af_parts(mean, std, best_f, cost, maximize, si)
+    pdf, _ = _std_normal_pdf_cdf(u)
+    return (sigma * pdf if kind == "LF" else sigma * u) / cost
+
+
+def oracle_bo_pool_scores(oracle: "OracleGP", pool, best_values, cost_fun, num_fidelity: int, maximize: bool = False):
+    """The selection of one iteration of the pool branch of BO (BO_GP_plus.py:183-197): for every source i the candidates
+    ``pool[pool[:, -2] == i]`` (columns: inputs ..., source, response) are predicted WITHOUT noise (:187), scored with the
+    high-fidelity utility for source 0 and the low-fidelity one otherwise (:188-192), the scores concatenated in source order
+    (:194) and the argmax taken (:195).  Returns (scores, index).  As in the reference the index addresses the concatenation
+    (which the reference then applies to the pool itself, :197 — identical when the pool is sorted by source)."""
+    pool = torch.as_tensor(pool, dtype=DT)
+    scores = []
+    for i in range(num_fidelity):
+        cand = pool[pool[:, -2] == i][:, 0:-1]
+        mean, std = oracle.predict(cand, return_std=True, include_noise=False)
+        kind = "HF" if i == 0 else "LF"
+        scores.append(oracle_af_engineering(kind, best_values[i], mean.reshape(-1, 1), std.reshape(-1, 1), cand, cost_fun,
+                                            maximize=maximize).reshape(-1))
+    scores = torch.cat(scores, dim=0)
+    return scores, int(torch.argmax(scores))
+
+
+def oracle_sobol(oracle: "OracleGP", sequence, levels_per_cat: Sequence[int]):
+    """Sobol indices of the posterior mean by Saltelli's scheme (models/gp_plus.py:1148-1224) on a GIVEN (N, 2p) low-discrepancy
+    ``sequence`` in [0, 1): A from columns p.., B from columns ..p (:1177-1178), scaled to the training inputs' range (:1184-1185),
+    categorical columns mapped to their level grid and rounded (:1188-1192; every categorical column, see GP_Plus.Sobol here),
+    S_i = mean(FB (F_ABi - FA)) / Var, ST_i = mean((FA - F_ABi)^2) / 2 Var with Var over cat([FA, FB]) (:1212-1220)."""
+    seq = torch.as_tensor(sequence, dtype=DT)
+    p = oracle.train_x.shape[1]
+    mins, maxs = oracle.train_x.min(dim=0)[0], oracle.train_x.max(dim=0)[0]
+    halves = []
+    for part in (seq[:, p:], seq[:, :p]):
+        scaled = mins + (maxs - mins) * part
+        for j, col in enumerate(oracle.qual_cols):
+            scaled[:, col] = (part[:, col] * (levels_per_cat[j] - 1)).round()
+        halves.append(scaled)
+    A, B = halves
+    N = A.shape[0]
+    f = lambda Z: oracle.predict(Z, return_std=False).reshape(-1, 1)  # noqa: E731
+    FA, FB = f(A), f(B)
+    S, ST = torch.zeros(p, 1, dtype=DT), torch.zeros(p, 1, dtype=DT)
+    for i in range(p):
+        ABi = A.clone()
+        ABi[:, i] = B[:, i]
+        Fi = f(ABi)
+        S[i] = (FB * (Fi - FA)).sum(0) / N
+        ST[i] = ((FA - Fi) ** 2).sum(0) / (2 * N)
+    varY = torch.var(torch.cat([FA, FB]), dim=0, unbiased=False)  # np.var
+    return (S / varY).T.numpy(), (ST / varY).T.numpy()

@@ -220,3 +220,41 @@ def test_fit_model_torch_hands_an_indefinite_step_to_the_eager_path():
     assert np.isfinite(f) and len(hist[0]) == 12
     if g.declined:
         assert any("jitter" in str(x.message) for x in w)
+
+
+def test_two_captured_graphs_on_one_handle_alternate():
+    """Two evaluations captured on the SAME library handle (each holds one cooperative panel launch, N <= 2048), replayed in turn
+    and interleaved with eager evaluations of a third model: every captured panel launch owns a flag block of the capture ring
+    (csrc/gpp_api.hip::launch_panel) that neither the other graph nor an eager launch uses, so the numbers are those of the eager
+    evaluations, bit for bit, in any order."""
+    from gpplus_amd.gpcore import ExactMarginalLogLikelihood
+    from gpplus_amd.graphed import GraphedLossAndGrad
+
+    def eager(m):
+        m.train()
+        mll = ExactMarginalLogLikelihood(m.likelihood, m)
+        for p in m.parameters():
+            p.grad = None
+        loss = -mll(m(*m.train_inputs), m.train_targets)
+        loss.backward()
+        return loss.item(), [p.grad.clone() for p in m.parameters() if p.grad is not None]
+
+    ma, mb, mc = _model("plain", n=300), _model("plain", n=480), _model("plain", n=350)
+    ref = {k: eager(m) for k, m in (("a", ma), ("b", mb), ("c", mc))}
+    graphs = {}
+    for k, m in (("a", ma), ("b", mb)):
+        mll = ExactMarginalLogLikelihood(m.likelihood, m)
+        plist = [p for p in m.parameters() if p.requires_grad]
+        graphs[k] = GraphedLossAndGrad(lambda m=m, mll=mll: -mll(m(*m.train_inputs), m.train_targets), plist, int(m.train_targets.shape[0]),
+                                       torch.device("cuda:0"))
+    for k in ("a", "b", "c", "b", "a", "a", "c", "b"):
+        if k == "c":
+            got = eager(mc)
+            assert got[0] == ref["c"][0]
+            continue
+        m = ma if k == "a" else mb
+        v = graphs[k].step()
+        assert v is not None and v == ref[k][0], (k, v, ref[k][0])
+        grads = [p.grad for p in m.parameters() if p.grad is not None]
+        for g, r in zip(grads, ref[k][1]):
+            assert torch.equal(g, r), k

@@ -358,10 +358,10 @@ def test_panel_inside_the_lookahead_reports_the_failing_minor(gpu_ctx):
 
 
 def test_static_schedule_matches_the_launch_per_product_driver(gpu_ctx):
-    """gpp_potrf_ws above the bordering range: the throughput-bound steps as ONE statically scheduled persistent launch (gpp_exec_f64,
-    planned by gpp_plan.hip) against the same steps as launches per product (GPP_OPT_EXEC_SCHED = 0): same factor and inverse to
-    rounding, both against scipy; and a bad pivot inside the scheduled steps is reported as the failing leading minor (the launch
-    runs to its end on whatever the panel left: no counter waits on a value)."""
+    """gpp_potrf_ws through the DAG executor (gpp_dag_f64, planned by gpp_dag.hip: factorisation and right-looking inverse as one
+    ticket list) against launches per product + pair merges (GPP_OPT_DAG_SCHED = 0, of which GPP_OPT_EXEC_SCHED is an alias): same
+    factor and inverse to rounding, both against scipy; and a bad pivot inside the list's steps is reported as the failing leading
+    minor (the launch runs to its end on whatever the panel left: no counter waits on a value)."""
     import scipy.linalg as sla
 
     from gpplus_amd.backend import OPT_EXEC_SCHED

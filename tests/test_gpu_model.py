@@ -470,6 +470,83 @@ def test_bayesian_optimisation_consumers(gpu_ctx):
     assert bestf2.shape == (2,) and (cum2[1] - cum2[0]) in (10.0, 1.0)
 
 
+def test_bo_consumers_match_the_oracle(gpu_ctx):
+    """SURVEY.md §8 f4 against the ORACLE (oracle/gp_oracle.py: oracle_af, oracle_bo_pool_scores, oracle_sobol, restated from
+    bayesian_optimizations/AFs.py:1-159, BO_GP_plus.py:183-197 and models/gp_plus.py:1148-1224 on top of OracleGP.predict): on a
+    seeded two-source problem with the SAME raw parameters in both, the HIP model's acquisition values, the pool branch's scores and
+    chosen candidate, and the Sobol indices on the same low-discrepancy sample agree with the oracle's."""
+    import warnings as _w
+
+    from gpplus_amd.bayesian_optimizations import AF_EI, AF_HF, AF_LF
+    from gpplus_amd.bayesian_optimizations.AFs import AF_HF_Engineering, AF_LF_Engineering
+    from gpplus_amd.models import GP_Plus
+    from gpplus_amd.utils import set_seed
+    from oracle.gp_oracle import OracleGP, oracle_af, oracle_bo_pool_scores, oracle_sobol
+    from scipy.stats import qmc
+
+    set_seed(7)
+    rng = np.random.default_rng(11)
+
+    def truth(x1, x2, s):
+        return np.sin(3.0 * x1) + 0.5 * x2 * x2 + (0.3 * np.cos(2.0 * x1) + 0.1 if s == 1 else 0.0)
+
+    n = 60
+    raw = rng.uniform(-2.0, 2.0, (n, 2))
+    src = np.array([0] * 20 + [1] * 40)
+    xmean, xstd = raw.mean(0), raw.std(0)
+    Xtr = np.concatenate([(raw - xmean) / xstd, src[:, None].astype(float)], axis=1)
+    ytr = np.array([truth(a, b, s) for (a, b), s in zip(raw, src)])
+    m = GP_Plus(torch.tensor(Xtr), torch.tensor(ytr), qual_dict={2: 2}, dtype=torch.float64, device="cuda")
+    o = OracleGP(Xtr, ytr, qual_dict={2: 2})
+    sd = m.state_dict()
+    vals = {"raw_lengthscale": -0.4, "raw_outputscale": 0.5, "raw_noise": -5.0, "constant": 0.2}
+    for k in list(o.params):
+        for frag, v in vals.items():
+            if frag in k:
+                sd[k] = torch.full_like(sd[k], v)
+        o.params[k] = sd[k].detach().cpu().double().reshape(o.params[k].shape).clone()
+    m.load_state_dict(sd)
+    m.eval()
+    costs = {"0": 10.0, "1": 1.0}
+    cf = lambda v: costs[str(int(v))]  # noqa: E731
+    best = float(ytr[src == 0].min())
+    # point-wise acquisition functions (the continuous branch's objective, BO_GP_plus.py:68)
+    for pt in ([0.3, -1.1, 1.0], [-1.7, 0.4, 0.0], [1.9, 1.9, 1.0], [0.0, 0.0, 0.0], [-0.6, 1.3, 1.0]):
+        pt = np.array(pt)
+        for fn, kind in ((AF_LF, "LF"), (AF_HF, "HF"), (AF_EI, "EI")):
+            for maximize in (False, True):
+                got = fn(pt, best, m, xmean, xstd, cf, maximize=maximize, si=0.01)
+                ref = oracle_af(kind, pt, best, o, xmean, xstd, cf, maximize=maximize, si=0.01)
+                assert abs(got - ref) <= 1e-6 * max(abs(ref), 1e-6), (kind, pt, maximize, got, ref)
+    # one selection of the pool branch (BO_GP_plus.py:183-197): scores per source, concatenated, argmax
+    praw = rng.uniform(-2.0, 2.0, (90, 2))
+    psrc = np.array([0] * 30 + [1] * 60)
+    pool = np.concatenate([(praw - xmean) / xstd, psrc[:, None].astype(float),
+                           np.array([truth(a, b, s) for (a, b), s in zip(praw, psrc)])[:, None]], axis=1)
+    best_values = [float(ytr[src == i].min()) for i in range(2)]
+    ref_scores, ref_idx = oracle_bo_pool_scores(o, pool, best_values, cf, 2, maximize=False)
+    scores = []
+    for i in range(2):
+        cand = torch.tensor(pool[pool[:, -2] == i][:, 0:-1])
+        with torch.no_grad():
+            ytest, ystd = m.predict(cand, return_std=True, include_noise=False)
+        af = AF_HF_Engineering if i == 0 else AF_LF_Engineering
+        scores.append(af(best_values[i], ytest.reshape(-1, 1), ystd.reshape(-1, 1), cand, cf, maximize=False).reshape(-1))
+    scores = torch.cat(scores, dim=0)
+    np.testing.assert_allclose(scores.cpu().numpy(), ref_scores.numpy(), rtol=1e-6, atol=1e-9)
+    assert int(torch.argmax(scores)) == ref_idx
+    # Sobol indices on the same sample
+    Nq = 512
+    gen = qmc.Sobol(d=6, scramble=False)
+    gen.fast_forward(1)
+    S_ref, ST_ref = oracle_sobol(o, gen.random(Nq), [2])
+    with _w.catch_warnings():
+        _w.simplefilter("ignore")
+        S, ST = m.Sobol(N=Nq, batch=200)
+    np.testing.assert_allclose(S, S_ref, rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(ST, ST_ref, rtol=1e-6, atol=1e-8)
+
+
 def test_sobol_indices(gpu_ctx):
     """Sobol indices from p + 2 batched predictions (gp_plus.py:1148-1224).  For an additive truth
     y = 2 x0 + x1^2 + (level effect of a categorical x2) the analytic indices follow from the term variances."""

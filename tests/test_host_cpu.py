@@ -282,51 +282,55 @@ def test_panel_hand_off_waits_for_the_write_back_before_raising_a_flag():
                 raise AssertionError(f"{name}: no s_waitcnt vmcnt(0) within 40 instructions of a buffer_wbl2")
 
 
-# ---- the static-schedule executor's planner (gpp_plan.hip): host logic, no GPU ---------------------------------------------------
-def _plan_check():
+# ---- the DAG executor's planner (gpp_dag.hip): host logic, no GPU ---------------------------------------------------------------------
+def _dag_check():
     import ctypes
 
     from gpplus_amd import _lib
 
     lib = _lib.load()
-    f = lib.gpp_debug_plan_check
+    f = lib.gpp_debug_dag_check
     f.restype = ctypes.c_int
-    f.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint,
+    f.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint,
                   ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
     return f, (ctypes.c_int64 * 4)()
 
 
-@pytest.mark.parametrize("N,K,W,F,fill", [(12288, 6, 448, 64, 1), (13500, 7, 448, 64, 1), (20000, 14, 448, 64, 1), (20000, 14, 448, 64, 0),
-                                          (20001, 14, 448, 64, 1), (15000, 9, 448, 64, 1), (9000, 3, 448, 64, 1), (16384, 10, 14, 2, 1),
-                                          (16384, 10, 30, 6, 1), (33000, 26, 448, 64, 1)])
-def test_exec_plan_is_a_valid_schedule_under_any_interleaving(N, K, W, F, fill):
-    """The host-precomputed task lists of the statically scheduled Cholesky steps (gpp_plan.hip), executed on the host in random and
-    adversarial interleavings that respect only what the device respects (list order per worker, counters, stream order of the panel
-    stream): every tile gets the updates of steps 0, 1, 2, ... in order and exactly once, solves read fully updated, not yet
-    overwritten block rows of a factored diagonal block, updates read completely solved strips, panels start on fully updated
-    diagonal blocks, nothing deadlocks, everything is complete at the end."""
-    f, st = _plan_check()
+@pytest.mark.parametrize("N,nb,flags,chain_tile,W,fill", [
+    (4096, 1024, 1, 64, 448, 64), (7168, 1024, 1, 64, 448, 64), (10000, 1024, 1, 64, 448, 64), (10000, 1024, 0, 128, 448, 0),
+    (9300, 1024, 1, 64, 30, 6),      # a last block of 84 rows joins its neighbour
+    (5000, 512, 1, 64, 1, 0),        # ONE worker executes the list in order: the order itself must be topological
+    (11264, 1024, 1, 128, 7, 2), (13500, 1024, 1, 64, 448, 64), (15000, 1024, 0, 64, 448, 64), (20001, 1024, 0, 64, 448, 64)])
+def test_dag_plan_is_a_valid_schedule_under_any_interleaving(N, nb, flags, chain_tile, W, fill):
+    """The ticket list of the DAG executor (gpp_dag.hip: factorisation, and with flags = 1 the right-looking inverse beside it),
+    executed on the host by W workers + filler launches in random and adversarial interleavings that respect only what the device
+    respects (tickets in list order, counters, stream order of the panel stream, the fillers' ticket limit): every tile gets its
+    updates in order and exactly once, solves read fully updated, not yet overwritten block rows of a factored diagonal block,
+    updates read completely solved strips, panels start on fully updated blocks, the inverse's sums take their contributions in
+    order from finished rows, nothing deadlocks (a filler launch in front of a panel never holds a task that needs that panel),
+    everything is complete at the end."""
+    f, st = _dag_check()
     for seed in range(8):
-        rc = f(N, 1024, K, W, F, fill, 4, seed, st, 0)
+        rc = f(N, nb, flags, chain_tile, W, fill, seed, st, 0)
         assert rc == 0, (seed, rc)
     assert st[0] > 0 and st[1] > 0 and st[2] > 0
 
 
-def test_exec_plan_check_notices_a_missing_wait():
-    """The test of the test above: with ONE wait removed from the plan the host execution must find a violation in most cases
-    (some waits are implied by the others in every interleaving the checker produces; a panel or filler hand-off never is)."""
-    f, st = _plan_check()
-    caught = total = 0
-    must = {"PD": [0, 0], "FD": [0, 0]}
-    names = {0: "PD", 1: "G1D", 2: "HR", 3: "RR", 4: "SH", 5: "SA", 6: "FD"}
-    for mut in range(1, 9000, 211):
-        rcs = [f(13500, 1024, 7, 448, 64, 1, 4, seed, st, mut) for seed in range(8)]
-        kind = names[int(st[3]) % 10]
-        total += 1
-        caught += any(rcs)
-        if kind in must and (int(st[3]) // 10) % 10 == 0:
-            must[kind][0] += 1
-            must[kind][1] += any(rcs)
-    assert caught >= 0.6 * total, (caught, total)
-    for kind, (n, c) in must.items():
-        assert n == c, (kind, n, c)
+def test_dag_plan_check_notices_a_missing_wait():
+    """The test of the test above: with ONE wait removed, and the tasks that raise that counter made slow (they run only when
+    nothing else can; for a panel's counter: a lazy panel stream), the host execution must find a violation in most cases.  Some
+    waits are implied by the others for every schedule the given number of workers can produce (a worker holds one ticket, so only
+    so much of the list is in flight at once): with 4096 workers nearly every removed wait is exposed, with the device's 448 most."""
+    f, st = _dag_check()
+    for W, need, need_panel in ((448, 0.75, 0.0), (4096, 0.9, 0.5)):
+        caught = total = 0
+        panel = [0, 0]
+        for mut in range(1, 68000, 1511):
+            rcs = [f(10000, 1024, 1, 64, W, 64, seed, st, mut) for seed in range(4)]
+            total += 1
+            caught += any(rcs)
+            if int(st[3]) % 10 == 0:  # the removed wait was for a panel (PD)
+                panel[0] += 1
+                panel[1] += any(rcs)
+        assert caught >= need * total, (W, caught, total)
+        assert panel[0] > 0 and panel[1] >= need_panel * panel[0], (W, panel)

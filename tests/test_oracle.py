@@ -236,3 +236,41 @@ def test_transforms_against_the_reference_module():
         np.testing.assert_allclose(isp(pos).numpy(), fx["inv_softplus_pos"], rtol=1e-15, atol=1e-300)
         np.testing.assert_allclose(sp(x.float()).numpy(), fx["softplus_x32"], rtol=1e-7, atol=0)
         np.testing.assert_allclose(isp(pos.float()).numpy(), fx["inv_softplus_pos32"], rtol=1e-6, atol=1e-30)
+
+
+def test_oracle_bo_consumers_against_closed_forms():
+    """The f4 restatements (oracle_af, oracle_af_engineering, oracle_bo_pool_scores, oracle_sobol) against scipy's normal
+    distribution evaluated on OracleGP.predict's own numbers, and Sobol's sum rule on a near-additive posterior mean."""
+    from scipy.stats import norm, qmc
+
+    rng = np.random.default_rng(3)
+    xs = rng.uniform(-2.0, 2.0, 40)
+    src = np.array([0] * 14 + [1] * 26)
+    X = np.stack([(xs - xs.mean()) / xs.std(), src.astype(float)], axis=1)
+    y = np.sin(3 * xs) + 0.5 * xs + np.where(src == 1, 0.3 * np.cos(2 * xs), 0.0)
+    o = G.OracleGP(X, y, qual_dict={1: 2})
+    o.params["likelihood.noise_covar.raw_noise"] = torch.full_like(o.params["likelihood.noise_covar.raw_noise"], -5.0)
+    cf = lambda v: {0: 10.0, 1: 1.0}[int(v)]  # noqa: E731
+    best = float(y.min())
+    for pt, maximize in (([0.3, 1.0], False), ([-1.2, 0.0], False), ([1.5, 1.0], True)):
+        pt = np.array(pt)
+        mu, sd = o.predict(np.array([[(pt[0] - xs.mean()) / xs.std(), pt[1]]]), return_std=True, include_noise=True)
+        mu, sd = float(mu), float(sd)
+        u = (mu - best - np.sign(best) * 0.02) / sd
+        u = u if maximize else -u
+        c = cf(pt[1])
+        args = (pt, best, o, [xs.mean()], [xs.std()], cf)
+        assert abs(G.oracle_af("EI", *args, maximize=maximize, si=0.02) + sd * (norm.pdf(u) + u * norm.cdf(u)) / c) < 1e-12
+        assert abs(G.oracle_af("LF", *args, maximize=maximize, si=0.02) + sd * norm.pdf(u) / c) < 1e-12
+        assert abs(G.oracle_af("HF", *args, maximize=maximize, si=0.02) + sd * u / c) < 1e-12
+    pool = np.stack([rng.uniform(-1, 1, 30), np.array([0] * 10 + [1] * 20).astype(float), rng.normal(size=30)], axis=1)
+    bv = [float(y[src == 0].min()), float(y[src == 1].min())]
+    scores, idx = G.oracle_bo_pool_scores(o, pool, bv, cf, 2)
+    assert scores.shape == (30,) and idx == int(torch.argmax(scores))
+    m0, s0 = o.predict(pool[:10, :2], return_std=True, include_noise=False)
+    u0 = -(m0 - bv[0]) / s0
+    np.testing.assert_allclose(scores[:10].numpy(), (s0 * u0 / 10.0).numpy(), rtol=1e-12)
+    gen = qmc.Sobol(d=4, scramble=False)
+    gen.fast_forward(1)
+    S, ST = G.oracle_sobol(o, gen.random(1024), [2])
+    assert S.shape == (1, 2) and ST.shape == (1, 2) and (ST > 0).all() and (ST[0] >= S[0] - 0.05).all()
