@@ -52,3 +52,49 @@ def fit_restarts_parallel(model, num_restarts: int = 0, fit_fn: Optional[Callabl
     if rank != best_rank:
         model.load_state_dict(state[0])
     return best_loss, hist
+
+
+def fit_scipy_parallel(model, num_restarts: int = 1, seed: int = 0, fit_fn: Optional[Callable] = None,
+                       pack_fn: Optional[Callable] = None, **fit_kwargs):
+    """``fit_model_scipy``'s multistart mapped over the ranks of the default process group — the MI355X form of the reference's
+    ``Parallel(n_jobs)(delayed(_fit_model_from_state)(...) for theta0 in theta0_list)`` over CPU workers
+    (optim/mll_scipy.py:287-293): one process per GPU, every rank draws the SAME ``num_restarts + 1`` start points from the priors
+    (``seed``; the reference's sampling loop, optim/mll_scipy.py:266-276), runs L-BFGS from starts ``rank, rank + P, ...`` on its own
+    replica (each objective evaluation a replayed HIP graph or the DAG-scheduled factorisation, as in the sequential driver), and
+    the best optimum wins everywhere.  No data-path collective: one ``all_gather_object`` of (objective, rank) and one broadcast of
+    the winning state dict.  Returns ``(this rank's OptimizeResults, best objective over all ranks)``.
+
+    ``fit_fn(model, theta0_list=..., **fit_kwargs) -> (results, best)`` and ``pack_fn(model) -> flat parameter vector`` are
+    injectable (the CPU test suite passes oracle-backed stand-ins); the product's are ``fit_model_scipy`` and
+    ``MLLObjective.pack_parameters``."""
+    from copy import deepcopy
+
+    if fit_fn is None:
+        from .mll_scipy import fit_model_scipy as fit_fn
+    if not (dist.is_available() and dist.is_initialized()):
+        return fit_fn(model, num_restarts=num_restarts, **fit_kwargs)
+    if pack_fn is None:
+        from .mll_scipy import MLLObjective
+
+        def pack_fn(m):
+            return MLLObjective(m, fit_kwargs.get("add_prior", True), fit_kwargs.get("regularization_parameter", [0, 0])).pack_parameters()
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.manual_seed(seed)  # identical draws on every rank
+    start_state = deepcopy(model.state_dict())
+    thetas = []
+    for _ in range(num_restarts + 1):
+        model.reset_parameters()
+        thetas.append(pack_fn(model))
+    model.load_state_dict(start_state)
+    mine = thetas[rank::world]
+    results, best = [], math.inf
+    if mine:
+        results, best = fit_fn(model, theta0_list=mine, **fit_kwargs)
+    scores = [None] * world
+    dist.all_gather_object(scores, (float(best) if math.isfinite(best) else math.inf, rank))
+    best_loss, best_rank = min(scores)
+    state = [model.state_dict() if rank == best_rank else None]
+    dist.broadcast_object_list(state, src=best_rank)
+    if rank != best_rank and math.isfinite(best_loss):
+        model.load_state_dict(state[0])
+    return results, best_loss

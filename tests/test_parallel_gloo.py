@@ -89,3 +89,66 @@ def test_restart_parallel_two_ranks(tmp_path):
     assert r0["f"] == r1["f"]                                # both agree on the incumbent
     assert torch.equal(r0["flat"], r1["flat"])              # ... and hold the same (best) state
     assert abs(r0["final"] - r0["f"]) < 5e-2                # the state reproduces (about) the reported loss
+
+
+def _scipy_fit(model, theta0_list=None, num_restarts=0, maxiter=25):
+    """Stand-in for fit_model_scipy with the same contract: L-BFGS from every start, the best optimum loaded into the model."""
+    from scipy.optimize import minimize
+
+    names = list(model.theta.keys())
+    shapes = [model.theta[k].shape for k in names]
+
+    def load(x):
+        i = 0
+        with torch.no_grad():
+            for k, sh in zip(names, shapes):
+                n = int(np.prod(sh)) if len(sh) else 1
+                model.theta[k].copy_(torch.as_tensor(x[i:i + n]).reshape(sh))
+                i += n
+
+    def fun(x):
+        load(x)
+        for p in model.parameters():
+            p.grad = None
+        loss = model.loss()
+        loss.backward()
+        return loss.item(), np.concatenate([model.theta[k].grad.reshape(-1).numpy() for k in names])
+
+    out = [minimize(fun, x0, jac=True, method="L-BFGS-B", options={"maxiter": maxiter}) for x0 in theta0_list]
+    best = int(np.argmin([r.fun for r in out]))
+    load(out[best].x)
+    return out, float(out[best].fun)
+
+
+def _pack(model):
+    return np.concatenate([v.detach().reshape(-1).numpy() for v in model.theta.values()])
+
+
+def _worker_scipy(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gpplus_amd.optim.mll_parallel import fit_scipy_parallel
+
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((60, 3))
+    y = np.sin(X[:, 0]) + 0.1 * X[:, 1]
+    torch.set_num_threads(1)
+    m = _OracleBackedModel(X, y)
+    res, f = fit_scipy_parallel(m, num_restarts=4, seed=5, fit_fn=_scipy_fit, pack_fn=_pack)
+    flat = torch.cat([v.detach().reshape(-1) for v in m.state_dict().values()])
+    torch.save({"f": f, "final": m.loss().item(), "flat": flat, "nres": len(res), "funs": [float(r.fun) for r in res],
+                "x0": [r.x.copy() for r in res]}, os.path.join(out, f"s{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_scipy_multistart_over_two_ranks(tmp_path):
+    """fit_model_scipy's starts mapped over ranks (optim/mll_scipy.py:287-293 maps them over joblib workers): 5 starts split 3 + 2,
+    both ranks end with the same best objective and the same state, which is the best of ALL starts."""
+    port = 29700 + (os.getpid() % 1000)
+    mp.spawn(_worker_scipy, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "s0.pt", weights_only=False), torch.load(tmp_path / "s1.pt", weights_only=False)
+    assert r0["nres"] == 3 and r1["nres"] == 2
+    assert r0["f"] == r1["f"] == min(r0["funs"] + r1["funs"])
+    assert torch.equal(r0["flat"], r1["flat"])
+    assert abs(r0["final"] - r0["f"]) < 1e-9
