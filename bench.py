@@ -365,16 +365,16 @@ def run_replicas(args, dist, dev, rank, world, local_rank):
         eval_tf = N ** 3 / (elapsed / args.steps) / 1e12
         # HBM-side bytes come from committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE cannot run inside this
         # process); they only apply to the size they were collected at
-        pmc_l = _pmc_record("r04_lauum_pmc.json") if N == N_C2 else None
-        pmc_p = _pmc_record("r04_potrf_pmc.json") if N == N_C2 else None
-        pmc_t = _pmc_record("r04_trtri_pmc.json") if N == N_C2 else None
+        pmc_l = _pmc_record("r05_lauum_pmc.json") if N == N_C2 else None
+        pmc_p = _pmc_record("r05_potrf_pmc.json") if N == N_C2 else None
+        pmc_t = _pmc_record("r05_trtri_pmc.json") if N == N_C2 else None
         third = N ** 3 / 3
         entries = []
         for name, kernel, pmc in (
-                ("potrf", "gpp_potrf_ws: look-ahead blocked Cholesky; its throughput-bound steps ONE persistent launch of gpp_exec_f64 "
-                          "(448 work-groups walking host-planned tile lists gated by device counters: row solves, trailing updates) + "
-                          "gpp_panel_potrf_inv on 32 reserved CUs with filler launches between; the chain-bound tail as launches of "
-                          "gpp_gemm_f64<2,64,64,0,16,2>.  Traffic record: the launch-per-product form of the same steps (counter "
+                ("potrf", "gpp_potrf_ws: blocked Cholesky as ONE ticket list of 128 x 128 tile tasks (row solves, trailing updates, strip "
+                          "copies; host-planned topological order, gpp_dag.hip) taken by the persistent work-groups of gpp_dag_f64 — 448 "
+                          "on the 224 throughput CUs + filler launches of 64 on the panel's 32 CUs between gpp_panel_potrf_inv launches.  "
+                          "Traffic record: the same kernel over the same list as a sequence of launches (GPP_DAG_PHASED=1: counter "
                           "collection serialises dispatches)", pmc_p),
                 ("trtri", "gpp_trtri: batched pair merges, gpp_gemm_f64<2,64,64,0,16,2>", pmc_t),
                 ("lauum", "gpp_gemm_f64<2, 64, 64, 1, 16, 2> (Kinv = Linv^T Linv, ONE lower-triangular TN launch)", pmc_l)):
@@ -445,13 +445,19 @@ def run_sharded(args, dist, dev, rank, world, n, steps, warmup):
             out = step()
         return out
 
+    from gpplus_amd import sharded as _sh0
+
     run_steps(warmup)
     linalg.STAGE_EVENTS = []
+    _sh0.COMM_LOG = []  # every collective of the timed evaluations is bracketed by events on its stream
     elapsed, loss = _bracket(dist, dev, lambda: run_steps(steps))
     events, linalg.STAGE_EVENTS = (linalg.STAGE_EVENTS or []), None
+    comm_log, _sh0.COMM_LOG = _sh0.COMM_LOG, None
+    torch.cuda.synchronize()
+    comm = {k: {"calls": v["calls"] // steps, "bytes": v["bytes"] // steps, "comm_ms": v["comm_ms"] / steps}
+            for k, v in _sh0.comm_report(comm_log).items()}
     out = None
     # what a reader needs to see that the collective backend really formed `world` ranks on `world` devices, and what each holds
-    from gpplus_amd import sharded as _sh0
     mine = {"rank": rank, "device": int(torch.cuda.current_device()),
             "matrix_gb": round(sum(w.nbytes() for w in _sh0._workspaces.values()) / 1e9, 3)}
     ranks = [mine]
@@ -480,7 +486,10 @@ def run_sharded(args, dist, dev, rank, world, n, steps, warmup):
                "roofline": {"bound": "mfma", "kernel": "whole sharded evaluation, N^3 flop / (time x GPUs)",
                             "achieved": per_gpu_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
                             "frac": per_gpu_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": None},
-               "stages": {"ms": stage_ms, "tflops_per_gpu": stage_rate}}
+               "stages": {"ms": stage_ms, "tflops_per_gpu": stage_rate},
+               # per evaluation, rank 0's view: collectives issued, bytes they carried and the time they occupied their stream (the
+               # factor's broadcasts run on the communication stream beside the updates: comm_ms is NOT all exposed time)
+               "comm": comm}
     del model
     from gpplus_amd import sharded as _sh
     _sh._workspaces.clear()

@@ -688,6 +688,37 @@ hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64
   dl.max_tasks = 0; dl.quit_id = -1; dl.quit_val = 0; dl.ticket_limit = 0;
   dl.trace = P->d_trace; dl.tag = 0;
   static const int dag_workers = getenv("GPP_DAG_WORKERS") ? atoi(getenv("GPP_DAG_WORKERS")) : 0;
+  // GPP_DAG_PHASED=1 (profiling): the SAME ticket list executed as a sequence of launches on the caller's stream that never wait for
+  // each other — panel b, then one launch of the executor's kernel that stops in front of the first task that needs panel b + 1
+  // (the fillers' ticket limit, for every work-group), and so on.  Counter collection (rocprofv3 --pmc) serialises dispatches,
+  // under which the concurrent form cannot run; this form runs the same kernel over the same tasks in the same order, so its
+  // FETCH_SIZE / WRITE_SIZE describe the timed path's tiles (profiles/r05_potrf_pmc.json).
+  static const bool phased = getenv("GPP_DAG_PHASED") && atoi(getenv("GPP_DAG_PHASED")) != 0;
+  if (phased) {
+    const int wgs = 2 * h->ncu;
+    for (int b = 0; b < P->B; ++b) {
+      const int64_t o = (int64_t)P->tb[b] * NBLK, rows = std::min<int64_t>((int64_t)P->tb[b + 1] * NBLK, N) - o;
+      HIP_TRY(launch_panel(h, cm, o, rows, std::min(64, h->ncu)));
+      HIP_TRY(gpp_launch_exec_signal(cm.s, P->d_counters, P->c_pd + b));
+      DagLaunch pl = dl;
+      pl.ticket_limit = b + 1 < P->B ? P->level_first[b + 1] : 0;
+      pl.tag = b;
+      if (b + 1 == P->B || pl.ticket_limit > 0) HIP_TRY(gpp_launch_dag(cm.s, wgs, pl));
+      if (!(flags & DAG_INV) && h->inv_nblocks < 128) {
+        h->inv_o[h->inv_nblocks] = o;
+        h->inv_n[h->inv_nblocks] = rows;
+        ++h->inv_nblocks;
+      }
+    }
+    HIP_TRY(hipEventRecord(P->last_use, cm.s));
+    if (flags & DAG_INV) {
+      h->inv_nblocks = 1;
+      h->inv_o[0] = 0;
+      h->inv_n[0] = N;
+    }
+    *used = true;
+    return hipSuccess;
+  }
   HIP_TRY(gpp_launch_dag(cu.s, dag_workers > 0 ? dag_workers : 2 * (h->ncu - h->panel_cus), dl));
   for (const DagPlan::Op& op : P->stream_ops) {
     const int64_t o = op.kind < 3 ? (int64_t)P->tb[op.arg] * NBLK : 0;

@@ -540,6 +540,7 @@ DagPlan* emit(Planner& pl) {
     }
     for (int b = pl.B - 1; b >= 0; --b) first_of[b] = std::min(first_of[b], first_of[b + 1]);  // "level >= b"
   }
+  P->level_first = first_of;
   for (int t : pl.order) {
     const Node& n = pl.nodes[t];
     if (n.kind < 0) {

@@ -210,6 +210,7 @@ struct DagPlan {
                                        // n = the block whose gate ends it, lim = first ticket it must not take)
   std::vector<Op> stream_ops;
   std::vector<int> gate_target;
+  std::vector<int> level_first;        // per block b: the first ticket whose task needs the panel of block b or of a later one
   int ncounters = 0;
   int c_pd = 0, c_g1d = 0;             // first ids of the panel-done / gate counters (index by block)
   double sim_ms = 0, sim_busy = 0;     // the planner's own estimate (makespan, mean worker occupancy)

@@ -67,6 +67,20 @@ class _Comm:
         # request: the RCCL calls, their stream ordering and the buffer reuse then execute in a group of ONE rank too
         self.travel = self.world > 1 or os.environ.get("GPP_SHARDED_FORCE_COLLECTIVES", "0") not in ("", "0")
         self.calls = 0  # collectives issued (tests)
+        # per-collective timing (bench.py --mode sharded): (stage, bytes, start event, end event) on the stream the collective is
+        # enqueued on; read out by ``comm_report`` after a synchronisation.  Off unless a log list is attached.
+        self.log = None
+        self.stage = "factor"
+
+    def _timed(self, fn, nbytes: int) -> None:
+        if self.log is None:
+            fn()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        self.log.append((self.stage, nbytes, e0, e1))
 
     def _global(self, r: int) -> int:
         return r if self.group is None else dist.get_global_rank(self.group, r)
@@ -76,23 +90,47 @@ class _Comm:
             return
         self.calls += 1
         if self.direct:
-            dist.broadcast(t, self._global(src), group=self.group)
+            self._timed(lambda: dist.broadcast(t, self._global(src), group=self.group), t.numel() * t.element_size())
             return
-        h = t.detach().cpu() if self.rank == src else torch.empty(t.shape, dtype=t.dtype)
-        dist.broadcast(h, self._global(src), group=self.group)
-        if self.rank != src:
-            t.copy_(h)
+
+        def staged():
+            h = t.detach().cpu() if self.rank == src else torch.empty(t.shape, dtype=t.dtype)
+            dist.broadcast(h, self._global(src), group=self.group)
+            if self.rank != src:
+                t.copy_(h)
+
+        self._timed(staged, t.numel() * t.element_size())
 
     def allreduce(self, t: torch.Tensor, op=dist.ReduceOp.SUM) -> None:
         if not self.travel:
             return
         self.calls += 1
         if self.direct:
-            dist.all_reduce(t, op=op, group=self.group)
+            self._timed(lambda: dist.all_reduce(t, op=op, group=self.group), t.numel() * t.element_size())
             return
-        h = t.detach().cpu()
-        dist.all_reduce(h, op=op, group=self.group)
-        t.copy_(h)
+
+        def staged():
+            h = t.detach().cpu()
+            dist.all_reduce(h, op=op, group=self.group)
+            t.copy_(h)
+
+        self._timed(staged, t.numel() * t.element_size())
+
+
+#: bench.py attaches a list here to have every collective of the following evaluations timed with events (see _Comm._timed)
+COMM_LOG = None
+
+
+def comm_report(log) -> dict:
+    """Per stage: collectives issued, bytes moved and the sum of their durations on their stream in ms (after a device
+    synchronisation).  At one rank with GPP_SHARDED_FORCE_COLLECTIVES=1 this is the cost of the calls themselves."""
+    out = {}
+    for stage, nbytes, e0, e1 in log:
+        d = out.setdefault(stage, {"calls": 0, "bytes": 0, "comm_ms": 0.0})
+        d["calls"] += 1
+        d["bytes"] += int(nbytes)
+        d["comm_ms"] += e0.elapsed_time(e1)
+    return out
 
 
 class ShardedWorkspace:
@@ -479,6 +517,7 @@ class ShardedMLLFunction(torch.autograd.Function):
         Ud, wd, sd, td = f64(U), f64(w), f64(sf2).reshape(1), f64(tau).reshape(-1)
         if grp is not None and grp.dtype != torch.int32:
             grp = grp.to(torch.int32)
+        comm.log = COMM_LOG
         ws = _workspace(gctx, N, nb, comm.rank, comm.world)
         ws.epoch += 1
         jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
@@ -517,6 +556,7 @@ class ShardedMLLFunction(torch.autograd.Function):
         with _stage("shard_inverse"):
             _forward(gctx, comm, ws)
         torch.sub(f64(y), f64(mean), out=ws.r)
+        comm.stage = "vectors"
         _vectors(gctx, comm, ws, need_alpha=need_grad)
         if need_grad:
             with _stage("shard_backsolve"):
@@ -542,6 +582,7 @@ class ShardedMLLFunction(torch.autograd.Function):
         g_Ud = flat[D + 1 + S:].view(N, dU) if need_U else None
         gctx.grad_reduce_cols(Ud, wd, sd, grp, S, ws.alpha, ws.Lc, dU if need_U else 0, ws.nb, comm.rank, comm.world, g_w,
                               g_s, g_t, g_Ud, kind=kind, d_split=d_split, compact=True)
+        comm.stage = "grad"
         comm.allreduce(flat)
         ws.comm_calls = comm.calls
         g_U = None

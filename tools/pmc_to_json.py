@@ -1,5 +1,5 @@
-"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/collect_r04_profiles.sh) into the per-stage traffic records that
-bench.py reads: profiles/r04_{potrf,trtri,lauum}_pmc.json.  Each record carries the signature of the kernel build it was collected
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/collect_r05_profiles.sh) into the per-stage traffic records that
+bench.py reads: profiles/<ROUND>_{potrf,trtri,lauum}_pmc.json (ROUND from the environment, default r05).  Each record carries the signature of the kernel build it was collected
 with (gpp_version()), and bench.py refuses a record whose signature differs from the library it runs.
 Bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB — FETCH_SIZE counts 128-byte requests at 64 B on gfx950 (MI355X_MICROARCH.md, HBM) — per
 evaluation (the passes run tools/bench_stages.py N 8 1 = two evaluations).
@@ -9,6 +9,7 @@ import collections, csv, glob, json, os, sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 EVALS = 2
+ROUND = os.environ.get("ROUND", "r05")
 
 
 def sums(d, counter, only=None):
@@ -28,7 +29,7 @@ def main():
     from gpplus_amd import _lib
     sig = _lib.load().gpp_version().decode().split("src ")[-1]
     how = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of tools/bench_stages.py 20000 8 1 "
-           "(STAGES_ONLY selects the stages; two evaluations per pass, values per evaluation); bytes = (2*FETCH_SIZE + WRITE_SIZE) KB "
+           "(STAGES_ONLY selects the stages; two evaluations per pass, values per evaluation; GPP_DAG_PHASED=1: the factorisation's ticket list as a sequence of launches of the same kernel); bytes = (2*FETCH_SIZE + WRITE_SIZE) KB "
            "(gfx950 correction); fabric-side counters, Infinity-Cache hits included")
     fp, wp = sums(fP, "FETCH_SIZE"), sums(wP, "WRITE_SIZE")
     fpt, wpt = sums(fPT, "FETCH_SIZE"), sums(wPT, "WRITE_SIZE")
@@ -42,8 +43,8 @@ def main():
     }
     for name, (kernel, f, w, what) in recs.items():
         rec = {"kernel": kernel, "lib_signature": sig, "fetch_bytes_per_launch": 2 * f * 1024, "write_bytes_per_launch": w * 1024,
-               "traffic_bytes_per_launch": (2 * f + w) * 1024, "note": f"{how}; {what}; kernel build {sig}; profiles/r04_pmc_fetch_write.txt"}
-        with open(os.path.join(out, f"r04_{name}_pmc.json"), "w") as fh:
+               "traffic_bytes_per_launch": (2 * f + w) * 1024, "note": f"{how}; {what}; kernel build {sig}; profiles/{ROUND}_pmc_fetch_write.txt"}
+        with open(os.path.join(out, f"{ROUND}_{name}_pmc.json"), "w") as fh:
             json.dump(rec, fh, indent=1)
         print(f"{name:6s}: fetch {2 * f * 1024 / 1e9:8.2f} GB  write {w * 1024 / 1e9:7.2f} GB  total {(2 * f + w) * 1024 / 1e9:8.2f} GB per evaluation"
               f"   (algorithmic: 3.2 GB = read + write one triangle)")
