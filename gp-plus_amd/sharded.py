@@ -149,12 +149,18 @@ class ShardedWorkspace:
         self.Lc = torch.empty((N, wc), dtype=torch.float64, device=dev)
         self.Kc = torch.empty((N, wc), dtype=torch.float64, device=dev)
         self.D = torch.empty((nblk, nb, nb), dtype=torch.float64, device=dev)  # every diagonal block's inverse L_kk^-1 (+ mirror)
-        self.W = torch.empty((nb, self.A.stride(0)), dtype=torch.float64, device=dev)[:, :N]  # scratch of the row solves
+        # scratch of the row solves, THREE of them used in turn: the owner's consumers of a solved block row (next diagonal block,
+        # trailing updates, mirror, packing) read it HERE, and the copy into the factor's place happens off every critical path.
+        # (Three: step k's solve may overwrite what step k-3's bulk update read, and block row k's own last bulk update IS step
+        # k-3's — the chain already waits for it; with two, every panel waited for the bulk update two steps back: 56.6 -> 63.3 ms.)
+        self.W2 = [torch.empty((nb, self.A.stride(0)), dtype=torch.float64, device=dev)[:, :N] for _ in range(3)]
+        self.W = self.W2[0]
         self.Tk = torch.empty((nb, nb), dtype=torch.float64, device=dev)       # scratch of a diagonal block's factorisation
         self.ld = self.A.stride(0)
         self.pack = torch.empty(N * nb, dtype=torch.float64, device=dev)       # the packed tail of a row slab of the factor
         self.hbuf = torch.empty(3 * nb * nb, dtype=torch.float64, device=dev)  # its packed head: diagonal block, block k+1, inverse
         self.comm_stream = torch.cuda.Stream(device=dev)
+        self.copy_stream = torch.cuda.Stream(device=dev)
         self.dscr = torch.zeros(nb, nb, dtype=torch.float64, device=dev)       # scratch of the back-substitution's diagonal blocks
         self.z = torch.empty(N, dtype=torch.float64, device=dev)
         self.alpha = torch.empty(N, dtype=torch.float64, device=dev)
@@ -175,7 +181,7 @@ class ShardedWorkspace:
 
     def nbytes(self) -> int:
         """Device bytes of the matrices (what grows with N)."""
-        return sum(t.untyped_storage().nbytes() for t in (self.A, self.Lc, self.Kc, self.D, self.W, self.pack))
+        return sum(t.untyped_storage().nbytes() for t in (self.A, self.Lc, self.Kc, self.D, *self.W2, self.pack))
 
 
 _workspaces = {}
@@ -248,19 +254,22 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
     for k in owned(0, nblk):
         ctx.kernel_build(U, w, sf2, tau, grp, A, jitter=jitter, kind=kind, d_split=d_split, uplo=UPLO_FULL, row0=offs[k],
                          nrows=offs[k + 1] - offs[k])
-    for s in (side, upd, full, cs):
+    for s in (side, upd, full, cs, ws.copy_stream):
         s.wait_stream(main)
     rows = _RowEvents()   # latest update of each block row (the build is ordered before everything by the waits above)
     diag_ready = None     # DIAG(k): the diagonal block of the step about to start carries every update
     pending = None        # the bulk of the previous step's update, held back until this step's panel is enqueued
 
-    def row_update(i, c0, k_o, k_o1, stream):
-        """A[i, c0:] -= U[k, i]^T U[k, c0:] for block row i (columns from c0 on)."""
+    def row_update(i, c0, src, k_n, stream):
+        """A[i, c0:] -= U[k, i]^T U[k, c0:] for block row i (columns from c0 on); ``src``: where block row k of the factor is read
+        (all N columns addressed as in A)."""
         oi, oi1 = offs[i], offs[i + 1]
-        ctx.gemm(1, 0, oi1 - oi, N - c0, k_o1 - k_o, -1.0, A[k_o:k_o1, oi:oi1], A[k_o:k_o1, c0:N], 1.0, A[oi:oi1, c0:N])
+        ctx.gemm(1, 0, oi1 - oi, N - c0, k_n, -1.0, src[:, oi:oi1], src[:, c0:N], 1.0, A[oi:oi1, c0:N])
+
+    w_free = [None, None, None]  # per scratch row: the event behind its last reader (the step that used it three steps ago)
 
     def issue_bulk(job, after=None):
-        o_, o1_, first, arrived_ = job
+        o_, o1_, first, arrived_, src_, slot_ = job
         with torch.cuda.stream(full):
             full.wait_event(arrived_)
             if after is not None:
@@ -269,20 +278,40 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
             if bulk:
                 oc = offs[first]
                 rows.needed(bulk, full)
-                ctx.syrk_rows(A[o_:o1_, oc:N], A[oc:N, oc:N], nb, first, me, P)
+                ctx.syrk_rows(src_[:, oc:N], A[oc:N, oc:N], nb, first, me, P)
                 rows.produced(bulk, full)
-            if o1_ < N:  # the mirror L[o1:, k] = U[k, o1:]^T for the back-substitution (off every critical path)
-                ctx.transpose(A[o_:o1_, o1_:N], A[o1_:N, o_:o1_])
+            bulk_done = torch.cuda.Event()
+            bulk_done.record(full)
+        # off EVERY critical path, on a stream of their own (on ``full`` they sat between two steps' bulk updates: measured
+        # 56.6 -> 61.9 ms for the one-rank factor at C2): the mirror L[o1:, k] = U[k, o1:]^T for the back-substitution and, on the
+        # owner, the solved row into the factor's place, where the sweeps read it
+        cpy = ws.copy_stream
+        with torch.cuda.stream(cpy):
+            cpy.wait_event(arrived_)
+            if o1_ < N:
+                ctx.transpose(src_[:, o1_:N], A[o1_:N, o_:o1_])
+                if slot_ is not None:
+                    A[o_:o1_, o1_:N].copy_(src_[:, o1_:N])
+            if slot_ is not None:
+                cpy.wait_event(bulk_done)
+                w_free[slot_] = torch.cuda.Event()
+                w_free[slot_].record(cpy)
 
     for k in range(nblk):
         o, o1 = offs[k], offs[k + 1]
         o2 = offs[k + 2] if k + 2 <= nblk else N  # end of the head's columns (block k+1)
         nbk, own = o1 - o, (k % P == me)
         Lkk = ws.dblk(k)
-        W = ws.W[:nbk]  # scratch of the row solves (the product cannot run in place)
+        slot = k % 3 if own else None
+        W = ws.W2[k % 3][:nbk]  # scratch of the row solves (the product cannot run in place)
+        # where this step's consumers read block row k of the factor: the owner straight from the solve's output (round 5: the
+        # strided copies into A were ~0.2 ms each on the critical path of every step), the others from the unpacked slab in A
+        src = W if own else A[o:o1]
         head_solved = tail_solved = None
         if own:
             with torch.cuda.stream(side):
+                if w_free[slot] is not None:
+                    side.wait_event(w_free[slot])
                 if diag_ready is not None:
                     side.wait_event(diag_ready)
                 else:
@@ -297,7 +326,6 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
                 if o2 > o1:
                     rows.needed([k], side)  # block row k carries every update of the steps before k
                     ctx.gemm(1, 0, nbk, o2 - o1, nbk, 1.0, Lkk, A[o:o1, o1:o2], 0.0, W[:, o1:o2], a_mask=1, khi_mode=1)
-                    A[o:o1, o1:o2].copy_(W[:, o1:o2])
                 head_solved = torch.cuda.Event()
                 head_solved.record(side)
             if pending is not None:
@@ -306,11 +334,10 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
                 issue_bulk(pending, after=factored)
                 pending = None
             with torch.cuda.stream(upd):
-                upd.wait_event(factored)
+                upd.wait_event(factored)  # (which follows w_free[slot] on the panel stream)
                 rows.needed([k], upd)
                 if N > o2:  # the TAIL of the row (columns from block k+2 on): one wide launch on the throughput CUs
                     ctx.gemm(1, 0, nbk, N - o2, nbk, 1.0, Lkk, A[o:o1, o2:N], 0.0, W[:, o2:N], a_mask=1, khi_mode=1)
-                    A[o:o1, o2:N].copy_(W[:, o2:N])
                 upd.wait_event(head_solved)  # (TAIL below stands for the whole row)
                 tail_solved = torch.cuda.Event()
                 tail_solved.record(upd)
@@ -325,7 +352,8 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
                 dblk = ws.hbuf[nbk * wh:nbk * (wh + nbk)].view(nbk, nbk)
                 if own:
                     cs.wait_event(head_solved)
-                    head.copy_(A[o:o1, o:o2])
+                    head[:, :o1 - o].copy_(A[o:o1, o:o1])   # the factored diagonal block ...
+                    head[:, o1 - o:].copy_(W[:, o1:o2])      # ... and the solved head, from where the solve left it
                     dblk.copy_(Lkk)
                 comm.bcast(ws.hbuf[:nbk * (wh + nbk)], k % P)
                 if not own:
@@ -337,7 +365,7 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
                     tail = ws.pack[:nbk * (N - o2)].view(nbk, N - o2)
                     if own:
                         cs.wait_event(tail_solved)
-                        tail.copy_(A[o:o1, o2:N])
+                        tail.copy_(W[:, o2:N])
                     comm.bcast(ws.pack[:nbk * (N - o2)], k % P)
                     if not own:
                         A[o:o1, o2:N].copy_(tail)
@@ -359,26 +387,26 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
             with torch.cuda.stream(side):  # the next diagonal block, as soon as the head is here (panel CUs again)
                 side.wait_event(head_arrived)
                 rows.needed([k + 1], side)
-                ctx.gemm(1, 0, o2 - o1, o2 - o1, nbk, -1.0, A[o:o1, o1:o2], A[o:o1, o1:o2], 1.0, A[o1:o2, o1:o2], c_tri=2)
+                ctx.gemm(1, 0, o2 - o1, o2 - o1, nbk, -1.0, src[:, o1:o2], src[:, o1:o2], 1.0, A[o1:o2, o1:o2], c_tri=2)
                 diag_ready = torch.cuda.Event()
                 diag_ready.record(side)
         with torch.cuda.stream(upd):
             upd.wait_event(arrived)
             if panel_here and N > o2:
-                row_update(k + 1, o2, o, o1, upd)  # the rest of block row k+1: the next step's head and tail come from it
+                row_update(k + 1, o2, src, nbk, upd)  # the rest of block row k+1: the next step's head and tail come from it
                 rows.produced([k + 1], upd)
             for i in owned(k + 2, e_end):  # block row k+2 (the diagonal block after next), then the early rows: one launch each
                 rows.needed([i], upd)
-                row_update(i, offs[i], o, o1, upd)
+                row_update(i, offs[i], src, nbk, upd)
                 rows.produced([i], upd)
-        job = (o, o1, e_end, arrived)
+        job = (o, o1, e_end, arrived, src, slot)
         if panel_here:
             pending = job  # issued in the next iteration, behind that panel
         else:
             issue_bulk(job)
     if pending is not None:
         issue_bulk(pending)
-    for s in (side, upd, full, cs):
+    for s in (side, upd, full, cs, ws.copy_stream):
         main.wait_stream(s)
     info = ws.info.max().to(torch.int32).reshape(1)
     comm.allreduce(info, dist.ReduceOp.MAX)

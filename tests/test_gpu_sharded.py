@@ -52,8 +52,8 @@ def test_sharded_more_ranks_and_block_counts(world, N, D, nb, kind, S, dU):
     nblk = -(-N // nb)
     assert out["owned_cols"] == max(-(-nblk // world), 1) * nb, out
     if nblk >= 2 * world:
-        # (factor + two compact matrices + three nb-row strips: diagonal inverses, row-solve scratch, packing buffer)
-        assert out["matrix_bytes"] < (1.0 + 2.0 * (-(-nblk // world)) / nblk + 3.0 * nb / N + 0.1) * out["full_matrix_bytes"], out
+        # (factor + two compact matrices + five nb-row strips: diagonal inverses, three row-solve scratches, packing buffer)
+        assert out["matrix_bytes"] < (1.0 + 2.0 * (-(-nblk // world)) / nblk + 5.0 * nb / N + 0.1) * out["full_matrix_bytes"], out
 
 
 @pytest.mark.gpu
