@@ -619,6 +619,24 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
 // and every bordering product's few long tiles cost idle CUs (profiles/r04_timeline_n10000.txt: 16.3 ms for 10 ms of tile work).
 // Plans depend on (N, nb, leading dimensions, flags) only — the operands' addresses are kernel arguments — and live in a small LRU
 // per handle; nothing here synchronises the device.  *used = false: not applicable, the caller continues with the older paths.
+// what gpp_trtri will find inverted: the leading block the list built (all of the matrix: nothing left to merge), and every
+// diagonal block behind it
+void dag_note_inverted(gpp_handle_s* h, const DagPlan* P, int64_t N) {
+  h->inv_nblocks = 0;
+  if (P->inv_rows > 0) {
+    h->inv_o[0] = 0;
+    h->inv_n[0] = std::min(P->inv_rows, N);
+    h->inv_nblocks = 1;
+  }
+  for (int b = 0; b < P->B && h->inv_nblocks < 128; ++b) {
+    const int64_t o = (int64_t)P->tb[b] * NBLK, rows = std::min<int64_t>((int64_t)P->tb[b + 1] * NBLK, N) - o;
+    if (o < P->inv_rows) continue;
+    h->inv_o[h->inv_nblocks] = o;
+    h->inv_n[h->inv_nblocks] = rows;
+    ++h->inv_nblocks;
+  }
+}
+
 hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64_t ldt, bool* used) {
   *used = false;
   static const bool dag_env = !(getenv("GPP_DAG_SCHED") && atoi(getenv("GPP_DAG_SCHED")) == 0);
@@ -637,13 +655,27 @@ hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64
   if (h->cu_split != 1) return hipSuccess;
   const int64_t nb = dag_nb_env ? dag_nb_env : (N <= dag_nb_small ? 512 : 1024);
   if (nb % NBLK != 0 || !panel_fits(h, nb) || !panel_fits(h, nb + 256)) return hipSuccess;
-  const int flags = N <= dag_inv_max ? DAG_INV : 0;
+  // Above GPP_DAG_INV_MAX only the LEADING block of the inverse is built inside the list: its low-priority tasks fill the slots the
+  // factorisation leaves idle (start-up, the dips beside each panel, the chain-bound tail), and gpp_trtri, which treats a
+  // complete leading block like the diagonal blocks it finds inverted, merges the rest around it.  The block is a power of two
+  // times 1024 rows (the pair merges' alignment), by default the largest one <= 0.42 N (8192 of 20 000).
+  static const int64_t dag_inv_lead = getenv("GPP_DAG_INV_LEAD") ? atol(getenv("GPP_DAG_INV_LEAD")) : -1;
+  int64_t inv_rows = N;
+  if (N > dag_inv_max) {
+    inv_rows = 0;
+    if (dag_inv_lead < 0) {
+      for (int64_t r = 2 * nb; r <= (int64_t)(0.42 * (double)N); r *= 2) inv_rows = r;
+    } else if (dag_inv_lead >= 2 * nb && dag_inv_lead < N && dag_inv_lead % nb == 0) {
+      inv_rows = dag_inv_lead;
+    }
+  }
+  const int flags = inv_rows > 0 ? DAG_INV : 0;
   // the plan: a hit in the handle's LRU, or planned now (host only) and uploaded (a few MB, once per shape)
   DagPlan* P = nullptr;
   int slot = -1, lru = 0;
   for (int i = 0; i < 4; ++i) {
     DagPlan* q = h->dag_plans[i];
-    if (q && q->N == N && q->nb == nb && q->ld == cm.ld && q->ldi == cm.ldi && q->ldt == ldt && q->flags == flags) slot = i;
+    if (q && q->N == N && q->nb == nb && q->ld == cm.ld && q->ldi == cm.ldi && q->ldt == ldt && q->flags == flags && q->inv_rows == inv_rows) slot = i;
     if (!q) lru = i;
     else if (h->dag_plans[lru] && q->stamp < h->dag_plans[lru]->stamp) lru = i;
   }
@@ -652,6 +684,7 @@ hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64
     DagTuning tune = gpp_dag_default_tuning();
     tune.workers = 2 * (h->ncu - h->panel_cus);
     if (tune.fill > 0) tune.fill = 2 * h->panel_cus;
+    tune.inv_rows = inv_rows;
     P = gpp_dag_plan(N, nb, cm.ld, cm.ldi, ldt, 0, flags, tune);
     if (!P) return hipSuccess;
     for (int b = 0; b < P->B; ++b) {
@@ -704,18 +737,9 @@ hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64
       pl.ticket_limit = b + 1 < P->B ? P->level_first[b + 1] : 0;
       pl.tag = b;
       if (b + 1 == P->B || pl.ticket_limit > 0) HIP_TRY(gpp_launch_dag(cm.s, wgs, pl));
-      if (!(flags & DAG_INV) && h->inv_nblocks < 128) {
-        h->inv_o[h->inv_nblocks] = o;
-        h->inv_n[h->inv_nblocks] = rows;
-        ++h->inv_nblocks;
-      }
     }
     HIP_TRY(hipEventRecord(P->last_use, cm.s));
-    if (flags & DAG_INV) {
-      h->inv_nblocks = 1;
-      h->inv_o[0] = 0;
-      h->inv_n[0] = N;
-    }
+    dag_note_inverted(h, P, N);
     *used = true;
     return hipSuccess;
   }
@@ -727,11 +751,6 @@ hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64
     } else if (op.kind == 1) {
       const int64_t rows = std::min<int64_t>((int64_t)P->tb[op.arg + 1] * NBLK, N) - o;
       HIP_TRY(launch_panel(h, cp, o, rows, h->panel_cus));
-      if (!(flags & DAG_INV) && h->inv_nblocks < 128) {
-        h->inv_o[h->inv_nblocks] = o;
-        h->inv_n[h->inv_nblocks] = rows;
-        ++h->inv_nblocks;
-      }
     } else if (op.kind == 2) {
       HIP_TRY(gpp_launch_exec_signal(cp.s, P->d_counters, P->c_pd + op.arg));
     } else {
@@ -751,11 +770,7 @@ hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64
   HIP_TRY(hipStreamWaitEvent(cm.s, E, 0));
   HIP_TRY(hipStreamWaitEvent(cm.s, F, 0));
   HIP_TRY(hipEventRecord(P->last_use, cm.s));
-  if (flags & DAG_INV) {
-    h->inv_nblocks = 1;  // the inverse is complete: gpp_trtri has nothing left to merge
-    h->inv_o[0] = 0;
-    h->inv_n[0] = N;
-  }
+  dag_note_inverted(h, P, N);
   *used = true;
   return hipSuccess;
 }

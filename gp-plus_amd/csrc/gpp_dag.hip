@@ -46,6 +46,7 @@ struct Planner {
   int flags;
   DagTuning tune;
   int nt = 0, B = 0;
+  int inv_tiles = 0;                       // the inverse is built for the tile rows below this (block aligned)
   std::vector<int> tb;
   std::vector<GemmArgs> groups;
   std::vector<std::pair<int, int>> gmeta;  // per group: (kind, block)
@@ -127,6 +128,16 @@ struct Planner {
     tb.push_back(nt);
     B = (int)tb.size() - 1;
     if (B < 2) return false;
+    inv_tiles = 0;
+    if (flags & DAG_INV) {
+      inv_tiles = nt;
+      if (tune.inv_rows > 0 && tune.inv_rows < N) {
+        inv_tiles = (int)(tune.inv_rows / GPP_TILE);
+        bool aligned = false;
+        for (int b = 1; b <= B; ++b) aligned |= (tb[b] == inv_tiles);
+        if (!aligned || tune.inv_rows % GPP_TILE != 0) return false;
+      }
+    }
     c_pd = ncounters; ncounters += B;
     c_g1d = ncounters; ncounters += B;
     c_ur = ncounters; ncounters += B * nt;
@@ -156,7 +167,7 @@ struct Planner {
         if (k > 0) wait(p, G1D(k), ALL);
         inc(p, PD(k));
       }
-      if ((flags & DAG_INV) && k > 0) {
+      if ((flags & DAG_INV) && k > 0 && tb[k + 1] <= inv_tiles) {
         // XA(k; r, j): X[k rows, j] = -W_kk^T T[k rows, j] (+ mirror), j left of block k
         GemmArgs g{};
         g.A = off(o * ldi + o); g.lda = ldi; g.buf[0] = 1;
@@ -274,7 +285,7 @@ struct Planner {
         wait(n, SS(k, cc), ALL);
       }
       // ---- XB(k): the inverse's running sums ------------------------------------------------------------------------------------
-      if (flags & DAG_INV) {
+      if ((flags & DAG_INV) && tb[k + 1] < inv_tiles) {
         GemmArgs x0{};  // columns of block k: the first contribution (beta = 0), X_kk lower triangular
         x0.A = off(o * ldt + c0); x0.lda = ldt; x0.buf[0] = 2;
         x0.B = off(o * ldi + o); x0.ldb = ldi; x0.buf[1] = 1;
@@ -295,7 +306,7 @@ struct Planner {
           x1.b_mask = 0; x1.klo_mode = 0;
           g1 = add_group(x1, DK_XB, k);
         }
-        for (int i = lo; i < nt; ++i) {
+        for (int i = lo; i < inv_tiles; ++i) {
           const bool fin = i < hi;  // block row k+1: the sums of that block row are complete after this step
           for (int j = 0; j < lo; ++j) {
             const bool own = j >= tb[k];
@@ -521,6 +532,8 @@ DagPlan* emit(Planner& pl) {
   DagPlan* P = new DagPlan();
   P->N = pl.N; P->nb = pl.nb; P->ld = pl.ld; P->ldi = pl.ldi; P->ldt = pl.ldt; P->ldk = pl.ldk;
   P->flags = pl.flags;
+  P->inv_rows = (pl.flags & DAG_INV) ? (int64_t)pl.inv_tiles * GPP_TILE : 0;
+  if (P->inv_rows > pl.N) P->inv_rows = pl.N;
   P->B = pl.B; P->nt = pl.nt; P->tb = pl.tb;
   P->groups = pl.groups;
   P->ncounters = pl.ncounters;
@@ -586,6 +599,7 @@ DagTuning gpp_dag_default_tuning() {
   t.t_gate = 15.0;
   t.chain_tile = getenv("GPP_DAG_CHAIN_TILE") ? atoi(getenv("GPP_DAG_CHAIN_TILE")) : 64;
   t.workers = 448;
+  t.inv_rows = 0;
   t.fill = getenv("GPP_DAG_FILL") ? atoi(getenv("GPP_DAG_FILL")) : 64;
   return t;
 }
@@ -658,7 +672,10 @@ void gpp_dag_free(DagPlan* P) {
 // must then FAIL), the kind of the task that lost its wait * 10 + which counter family.
 extern "C" int gpp_debug_dag_check(int64_t N, int64_t nb, int flags, int chain_tile, int W, int fill, unsigned seed, int64_t* stats,
                                    int mutate) {
+  // (flags >= 4: flags >> 2 = rows of the leading block whose inverse is built inside the list, flags & 3 as usual)
   DagTuning tune = gpp_dag_default_tuning();
+  tune.inv_rows = (int64_t)(flags >> 2);
+  flags &= 3;
   tune.chain_tile = chain_tile;
   tune.fill = fill;
   tune.workers = std::max(W, 1);
@@ -919,7 +936,7 @@ extern "C" int gpp_debug_dag_check(int64_t N, int64_t nb, int flags, int chain_t
       if (!panel_done[b]) fail(80);
       for (int c = tb[b + 1]; c < nt && !rc; ++c)
         if (!copied[(size_t)b * nt + c]) fail(81);
-      if (flags & DAG_INV)
+      if ((flags & DAG_INV) && (int64_t)tb[b + 1] * 128 <= std::max<int64_t>(P->inv_rows, 0) + 127)
         for (int i = tb[b]; i < tb[b + 1] && !rc; ++i)
           for (int j = 0; j < tb[b]; ++j)
             if (!x_done[(size_t)i * nt + j]) { fail(82); break; }

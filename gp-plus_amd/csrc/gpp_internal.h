@@ -198,9 +198,11 @@ struct DagTuning {
   int chain_tile;             // tile of the chain's tasks (head solve, next diagonal block's update): 128 or 64
   int workers;                // workers the order is simulated for
   int fill;                   // filler work-groups per launch (0: no filler launches)
+  int64_t inv_rows;           // DAG_INV: rows of the inverse built inside the list — >= N: all of it; a multiple of nb below N: only
+                              // the leading inv_rows x inv_rows block (gpp_trtri then merges the rest around it)
 };
 struct DagPlan {
-  int64_t N = 0, nb = 0, ld = 0, ldi = 0, ldt = 0, ldk = 0;
+  int64_t N = 0, nb = 0, ld = 0, ldi = 0, ldt = 0, ldk = 0, inv_rows = 0;
   int flags = 0;                       // DAG_INV: also the inverse (right-looking), DAG_LAUUM: and Kinv
   int B = 0, nt = 0;
   std::vector<int> tb;                 // first tile of block b (tb[B] = nt)
