@@ -814,9 +814,13 @@ static DagPlan* dag_mru(gpp_handle_t h) {
       if (h->dag_plans[i] && (!P || h->dag_plans[i]->stamp > P->stamp)) P = h->dag_plans[i];
   return P;
 }
+// info[0..9]: tasks, groups, blocks, tiles per side, counters, simulated us, simulated busy per mille, flags, rows of the leading block
+// of the inverse built inside the list (N: all of it, 0: none), N
 int gpp_debug_dag_info(gpp_handle_t h, int64_t* info8) {
   const DagPlan* P = dag_mru(h);
   if (!P) return -1;
+  info8[8] = P->inv_rows;
+  info8[9] = P->N;
   info8[0] = (int64_t)P->tasks.size(); info8[1] = (int64_t)P->groups.size(); info8[2] = P->B; info8[3] = P->nt;
   info8[4] = P->ncounters; info8[5] = (int64_t)(P->sim_ms * 1000.0); info8[6] = (int64_t)(P->sim_busy * 1000.0); info8[7] = P->flags;
   return 0;

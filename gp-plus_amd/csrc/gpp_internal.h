@@ -184,10 +184,10 @@ struct DagLaunch {
   int tag;
 };
 hipError_t gpp_launch_dag(hipStream_t s, int nworkers, const DagLaunch& e);
-struct DagBases { char* p[4]; };  // operand bases the groups' byte offsets refer to: A, Linv, T, Kinv
+struct DagBases { char* p[4]; };  // operand bases the groups' byte offsets refer to: A, Linv, T (a fourth is unused)
 hipError_t gpp_launch_dag_bind(hipStream_t s, const GemmArgs* rel, GemmArgs* abs, int n, const DagBases& bases);
 
-enum { DK_S = 0, DK_U = 1, DK_CP = 2, DK_XB = 3, DK_XA = 4, DK_SH = 5, DK_UD = 6, DK_LU = 7, DK_NKINDS = 8 };
+enum { DK_S = 0, DK_U = 1, DK_CP = 2, DK_XB = 3, DK_XA = 4, DK_SH = 5, DK_UD = 6, DK_NKINDS = 7 };
 struct DagTuning {
   double t0_big, tc_big;      // us of a 128 x 128 tile task: t0 + tc * (K / 16)
   double t0_64, tc_64;        // 64 x 64 tile
@@ -203,7 +203,7 @@ struct DagTuning {
 };
 struct DagPlan {
   int64_t N = 0, nb = 0, ld = 0, ldi = 0, ldt = 0, ldk = 0, inv_rows = 0;
-  int flags = 0;                       // DAG_INV: also the inverse (right-looking), DAG_LAUUM: and Kinv
+  int flags = 0;                       // DAG_INV: also the inverse (right-looking; all of it or its leading inv_rows block)
   int B = 0, nt = 0;
   std::vector<int> tb;                 // first tile of block b (tb[B] = nt)
   std::vector<GemmArgs> groups;
@@ -224,7 +224,7 @@ struct DagPlan {
   hipEvent_t last_use = nullptr;       // recorded behind the launches that read the device copies
   uint64_t stamp = 0;                  // LRU
 };
-enum { DAG_INV = 1, DAG_LAUUM = 2 };
+enum { DAG_INV = 1 };
 DagPlan* gpp_dag_plan(int64_t N, int64_t nb, int64_t ld, int64_t ldi, int64_t ldt, int64_t ldk, int flags, const DagTuning& tune);
 DagTuning gpp_dag_default_tuning();
 hipError_t gpp_dag_upload(DagPlan* P);

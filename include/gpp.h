@@ -115,12 +115,16 @@ int gpp_cross_kernel(gpp_handle_t h, const double* Ua, int64_t Ma, const double*
  * them.
  */
 int gpp_potrf(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, int64_t ldi, int32_t* info_dev);
-/* Same, with an N x N scratch T (may be the Kinv buffer): for large N the look-ahead driver then also completes the
- * inverse of every diagonal block row it factors (hidden behind the trailing updates) and uses it to solve each wide
- * block-row panel with ONE GEMM; the following gpp_trtri on the same handle skips the merges that are already done.
- * For 3840 <= N <= 11264, where the factorisation is bound by its chain of diagonal blocks and most CUs would idle, it
- * also builds the WHOLE inverse by bordering on a further internal stream while it factors (Linv is complete on return
- * and the following gpp_trtri launches nothing): 16.3 -> 14.0 ms per evaluation at N = 8192, 26.5 -> 23.6 at 10000. */
+/* Same, with an N x N scratch T (may be the Kinv buffer): the driver then also completes the inverse of every diagonal block it
+ * factors and uses it to solve each block row with GEMMs; the following gpp_trtri on the same handle skips the merges that are
+ * already done.  By size (round 5; gpp_api.hip):
+ *   3840 <= N < 6656    look-ahead with launches on two CU-masked streams, the WHOLE inverse by bordering on a third beside it;
+ *   6656 <= N <= 40000  the DAG executor (gpp_dag.hip, gpp_dag_f64): factorisation — and up to N = 16384 the whole inverse, above
+ *                       that its leading 2^j x 1024-row block — as ONE list of tile tasks in topological order that persistent
+ *                       work-groups take by atomic ticket, the diagonal blocks as cooperative panel launches behind gate kernels
+ *                       (22.75 -> 20.6 ms per evaluation at N = 10000, 61.6 -> 59.9 at 15000, 131.0 -> 129.2 at 20000);
+ *   N > 40000           look-ahead with launches (the bulk of each update on a stream without a CU mask).
+ * Linv is complete on return wherever the inverse was built beside the factorisation (gpp_trtri then launches nothing). */
 int gpp_potrf_ws(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, int64_t ldi, double* T, int64_t ldt,
                  int32_t* info_dev);
 

@@ -11,12 +11,12 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpplus_amd.backend import get_context, square_buffer  # noqa: E402
 
-KINDS = ["S", "U", "CP", "XB", "XA", "SH", "UD", "LU"]
+KINDS = ["S", "U", "CP", "XB", "XA", "SH", "UD"]
 
 
 def trace_report(ctx, N):
     lib = ctx.lib
-    info = (ctypes.c_int64 * 8)()
+    info = (ctypes.c_int64 * 10)()
     if lib.gpp_debug_dag_info(ctx.h, info) != 0:
         print("  (no DAG plan on this handle)")
         return
