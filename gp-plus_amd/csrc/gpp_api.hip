@@ -685,6 +685,11 @@ hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64
     tune.workers = 2 * (h->ncu - h->panel_cus);
     if (tune.fill > 0) tune.fill = 2 * h->panel_cus;
     tune.inv_rows = inv_rows;
+    // fused steps (gpp_dag.hip): far tiles take 2 / 4 consecutive steps' updates in one task.  Measured, factor + inverse, same box
+    // (profiles/r05_dag_sweep.txt): 26.85 -> 25.97 ms at 13 000 with 2; 40.15 -> 38.98 -> 38.75 at 15 000, 87.9 -> 86.4 -> 86.3 at
+    // 20 000, 284.4 -> 278.7 -> 278.2 at 30 000 with 2 -> 4; below ~11 000 rows the longer tasks cost the chain more than the saved
+    // epilogues return (8.03 -> 8.19 ms at 8192 with 2; 13.42 -> 13.58 at 10 000 with 4)
+    if (!getenv("GPP_DAG_FUSE")) tune.fuse = N >= 14336 ? 4 : N >= 11264 ? 2 : 1;
     P = gpp_dag_plan(N, nb, cm.ld, cm.ldi, ldt, 0, flags, tune);
     if (!P) return hipSuccess;
     for (int b = 0; b < P->B; ++b) {

@@ -37,6 +37,7 @@ struct Node {
   int lvl = 0;                               // the last block whose panel the task (transitively) needs
   int w[3] = {-1, -1, -1}, v[3] = {0, 0, 0};
   int inc[2] = {-1, -1};
+  int incv[2] = {0, 0};  // amounts (a fused task raises its tile's version by the number of steps it applies)
   float cost = 0;
   double bl = 0;  // bottom level
 };
@@ -102,13 +103,14 @@ struct Planner {
     fprintf(stderr, "libgpp_hip: dag planner: more than three waits on a task\n");
     abort();
   }
-  void inc(int node, int c) {
+  void inc(int node, int c, int amount = 1) {
     if (c < 0) return;
     Node& n = nodes[node];
     for (int q = 0; q < 2; ++q)
       if (n.inc[q] < 0) {
         n.inc[q] = c;
-        incs[c].push_back(node);
+        n.incv[q] = amount;
+        for (int a = 0; a < amount; ++a) incs[c].push_back(node);  // (one entry per unit: "the v-th increment" stays meaningful)
         return;
       }
     fprintf(stderr, "libgpp_hip: dag planner: more than two increments on a task\n");
@@ -258,11 +260,48 @@ struct Planner {
             inc(n, G1D(k + 1));
           }
       }
-      for (int i = lo; i < nt; ++i)
+      // Fused steps (tune.fuse = 2 or 4): a tile far enough below the chain skips the updates of steps k0 .. k0 + f - 2 of an
+      // aligned group of f steps and takes all f together at step k0 + f - 1, as ONE task with K = the f blocks' rows (adjacent
+      // rows of T): one prologue, one read-modify-write of the tile and one ticket instead of f.  "Far enough": its block row is
+      // at least f + 1 below k0, so nothing of the next f steps' chain or look-ahead reads it.  The strips of the earlier steps are
+      // complete when those of the last one are (block row k + 1's solves follow its own last update, which followed step k's
+      // solves), so the last step's two strip counters and the version suffice — the host checker verifies that from the geometry.
+      auto fuse_of = [&](int bi, int kk) {  // how many steps the update of a tile in block row bi is grouped by at step kk
+        for (int f = std::min(tune.fuse, 4); f >= 2; f >>= 1) {
+          const int g0 = kk - kk % f;
+          if (g0 + f - 1 <= B - 2 && bi >= g0 + f + 1) return f;
+        }
+        return 1;
+      };
+      int gUf[5] = {-1, -1, -1, -1, -1};  // fused groups ending at this step, by f
+      int64_t Kf[5] = {0, 0, 0, 0, 0};
+      for (int f = 2; f <= std::min(tune.fuse, 4); f <<= 1) {
+        if (k % f != f - 1 || k - (f - 1) < 0) continue;
+        const int g0 = k - (f - 1);
+        GemmArgs uf = u;
+        const int64_t o_first = (int64_t)tb[g0] * 128;
+        Kf[f] = (int64_t)tb[k + 1] * 128 - o_first;  // rows of blocks g0 .. k
+        uf.A = off(o_first * ldt + c0);
+        uf.B = uf.A;
+        uf.K = (int)Kf[f];
+        gUf[f] = add_group(uf, DK_U, k);
+      }
+      for (int i = lo; i < nt; ++i) {
+        const int f = fuse_of(blk_of(i), k);
         for (int j = i; j < nt; ++j) {
           const bool in_next = i < hi;          // block row k+1: this is the tile's LAST update
           const bool diag = in_next && j < hi;  // inside diagonal block k+1
           if (diag && gUd >= 0) continue;
+          if (f > 1) {
+            const int g0 = k - k % f;
+            if (k != g0 + f - 1) continue;  // taken together with the group's last step
+            const int n = add_node(gUf[f], i - lo, j - lo, DK_U, tile_cost(128, Kf[f]));
+            if (g0 > 0) wait(n, VA(i, j), g0);
+            wait(n, SS(k, i), ALL);
+            if (j != i) wait(n, SS(k, j), ALL);
+            inc(n, VA(i, j), f);
+            continue;
+          }
           const int n = add_node(gU, i - lo, j - lo, DK_U, tile_cost(128, nbk));
           if (k > 0) wait(n, VA(i, j), k);
           wait(n, SS(k, i), ALL);
@@ -271,6 +310,7 @@ struct Planner {
           else if (in_next) inc(n, UR(k + 1, j));
           else inc(n, VA(i, j));
         }
+      }
       // ---- CP(k): the factor's block row into place -----------------------------------------------------------------------------
       GemmArgs c{};
       c.A = off(0); c.buf[0] = 2;
@@ -306,11 +346,48 @@ struct Planner {
           x1.b_mask = 0; x1.klo_mode = 0;
           g1 = add_group(x1, DK_XB, k);
         }
+        // fused steps for the sums as for the updates: a far tile whose column lies at or left of the group's first block takes
+        // the group's f contributions at its last step, with K = the f blocks' rows of T and of X (both adjacent); X's rows of the
+        // earlier blocks are final when the last one's are (each XA follows the sums the previous step completed)
+        int gXf0[5] = {-1, -1, -1, -1, -1}, gXf1[5] = {-1, -1, -1, -1, -1};
+        for (int f = 2; f <= std::min(tune.fuse, 4); f <<= 1) {
+          if (k % f != f - 1 || k - (f - 1) < 0) continue;
+          const int q0 = k - (f - 1);
+          const int64_t o_first = (int64_t)tb[q0] * 128;
+          GemmArgs y0 = x0;
+          y0.A = off(o_first * ldt + c0);
+          y0.B = off(o_first * ldi + o_first);
+          y0.C = offw(c0 * ldt + o_first);
+          y0.N = (int)rows_of(q0);
+          y0.K = (int)Kf[f];
+          gXf0[f] = add_group(y0, DK_XB, k);
+          if (q0 > 0) {
+            GemmArgs y1 = y0;
+            y1.B = off(o_first * ldi);
+            y1.C = offw(c0 * ldt);
+            y1.N = (int)o_first;
+            y1.beta = 1.0;
+            y1.b_mask = 0; y1.klo_mode = 0;
+            gXf1[f] = add_group(y1, DK_XB, k);
+          }
+        }
         for (int i = lo; i < inv_tiles; ++i) {
           const bool fin = i < hi;  // block row k+1: the sums of that block row are complete after this step
+          const int fz = fuse_of(blk_of(i), k), q0 = k - k % fz;
           for (int j = 0; j < lo; ++j) {
             const bool own = j >= tb[k];
             const int bj = blk_of(j);
+            if (fz > 1 && bj <= q0) {
+              if (k != q0 + fz - 1) continue;  // taken together with the group's last step
+              const bool own0 = bj == q0;
+              const int64_t K = own0 ? Kf[fz] - (int64_t)(j - tb[q0]) * 128 : Kf[fz];
+              const int n = add_node(own0 ? gXf0[fz] : gXf1[fz], i - lo, own0 ? j - tb[q0] : j, DK_XB, tile_cost(128, K));
+              wait(n, SS(k, i), ALL);
+              wait(n, XS(k, j), ALL);
+              if (q0 - bj > 0) wait(n, VT(i, j), q0 - bj);
+              inc(n, VT(i, j), fz);
+              continue;
+            }
             const int64_t K = own ? nbk - (int64_t)(j - tb[k]) * 128 : nbk;
             const int n = add_node(own ? g0 : g1, i - lo, own ? j - tb[k] : j, DK_XB, tile_cost(128, K));
             wait(n, SS(k, i), ALL);
@@ -352,6 +429,7 @@ struct Planner {
     for (int c = 0; c < ncounters; ++c)
       if (chain[c])
         for (size_t q = 1; q < incs[c].size(); ++q) {
+          if (incs[c][q] == incs[c][q - 1]) continue;  // the second increment of a fused pair
           const Node& n = nodes[incs[c][q]];
           bool ok = false;
           for (int z = 0; z < 3; ++z) ok |= (n.w[z] == c && n.v[z] == (int)q);
@@ -491,7 +569,7 @@ struct Planner {
       for (int q = 0; q < 2; ++q) {
         const int c = nodes[t].inc[q];
         if (c < 0) continue;
-        const int v = ++value[c];
+        const int v = (value[c] += nodes[t].incv[q]);
         auto& wl = waiters[c];
         while (wpos[c] < (int)wl.size() && wl[wpos[c]].need <= v) {
           const int u = wl[wpos[c]++].node;
@@ -578,6 +656,8 @@ DagPlan* emit(Planner& pl) {
     }
     d.inc_id[0] = n.inc[0];
     d.inc_id[1] = n.inc[1];
+    d.inc_val[0] = (int16_t)n.incv[0];
+    d.inc_val[1] = (int16_t)n.incv[1];
     d.kind = n.kind;
     P->tasks.push_back(d);
   }
@@ -600,6 +680,7 @@ DagTuning gpp_dag_default_tuning() {
   t.chain_tile = getenv("GPP_DAG_CHAIN_TILE") ? atoi(getenv("GPP_DAG_CHAIN_TILE")) : 64;
   t.workers = 448;
   t.inv_rows = 0;
+  t.fuse = getenv("GPP_DAG_FUSE") ? atoi(getenv("GPP_DAG_FUSE")) : 1;  // (potrf_dag chooses by size)
   t.fill = getenv("GPP_DAG_FILL") ? atoi(getenv("GPP_DAG_FILL")) : 64;
   return t;
 }
@@ -672,10 +753,15 @@ void gpp_dag_free(DagPlan* P) {
 // must then FAIL), the kind of the task that lost its wait * 10 + which counter family.
 extern "C" int gpp_debug_dag_check(int64_t N, int64_t nb, int flags, int chain_tile, int W, int fill, unsigned seed, int64_t* stats,
                                    int mutate) {
-  // (flags >= 4: flags >> 2 = rows of the leading block whose inverse is built inside the list, flags & 3 as usual)
+  // (flags >= 4: flags >> 2 = rows of the leading block whose inverse is built inside the list; flags & 1 = DAG_INV;
+  //  chain_tile / 1000 = the fusion factor (0: 1), chain_tile % 1000 the tile)
   DagTuning tune = gpp_dag_default_tuning();
   tune.inv_rows = (int64_t)(flags >> 2);
   flags &= 3;
+  if (chain_tile >= 1000) {
+    tune.fuse = chain_tile / 1000;
+    chain_tile %= 1000;
+  }
   tune.chain_tile = chain_tile;
   tune.fill = fill;
   tune.workers = std::max(W, 1);
@@ -775,14 +861,20 @@ extern "C" int gpp_debug_dag_check(int64_t N, int64_t nb, int flags, int chain_t
       if (t_done[(size_t)i * nt + c] >= t_need[(size_t)i * nt + c]) fail(13);
       ++t_done[(size_t)i * nt + c];
     } else if (g.kind == DK_U || g.kind == DK_UD) {
-      const int lo = tb[k + 1];
+      // a fused pair (K spans two blocks of T's rows): the updates of steps k and k + 1 at once, tiles relative to block k + 2
+      int f = 1;  // steps this task applies: K spans the rows of blocks k .. k + f - 1
+      if (g.kind == DK_U)
+        while (k + f < B && (int64_t)a.K > std::min<int64_t>((int64_t)tb[k + f] * 128, N) - (int64_t)tb[k] * 128) ++f;
+      const int lo = tb[k + f];
       const int i = lo + t.tm * et / 128, j = lo + t.tn * et / 128;
       if (i > j || j >= nt) fail(20);
-      if (!solved(k, i) || !solved(k, j)) fail(21);
+      for (int q = 0; q < f; ++q)
+        if (!solved(k + q, i) || !solved(k + q, j)) fail(q == 0 ? 21 : 24);
       if (a_upd[tixU(i, j)] != k) fail(22);
       if (g.kind == DK_U) {
         if (ud_need[tixU(i, j)] != 0 && blk_of(i) == k + 1 && blk_of(j) == k + 1) fail(23);  // tile covered twice
-        a_upd[tixU(i, j)] = k + 1;
+        if (f > 1 && blk_of(i) < k + f + 1) fail(25);  // a fused task on a tile the group's own steps depend on
+        a_upd[tixU(i, j)] = k + f;
       } else {
         if (++ud_done[tixU(i, j)] == ud_need[tixU(i, j)]) {
           ud_done[tixU(i, j)] = 0;
@@ -795,22 +887,26 @@ extern "C" int gpp_debug_dag_check(int64_t N, int64_t nb, int flags, int chain_t
       if (copied[(size_t)k * nt + c]) fail(31);
       copied[(size_t)k * nt + c] = 1;
     } else if (g.kind == DK_XB) {
-      const int lo = tb[k + 1];
+      int f = 1;  // contributions this task adds: K spans the rows of blocks k .. k + f - 1
+      while (k + f < B && (int64_t)a.K > std::min<int64_t>((int64_t)tb[k + f] * 128, N) - (int64_t)tb[k] * 128) ++f;
+      const int lo = tb[k + f];
       const int i = lo + t.tm;
       const bool own = a.beta == 0.0;
       const int j = own ? tb[k] + t.tn : t.tn;
       const int bj = blk_of(j);
-      if (!solved(k, i)) fail(40);
-      if (own) {
-        if (!panel_done[k]) fail(41);
-        if (bj != k) fail(42);
-      } else {
-        if (bj >= k) fail(42);
-        for (int r = tb[k]; r < tb[k + 1]; ++r)
-          if (!x_done[(size_t)r * nt + j]) fail(43);
+      if (own ? bj != k : bj >= k) fail(42);
+      if (f > 1 && blk_of(i) < k + f + 1) fail(45);
+      for (int q = 0; q < f; ++q) {
+        if (!solved(k + q, i)) fail(40);
+        if (k + q == bj) {
+          if (!panel_done[k + q]) fail(41);
+        } else {
+          for (int r = tb[k + q]; r < tb[k + q + 1]; ++r)
+            if (!x_done[(size_t)r * nt + j]) fail(43);
+        }
       }
       if (t_acc[(size_t)i * nt + j] != k - bj) fail(44);
-      ++t_acc[(size_t)i * nt + j];
+      t_acc[(size_t)i * nt + j] += f;
     } else if (g.kind == DK_XA) {
       const int i = tb[k] + t.tm, j = t.tn, bj = blk_of(j);
       if (!panel_done[k]) fail(50);
@@ -826,7 +922,7 @@ extern "C" int gpp_debug_dag_check(int64_t N, int64_t nb, int flags, int chain_t
       if (t.wait_id[q] >= 0) ++waits;
     for (int q = 0; q < 2; ++q)
       if (t.inc_id[q] >= 0) {
-        ++counters[t.inc_id[q]];
+        counters[t.inc_id[q]] += t.inc_val[q];
         ++nincs;
       }
     ++ran;

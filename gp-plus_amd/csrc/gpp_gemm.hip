@@ -670,8 +670,8 @@ __global__ __launch_bounds__(256, 2) void gpp_dag_f64(DagLaunch e) {
         // (the explicit wait between the write-back and the increments is REQUIRED: see panel_publish in gpp_leaf.hip)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (i0 >= 0) __hip_atomic_fetch_add(e.counters + i0, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (i1 >= 0) __hip_atomic_fetch_add(e.counters + i1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i0 >= 0) __hip_atomic_fetch_add(e.counters + i0, (int)tasks[idx].inc_val[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (i1 >= 0) __hip_atomic_fetch_add(e.counters + i1, (int)tasks[idx].inc_val[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     if (e.trace) {

@@ -167,9 +167,11 @@ struct DagTask {           // 48 bytes
   int16_t tm, tn;          // tile of that group's product (in units of the group's etile), or the strip of a copy
   int32_t wait_id[3];      // counters to wait for (-1: none) ...
   int32_t wait_val[3];     // ... until they are >= these values
-  int32_t inc_id[2];       // counters to increment once the task's stores are visible (-1: none)
+  int32_t inc_id[2];       // counters to raise once the task's stores are visible (-1: none) ...
   int32_t kind;            // semantic class (gpp_dag.hip: DK_*), for traces and the host-side checker
+  int16_t inc_val[2];      // ... by these amounts (a fused task that applies f steps' updates raises its tile's version by f)
 };
+static_assert(sizeof(DagTask) == 48, "the device reads 48-byte task records");
 struct DagLaunch {
   const GemmArgs* groups;  // the ABSOLUTE copy of the plan's groups (gpp_launch_dag_bind)
   const DagTask* tasks;
@@ -198,6 +200,8 @@ struct DagTuning {
   int chain_tile;             // tile of the chain's tasks (head solve, next diagonal block's update): 128 or 64
   int workers;                // workers the order is simulated for
   int fill;                   // filler work-groups per launch (0: no filler launches)
+  int fuse;                   // far tiles take the updates of up to `fuse` (1, 2 or 4) consecutive steps in ONE task with K = fuse x nb
+                              // (one prologue, one read-modify-write of the tile and one ticket instead of `fuse`)
   int64_t inv_rows;           // DAG_INV: rows of the inverse built inside the list — >= N: all of it; a multiple of nb below N: only
                               // the leading inv_rows x inv_rows block (gpp_trtri then merges the rest around it)
 };

@@ -399,6 +399,46 @@ def test_static_schedule_matches_the_launch_per_product_driver(gpu_ctx):
         gpu_ctx.set_option(OPT_EXEC_SCHED, 1)
 
 
+@pytest.mark.parametrize("n", [7300, 17400])
+def test_dag_list_equals_launches_at_its_range_ends(gpu_ctx, n):
+    """The DAG executor at the two ends of its range that the other tests do not reach: just above its lower threshold (the whole
+    inverse inside the list, a ragged last block) and above GPP_DAG_INV_MAX (only the leading 4096 / 8192-row block of the inverse
+    inside the list, gpp_trtri merges the rest around it) — against launches per product + pair merges on the same matrix: same
+    factor and inverse to rounding, L X = I on a probe vector, the mirror exact, and bit-for-bit repeatable."""
+    from gpplus_amd.backend import OPT_DAG_SCHED
+
+    g = torch.Generator(device="cuda").manual_seed(n)
+    U = torch.randn(n, 6, dtype=torch.float64, device="cuda", generator=g)
+    w = torch.full((6,), 0.2, dtype=torch.float64, device="cuda")
+    sf2 = torch.tensor([0.9], dtype=torch.float64, device="cuda")
+    tau = torch.tensor([3e-3], dtype=torch.float64, device="cuda")
+    A, Li, T = _sq(n), _sq(n, 0.0), _sq(n)
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    res = {}
+    try:
+        for on in (0, 1, 1):
+            gpu_ctx.set_option(OPT_DAG_SCHED, on)
+            gpu_ctx.kernel_build(U, w, sf2, tau, None, A, uplo=2)
+            Li.zero_()
+            gpu_ctx.potrf(A, Li, info, T)
+            gpu_ctx.trtri(A, Li, T)
+            assert int(info.item()) == 0
+            cur = (torch.triu(A).clone(), Li.clone())
+            if on in res:
+                assert torch.equal(res[on][0], cur[0]) and torch.equal(res[on][1], cur[1])  # repeatable bit for bit
+            res[on] = cur
+    finally:
+        gpu_ctx.set_option(OPT_DAG_SCHED, 1)
+    scale = float(res[0][0].abs().max())
+    assert float((res[0][0] - res[1][0]).abs().max()) <= 1e-12 * scale
+    li0, li1 = torch.tril(res[0][1]), torch.tril(res[1][1])
+    assert float((li0 - li1).abs().max()) <= 1e-10 * float(li0.abs().max())
+    assert float((torch.triu(res[1][1], 1) - torch.tril(res[1][1], -1).T).abs().max()) == 0.0
+    v = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
+    Lv = torch.mv(res[1][0].T, torch.mv(li1, v))  # L (X v), L = U^T
+    assert float((Lv - v).norm() / v.norm()) <= 1e-9
+
+
 def test_panel_timeout_is_recovered_by_the_host(gpu_ctx):
     """GPP_OPT_PANEL_FAULT makes the next panel launch report the time-out status (what a wait inside the kernel reports after ~1 s
     when another tenant of the GPU holds part of its CUs).  The C ABI returns it in ``info``; ``linalg`` switches the panel off for

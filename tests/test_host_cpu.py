@@ -300,7 +300,9 @@ def _dag_check():
     (4096, 1024, 1, 64, 448, 64), (7168, 1024, 1, 64, 448, 64), (10000, 1024, 1, 64, 448, 64), (10000, 1024, 0, 128, 448, 0),
     (9300, 1024, 1, 64, 30, 6),      # a last block of 84 rows joins its neighbour
     (5000, 512, 1, 64, 1, 0),        # ONE worker executes the list in order: the order itself must be topological
-    (11264, 1024, 1, 128, 7, 2), (13500, 1024, 1, 64, 448, 64), (15000, 1024, 0, 64, 448, 64), (20001, 1024, 0, 64, 448, 64)])
+    (11264, 1024, 1, 128, 7, 2), (13500, 1024, 1, 2064, 448, 64), (15000, 1024, 0, 4064, 448, 64), (20001, 1024, 0, 64, 448, 64),
+    (20000, 1024, 1 + (8192 << 2), 4064, 448, 64),   # as at C2: fused groups of 4 steps, the leading 8192 rows of the inverse inside
+    (15000, 1024, 1, 4064, 1, 0), (9300, 1024, 1, 2064, 30, 6)])
 def test_dag_plan_is_a_valid_schedule_under_any_interleaving(N, nb, flags, chain_tile, W, fill):
     """The ticket list of the DAG executor (gpp_dag.hip: factorisation, and with flags = 1 the right-looking inverse beside it),
     executed on the host by W workers + filler launches in random and adversarial interleavings that respect only what the device
@@ -308,7 +310,8 @@ def test_dag_plan_is_a_valid_schedule_under_any_interleaving(N, nb, flags, chain
     updates in order and exactly once, solves read fully updated, not yet overwritten block rows of a factored diagonal block,
     updates read completely solved strips, panels start on fully updated blocks, the inverse's sums take their contributions in
     order from finished rows, nothing deadlocks (a filler launch in front of a panel never holds a task that needs that panel),
-    everything is complete at the end."""
+    everything is complete at the end.  (chain_tile // 1000 = the fusion factor: far tiles take that many steps' updates — and the
+    inverse's sums that many contributions — in one task; flags >> 2 = rows of the inverse's leading block built inside the list.)"""
     f, st = _dag_check()
     for seed in range(8):
         rc = f(N, nb, flags, chain_tile, W, fill, seed, st, 0)
