@@ -21,7 +21,8 @@ def trace_report(ctx, N):
         print("  (no DAG plan on this handle)")
         return
     nt = int(info[0])
-    tasks = np.zeros(nt, dtype=np.dtype([("group", "i4"), ("tm", "i2"), ("tn", "i2"), ("w", "i4", 3), ("v", "i4", 3), ("inc", "i4", 2), ("kind", "i4")]))
+    tasks = np.zeros(nt, dtype=np.dtype([("group", "i4"), ("tm", "i2"), ("tn", "i2"), ("w", "i4", 3), ("v", "i4", 3), ("inc", "i4", 2), ("kind", "i4"), ("incv", "i2", 2)]))
+    assert tasks.dtype.itemsize == 48
     trace = np.zeros((nt, 4), dtype=np.uint64)
     rc = lib.gpp_debug_dag_fetch(ctx.h, tasks.ctypes.data_as(ctypes.c_void_p), trace.ctypes.data_as(ctypes.c_void_p))
     assert rc == 0, rc
