@@ -13,8 +13,11 @@
 //   XA(m; r, j)   inverse, rows  X[m rows, j] = -X_mm T[m rows, j] (+ mirror)     j left of block m   (K <= nb, triangular)
 // (XB / XA: with S_m = sum_{k<m} L[m,k] X[k,:] accumulated in the lower-left part of T, X[m,:m) = -X_mm S_m — the sharded forward
 // sweep's recurrence; the solved block rows live in the upper-right part of T, so the two uses of the scratch never meet.)
+// (Above GPP_DAG_INV_MAX rows only the leading inv_rows x inv_rows block of X is built here, gpp_trtri merges the rest around it.)
+// FUSED STEPS: a tile at least f + 1 block rows below an aligned group of f steps takes the group's f updates (or the sum's f
+// contributions) in ONE task at the group's last step, with K = the f blocks' rows — see generate().
 // Every dependency is a monotone counter: strip counters (all tasks of a strip done) and per-tile version counters (the k-th
-// contribution to a tile follows the (k-1)-th).  The ORDER of the list is that of a list-scheduling simulation (priority = longest
+// contribution to a tile follows the (k-1)-th; a fused task raises its tile's version by f).  The ORDER of the list is that of a list-scheduling simulation (priority = longest
 // path to the end of the graph, cost model in DagTuning): with it a work-group that takes the next ticket finds its task ready or
 // nearly so, chain tasks (head solve, next diagonal block's update) are taken the moment they can run, and the inverse's tasks fill
 // whatever the factorisation's chain leaves idle.  Any topological order is CORRECT; the simulation only decides how good it is.

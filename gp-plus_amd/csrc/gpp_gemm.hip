@@ -187,10 +187,15 @@ __device__ __forceinline__ void load_fast(const double* __restrict__ ubase, cons
 // the kernel arguments) and the DAG executor (gpp_dag_f64, p in a device array read through the constant address
 // space: scalar loads, re-materialisable like kernel arguments).  A, B, C: the batch element's operands,
 // C2: its mirrored output (or null).  Ends with a work-group barrier after the last LDS read, so the caller may stage another tile at once.
-template <int VAR, int WTM, int WTN, int TAG, int BK, int NBUF, int WR, class P>
+struct GemmNoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
+// (`before_epilogue`: called by every thread after the last MFMA and before the first access to C — the DAG executor issues its
+//  next ticket's atomic there, so that its latency runs under the epilogue)
+template <int VAR, int WTM, int WTN, int TAG, int BK, int NBUF, int WR, class P, class H = GemmNoHook>
 __device__ __forceinline__ void gemm_tile(const P& p, const int tm, const int tn, const double* __restrict__ A,
                                           const double* __restrict__ B, double* __restrict__ C, double* C2,
-                                          double* __restrict__ smem) {
+                                          double* __restrict__ smem, H before_epilogue = H()) {
   static_assert(BK == 16 || VAR == 2, "wide K chunks are implemented for row-contiguous (TN) operands only");
   static_assert(BK % 16 == 0 && (NBUF == 1 || NBUF == 2), "bad staging parameters");
   static_assert(WR == 2 || (WR == 4 && VAR == 2 && BK == 16 && NBUF == 2 && WTM == 64 && WTN == 64), "the tall tile is TN only");
@@ -380,6 +385,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const int tm, const int tn
     }
   }
   for (; c < nch; ++c) general_iter(c);
+  before_epilogue();
 
   // epilogue: slab (a,b) holds C[row0+wm+4a+(l>>4)][col0+wn+16b+(l&15)].  The beta path first issues all C loads of a
   // group of slabs (clamped addresses, no branches around loads) and only then combines and stores.
@@ -590,24 +596,27 @@ __global__ __launch_bounds__(256, 2) void gpp_dag_f64(DagLaunch e) {
   CDagTask* tasks = (CDagTask*)e.tasks;
   CGemmArgs* groups = (CGemmArgs*)e.groups;
 #pragma clang diagnostic pop
+  // The ticket of the NEXT task is taken just before the current tile's epilogue (thread 0; the value is consumed after the task's
+  // increments), so the atomic's round trip runs under the epilogue's own memory traffic.  A work-group then holds two tickets for
+  // those few microseconds, its current one always the smaller: the earliest unfinished task is still some work-group's CURRENT
+  // task, so progress is as before.  (Earlier than the epilogue the next task — possibly a chain task — would sit behind a whole tile.)
+  int pre = -2;  // thread 0: -2 nothing taken ahead, -1 stop, >= 0 ticket
+  auto take = [&](int done_after) -> int {  // thread 0 only
+    // (main workers: no budget, no quit flag, no limit — nothing but the atomic; the abort word is seen by the waits)
+    if (e.max_tasks > 0 && done_after >= e.max_tasks) return -1;
+    if (e.quit_id >= 0 && (exec_load(e.counters) != 0 || exec_load(e.counters + e.quit_id) >= e.quit_val)) return -1;
+    if (e.ticket_limit <= 0) return __hip_atomic_fetch_add(e.counters + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // a filler launch in front of a panel never takes a task that needs that panel: the launch could not end (gpp_dag.hip)
+    int old = exec_load(e.counters + 1);
+    while (old < e.ticket_limit &&
+           !__hip_atomic_compare_exchange_strong(e.counters + 1, &old, old + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    }
+    return old < e.ticket_limit ? old : -1;
+  };
   for (int done = 0;; ++done) {
     if (tid == 0) {
-      int idx = -1;
-      const bool stop = (e.max_tasks > 0 && done >= e.max_tasks) || exec_load(e.counters) != 0 ||
-                        (e.quit_id >= 0 && exec_load(e.counters + e.quit_id) >= e.quit_val);
-      if (!stop) {
-        if (e.ticket_limit <= 0) {
-          idx = __hip_atomic_fetch_add(e.counters + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-          // a filler launch in front of a panel never takes a task that needs that panel: the launch could not end (gpp_dag.hip)
-          int old = exec_load(e.counters + 1);
-          while (old < e.ticket_limit &&
-                 !__hip_atomic_compare_exchange_strong(e.counters + 1, &old, old + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-          }
-          if (old < e.ticket_limit) idx = old;
-        }
-      }
-      s_idx = idx;
+      s_idx = pre != -2 ? pre : take(done);
+      pre = -2;
     }
     __syncthreads();
     const int idx = __builtin_amdgcn_readfirstlane(s_idx);
@@ -620,8 +629,15 @@ __global__ __launch_bounds__(256, 2) void gpp_dag_f64(DagLaunch e) {
     const int w0 = tasks[idx].wait_id[0], w1 = tasks[idx].wait_id[1], w2 = tasks[idx].wait_id[2];
     if (w0 >= 0 || w1 >= 0 || w2 >= 0) {
       if (tid == 0) {
-        bool ok = exec_poll(e.counters, w0, tasks[idx].wait_val[0], w1, tasks[idx].wait_val[1], e.budget, e.info, GPP_INFO_EXEC_TIMEOUT);
-        if (ok && w2 >= 0) ok = exec_poll(e.counters, w2, tasks[idx].wait_val[2], -1, 0, e.budget, e.info, GPP_INFO_EXEC_TIMEOUT);
+        // (fast path: all three counters' loads in flight together; the polling loop only when one of them is not there yet)
+        const int v0 = tasks[idx].wait_val[0], v1 = tasks[idx].wait_val[1], v2 = tasks[idx].wait_val[2];
+        const int c0 = w0 >= 0 ? exec_load(e.counters + w0) : v0, c1 = w1 >= 0 ? exec_load(e.counters + w1) : v1,
+                  c2 = w2 >= 0 ? exec_load(e.counters + w2) : v2;
+        bool ok = (c0 >= v0) & (c1 >= v1) & (c2 >= v2);
+        if (!ok) {
+          ok = exec_poll(e.counters, w0, v0, w1, v1, e.budget, e.info, GPP_INFO_EXEC_TIMEOUT);
+          if (ok && w2 >= 0) ok = exec_poll(e.counters, w2, v2, -1, 0, e.budget, e.info, GPP_INFO_EXEC_TIMEOUT);
+        }
         s_ok = ok ? 1 : 0;
       }
       __syncthreads();
@@ -634,8 +650,11 @@ __global__ __launch_bounds__(256, 2) void gpp_dag_f64(DagLaunch e) {
     const CGemmArgs& p = groups[tasks[idx].group];
     const int tm = tasks[idx].tm, tn = tasks[idx].tn;
     if (p.op == 0) {
+      auto ahead = [&]() {
+        if (tid == 0) pre = take(done + 1);
+      };
       if (p.etile == 64) gemm_tile<2, 32, 32, 0, 64, 1, 2>(p, tm, tn, p.A, p.B, p.C, p.C2, smem);
-      else gemm_tile<2, 64, 64, 0, 16, 2, 2>(p, tm, tn, p.A, p.B, p.C, p.C2, smem);
+      else gemm_tile<2, 64, 64, 0, 16, 2, 2>(p, tm, tn, p.A, p.B, p.C, p.C2, smem, ahead);
     } else {
       // copy the M x 128 strip tn of B into C: 64 16-byte vectors per row, 4 rows per pass, 8 passes in flight
       const int c = tn * 128 + ((tid & 63) << 1), r4 = tid >> 6;
