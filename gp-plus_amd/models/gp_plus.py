@@ -518,10 +518,42 @@ class GP_Plus(GPR):
 
 
 # ---------------------------------------------------------------------------------------------------------
+class _TallLinear(torch.autograd.Function):
+    """``x @ w.T`` for a TALL constant input x (N x L one-hot rows of the categorical levels, no gradient) and a small weight
+    (d_z x L): the forward is the library GEMM; the weight gradient ``g.T @ x`` is a (d_z x N)(N x L) product with a 2 x 10 result and
+    K = N, for which the BLAS picks one work-group (284 us at N = 10 000, 1.4 % of a C3 evaluation: profiles/EXPERIMENTS.md, round
+    5).  Here it is 64 batched partial products over row blocks + one sum: a fixed summation order, ~15 us."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x)
+        return nn.functional.linear(x, w)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        n, nb = x.shape[0], 64
+        m = (n // nb) * nb
+        gw = torch.bmm(g[:m].reshape(nb, m // nb, g.shape[1]).transpose(1, 2), x[:m].reshape(nb, m // nb, x.shape[1])).sum(0)
+        if m < n:
+            gw = gw + g[m:].t() @ x[m:]
+        return None, gw
+
+
+def _linear_tall(x, w):
+    """The manifold map of the training rows: the batched-gradient form for tall constant inputs on a GPU, F.linear otherwise."""
+    # (above the batched-restart range, N <= 6144, whose driver vectorises the model's own code with vmap: plain ops there)
+    if x.dim() == 2 and x.shape[0] > 6144 and not x.requires_grad and x.is_cuda and w.dim() == 2:
+        return _TallLinear.apply(x, w)
+    return nn.functional.linear(x, w)
+
+
 class Linear_MAP(nn.Linear):
     """gp_plus.py:1456-1461."""
 
     def forward(self, input, transform=lambda x: x):
+        if self.bias is None:
+            return _linear_tall(input, transform(self.weight))
         return nn.functional.linear(input, transform(self.weight), self.bias)
 
 
@@ -563,4 +595,4 @@ class FFNN(nn.Module):
             for w in ws[:-1]:
                 x = torch.tanh(nn.functional.linear(x, w))
             return nn.functional.linear(x, ws[-1])
-        return nn.functional.linear(x, transform(ws[0]))
+        return _linear_tall(x, transform(ws[0]))
