@@ -399,10 +399,10 @@ def test_static_schedule_matches_the_launch_per_product_driver(gpu_ctx):
         gpu_ctx.set_option(OPT_EXEC_SCHED, 1)
 
 
-@pytest.mark.parametrize("n", [7300, 17400])
+@pytest.mark.parametrize("n", [7300, 20200])
 def test_dag_list_equals_launches_at_its_range_ends(gpu_ctx, n):
     """The DAG executor at the two ends of its range that the other tests do not reach: just above its lower threshold (the whole
-    inverse inside the list, a ragged last block) and above GPP_DAG_INV_MAX (only the leading 4096 / 8192-row block of the inverse
+    inverse inside the list, a ragged last block) and above GPP_DAG_INV_MAX = 19 456 (only the leading 8192-row block of the inverse
     inside the list, gpp_trtri merges the rest around it) — against launches per product + pair merges on the same matrix: same
     factor and inverse to rounding, L X = I on a probe vector, the mirror exact, and bit-for-bit repeatable."""
     from gpplus_amd.backend import OPT_DAG_SCHED
