@@ -640,13 +640,13 @@ void dag_note_inverted(gpp_handle_s* h, const DagPlan* P, int64_t N) {
 hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64_t ldt, bool* used) {
   *used = false;
   static const bool dag_env = !(getenv("GPP_DAG_SCHED") && atoi(getenv("GPP_DAG_SCHED")) == 0);
-  // Measured on one box, potrf + inverse (tools/sweep_dag.sh, profiles/r05_dag_sweep.txt): launches win below ~6700 rows, where the
+  // Measured on one box, potrf + inverse (tools/sweep_dag.sh, profiles/r05_dag_sweep.txt): launches win below ~6900 rows, where the
   // chain of diagonal blocks is all there is (4.99 vs 5.39 ms at 6144), the ticket list from there (6.35 vs 6.82 at 7168, 8.05 vs
   // 9.16 at 8192, 13.45 vs 15.68 at 10 000, 18.14 vs 20.46 at 11 264).  With the inverse inside the list up to ~19 000 rows (22.64 vs
   // 24.73 at 12 288, 40.19 vs 41.97 at 15 000); above, the inverse's K = 1024 tiles on 503 slots lose to gpp_trtri's long-K launches on
   // 256 CUs and only the factorisation (+ the leading block of the inverse) runs here (88.23 vs 89.51 at 20 000 with the round-4
   // executor, 284.8 vs 287.1 at 30 000; with the fused steps 86.3 and 278.2).
-  static const int64_t dag_min = getenv("GPP_DAG_MIN_N") ? atol(getenv("GPP_DAG_MIN_N")) : 6656;
+  static const int64_t dag_min = getenv("GPP_DAG_MIN_N") ? atol(getenv("GPP_DAG_MIN_N")) : 6912;  // (6656: 5.98 vs 5.78 ms for launches; 7168: 6.32 vs 6.82)
   // (up to 65 536 rows since the fused steps: 645.9 vs 663.3 ms at 40 000, 1253 vs 1286 at 50 000, 2165 vs 2213 at 60 000 against
   //  the launch path; without them the list lost at 60 000.  Planning a 60 000-row list takes ~1.2 s of host time, once per size.)
   static const int64_t dag_max = getenv("GPP_DAG_MAX_N") ? atol(getenv("GPP_DAG_MAX_N")) : 65536;

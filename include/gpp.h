@@ -78,7 +78,7 @@ int gpp_internal_stream(gpp_handle_t h, int which, void** out);
 #define GPP_OPT_PANEL_FAULT 2
 #define GPP_OPT_PANEL_TIMEOUT_MS 3
 #define GPP_OPT_EXEC_SCHED 4 /* (round 4's statically scheduled executor, replaced by the DAG executor: an alias of GPP_OPT_DAG_SCHED) */
-#define GPP_OPT_DAG_SCHED 5  /* default 1 (0 with GPP_DAG_SCHED=0): factorisation (and, for 6656 <= N <= GPP_DAG_INV_MAX = 19456, the whole inverse
+#define GPP_OPT_DAG_SCHED 5  /* default 1 (0 with GPP_DAG_SCHED=0): factorisation (and, for 6912 <= N <= GPP_DAG_INV_MAX = 19456, the whole inverse
                               * beside it) as ONE list of tile tasks in topological order that persistent work-groups take by atomic
                               * ticket (gpp_dag.hip, gpp_dag_f64) — needs no co-residency of its work-groups; the diagonal blocks still
                               * run as cooperative panel launches (GPP_OPT_COOP_PANEL) */
@@ -118,8 +118,8 @@ int gpp_potrf(gpp_handle_t h, double* A, int64_t N, int64_t ld, double* Linv, in
 /* Same, with an N x N scratch T (may be the Kinv buffer): the driver then also completes the inverse of every diagonal block it
  * factors and uses it to solve each block row with GEMMs; the following gpp_trtri on the same handle skips the merges that are
  * already done.  By size (round 5; gpp_api.hip):
- *   3840 <= N < 6656    look-ahead with launches on two CU-masked streams, the WHOLE inverse by bordering on a third beside it;
- *   6656 <= N <= 65536  the DAG executor (gpp_dag.hip, gpp_dag_f64): factorisation — and up to N = 19456 the whole inverse, above
+ *   3840 <= N < 6912    look-ahead with launches on two CU-masked streams, the WHOLE inverse by bordering on a third beside it;
+ *   6912 <= N <= 65536  the DAG executor (gpp_dag.hip, gpp_dag_f64): factorisation — and up to N = 19456 the whole inverse, above
  *                       that its leading 2^j x 1024-row block — as ONE list of tile tasks in topological order that persistent
  *                       work-groups take by atomic ticket, the diagonal blocks as cooperative panel launches behind gate kernels
  *                       (22.75 -> 20.6 ms per evaluation at N = 10000, 61.6 -> 59.9 at 15000, 131.0 -> 129.2 at 20000);
