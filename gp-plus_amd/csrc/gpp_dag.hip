@@ -671,15 +671,18 @@ DagPlan* emit(Planner& pl) {
 
 DagTuning gpp_dag_default_tuning() {
   DagTuning t;
-  // two work-groups per CU, measured per task with tools/dag_trace.py (K = 1024: ~250 us for the big tile)
+  // two work-groups per CU, measured per task with TRACE=1 tools/dag_check.py (profiles/r05_dag_traces.txt): the big tile 264 us at
+  // K = 1024 and 1035 at 4096; the 64-tile 60 us at a mean K of 576 and 105 at 1024; a strip copy 150-180 us (latency-bound beside
+  // the MFMA work); a panel 620-640 us for 8 leaves.  The ORDER of the list is only as good as these: with the first guesses
+  // (3.7 us per chunk, 0.75 for the 64-tile, 12 us per copy, 580 us per panel) chain tasks were taken ~70 us before they could run.
   t.t0_big = getenv("GPP_DAG_T0") ? atof(getenv("GPP_DAG_T0")) : 14.0;
-  t.tc_big = getenv("GPP_DAG_TC") ? atof(getenv("GPP_DAG_TC")) : 3.7;
-  t.t0_64 = 8.0; t.tc_64 = 0.75;
+  t.tc_big = getenv("GPP_DAG_TC") ? atof(getenv("GPP_DAG_TC")) : 3.9;
+  t.t0_64 = 15.0; t.tc_64 = 1.4;
   t.t0_32 = 6.0; t.tc_32 = 0.55;
-  t.t_copy = 12.0;
+  t.t_copy = 160.0;
   t.t_panel0 = getenv("GPP_DAG_TP0") ? atof(getenv("GPP_DAG_TP0")) : 20.0;
-  t.t_panel_leaf = getenv("GPP_DAG_TPL") ? atof(getenv("GPP_DAG_TPL")) : 70.0;
-  t.t_gate = 15.0;
+  t.t_panel_leaf = getenv("GPP_DAG_TPL") ? atof(getenv("GPP_DAG_TPL")) : 77.0;
+  t.t_gate = getenv("GPP_DAG_TGATE") ? atof(getenv("GPP_DAG_TGATE")) : 15.0;
   t.chain_tile = getenv("GPP_DAG_CHAIN_TILE") ? atoi(getenv("GPP_DAG_CHAIN_TILE")) : 64;
   t.workers = 448;
   t.inv_rows = 0;

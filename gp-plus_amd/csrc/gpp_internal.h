@@ -159,7 +159,7 @@ hipError_t gpp_launch_exec_signal(hipStream_t s, int* counters, int id);
 // inverse built right-looking beside it); work-groups take the next task with an atomic ticket, wait for its (up to three)
 // counters, run the tile and raise its (up to two) counters.  Only RUNNING work-groups hold tasks and each holds one, so the
 // earliest unfinished task is always held by a running work-group whose predecessors are complete: progress needs NO co-residency
-// of the grid (the static lists of gpp_exec_f64 do), faster work-groups simply take more tasks (the older / younger wave asymmetry
+// of the grid (round 4's static per-worker lists did), faster work-groups simply take more tasks (the older / younger wave asymmetry
 // balances itself), and the same list serves any number of workers — including short filler launches on the panel's CUs.
 // counters[0] is the abort word, counters[1] the ticket.
 struct DagTask {           // 48 bytes

@@ -426,9 +426,10 @@ def test_batched_mll_function_matches_single(gpu_ctx):
 def test_lookahead_driver_is_bitwise_repeatable(gpu_ctx, n):
     """Race screen for the look-ahead factorisation's internal streams (panel, throughput, fill, unmasked): every tile
     product accumulates in a fixed order, so repeating the same factorisation + inverse + Ky^-1 must reproduce the
-    first result bit for bit; a missing event between two streams shows up as a difference.  4224, 6700 and 9984 take the
-    bordered-inverse path (9984 with the bordering products on the stream without a CU mask), 12000 and above the pair-merging one whose first steps run as the statically scheduled persistent
-    launch (gpp_exec_f64: counters between work-groups instead of events; 13500 is ragged, 16384 a multiple of the block height)."""
+    first result bit for bit; a missing event between two streams — or a missing counter wait in the DAG executor's ticket list —
+    shows up as a difference.  4224 and 6700 take the bordered-inverse path of the launches, 9984 and above the ticket list
+    (gpp_dag_f64: any work-group may run any tile, the order of a tile's updates is enforced by its version counter; 12000 and
+    13500 with fused pairs of steps, 13500 ragged, 16384 a multiple of the block height with groups of four)."""
     U, w, K = _spd(n, seed=n)
     Kd = _dev(np.triu(K))
     A, Li, Ki = _sq(n), _sq(n), _sq(n)

@@ -259,8 +259,8 @@ def test_panel_hand_off_waits_for_the_write_back_before_raising_a_flag():
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    # gpp_leaf.hip: panel_publish / panel_leave; gpp_gemm.hip (round 4): the static-schedule executor's counter increments and the
-    # one-wave signal kernel of the panel stream
+    # gpp_leaf.hip: panel_publish / panel_leave; gpp_gemm.hip: the DAG executor's counter increments (gpp_dag_f64) and the one-wave
+    # signal kernel of the panel stream
     for name in ("gpp_leaf.hip", "gpp_gemm.hip"):
         src = os.path.join(ROOT, "gp-plus_amd", "csrc", name)
         with tempfile.TemporaryDirectory() as tmp:

@@ -10,7 +10,7 @@ args = [int(a) for a in sys.argv[1:]] or [15000, 200, 20000, 200, 30000, 40]
 ctx = get_context("cuda:0")
 info = torch.zeros(1, dtype=torch.int32, device="cuda")
 # STRESS_BG=n: n copies of 1 GB on a side stream beside every factorisation (memory-saturating traffic: what exposed the missing
-# wait behind buffer_wbl2 in round 3; the statically scheduled steps hand data between work-groups the same way)
+# wait behind buffer_wbl2 in round 3; the DAG executor's tasks hand data between work-groups the same way)
 BG = int(os.environ.get("STRESS_BG", "0"))
 if BG:
     bg_stream = torch.cuda.Stream()
