@@ -251,6 +251,30 @@ class GppContext:
                                      first_block, rank, nranks), "gpp_syrk_rows")
 
     @_on_own_device
+    def shard_list_begin(self, N, nb, rank, nranks, A, Kc, Lc, D, W, info, workers=0) -> bool:
+        """Enqueue this rank's ticket list of the sharded factorisation + forward sweep (gpp_shard_list_begin in gpp.h).  False:
+        not applicable here, nothing was enqueued."""
+        self._stream()
+        used = ctypes.c_int(0)
+        check(self.lib.gpp_shard_list_begin(self.h, N, nb, rank, nranks, A.data_ptr(), _ld(A), Kc.data_ptr(), Lc.data_ptr(), _ld(Kc),
+                                            D.data_ptr(), W[0].data_ptr(), W[1].data_ptr(), W[2].data_ptr(), _ld(W[0]),
+                                            info.data_ptr(), int(workers), ctypes.byref(used)), "gpp_shard_list_begin")
+        return bool(used.value)
+
+    @_on_own_device
+    def shard_list_gate(self, stream, tail: bool, k: int) -> None:
+        check(self.lib.gpp_shard_list_gate(self.h, ctypes.c_void_p(stream.cuda_stream), int(tail), k), "gpp_shard_list_gate")
+
+    @_on_own_device
+    def shard_list_signal(self, stream, tail: bool, k: int) -> None:
+        check(self.lib.gpp_shard_list_signal(self.h, ctypes.c_void_p(stream.cuda_stream), int(tail), k), "gpp_shard_list_signal")
+
+    @_on_own_device
+    def shard_list_end(self) -> None:
+        self._stream()
+        check(self.lib.gpp_shard_list_end(self.h), "gpp_shard_list_end")
+
+    @_on_own_device
     def gemm_lower_cols(self, A, B, C, alpha, beta, nb, first_block, rank, nranks, row0=0, row1=None, compact=False):
         """C(lower, owned column blocks of width nb) = beta C + alpha A^T B;  A, B: K x M row-contiguous, C: M x M; rows
         [row0, row1) of C only.  ``compact``: B (K rows) and C (M rows) hold only the owned column blocks, side by side."""

@@ -183,6 +183,20 @@ hipError_t launch_panel(gpp_handle_s* h, const Ctx& c, int64_t o, int64_t n, int
                           h->panel_timeout_ms);
 }
 
+// the same with the block's own addresses in c.A / c.Li (the sharded list: the inverses live in a buffer of their own)
+hipError_t launch_panel_at(gpp_handle_s* h, const Ctx& c, int64_t o, int64_t n, int max_wgs) {
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(c.s, &cap) != hipSuccess) {
+    (void)hipGetLastError();
+    cap = hipStreamCaptureStatusNone;
+  }
+  int slot;
+  if (cap == hipStreamCaptureStatusActive) slot = GPP_PANEL_RING + (h->cap_next++ % GPP_PANEL_CAP_RING);
+  else slot = h->panel_next++ % GPP_PANEL_RING;
+  int* fl = reinterpret_cast<int*>(h->panel_flags + (size_t)slot * gpp_panel_flag_bytes());
+  return gpp_launch_panel(c.s, c.A, c.ld, c.Li, c.ldi, (int)n, c.info, (int)o, fl, max_wgs, h->panel_timeout_ms);
+}
+
 // ---- triangular inverse by pair merging -------------------------------------------------------------------------
 // One level: for the pairs of s-blocks [b, b+s), [b+s, min(b+2s, base+n)) of the range [base, base+n):
 //     T21 = U12^T Linv11 ;  Linv21 = -W22^T T21 (+ mirror).  ``skip(b)`` drops pairs that are already merged.
@@ -890,6 +904,8 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->panel_fault = 0;
   h->panel_timeout_ms = 500;
   for (int i = 0; i < 4; ++i) h->dag_plans[i] = nullptr;
+  h->shard_cur = nullptr;
+  h->shard_info = nullptr;
   h->dag_clock = 0;
   h->dag_sched = 1;
   h->ncu = 0;
@@ -969,6 +985,143 @@ int gpp_internal_stream(gpp_handle_t h, int which, void** out) {
   if (!out) return -3;
   GPP_TRY(ensure_streams(h));
   *out = reinterpret_cast<void*>(which == 0 ? h->panel_stream : which == 1 ? h->upd_stream : h->full_stream);
+  return 0;
+}
+
+// ---- the sharded evaluation's factorisation + forward sweep as ONE ticket list per rank (gpp_dag.hip, DAG_SHARD) -------------------
+static long long shard_budget(const gpp_handle_s* h) {
+  // the waits of a sharded list include the other ranks' progress (and, the first time, their planning): generous by default
+  static const long long ms = getenv("GPP_SHARD_TIMEOUT_MS") ? atoll(getenv("GPP_SHARD_TIMEOUT_MS")) : 60000;
+  (void)h;
+  return ms * 100000;
+}
+
+int gpp_shard_list_begin(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nranks, double* A, int64_t ld, double* Kc, double* Lc,
+                         int64_t ldc, double* D, double* W0, double* W1, double* W2, int64_t ldw, int32_t* info, int workers,
+                         int* used) {
+  if (!h) return -1;
+  if (!used) return -18;
+  *used = 0;
+  if (N < 2 || nb < 128 || nb % 128 != 0) return -2;
+  if (rank < 0 || nranks < 1 || rank >= nranks) return -4;
+  if (int e = check_mat(A, ld, N, 6)) return e;
+  if (!Kc || !aligned16(Kc)) return -8;
+  if (!Lc || !aligned16(Lc)) return -9;
+  const int64_t wc = ((N + nb - 1) / nb - rank + nranks - 1) / nranks * nb;  // owned blocks, whole
+  if ((ldc & 1) || ldc < wc) return -10;
+  if (!D || !aligned16(D)) return -11;
+  if (!W0 || !W1 || !W2 || !aligned16(W0) || !aligned16(W1) || !aligned16(W2)) return -12;
+  if ((ldw & 1) || ldw < N) return -15;
+  if (!info) return -16;
+  if (h->shard_cur) return -1;  // a list is open on this handle
+  static const bool list_env = !(getenv("GPP_SHARD_LIST") && atoi(getenv("GPP_SHARD_LIST")) == 0);
+  static const int64_t list_min = getenv("GPP_SHARD_LIST_MIN_N") ? atol(getenv("GPP_SHARD_LIST_MIN_N")) : 4096;
+  if (!list_env || !h->dag_sched || !h->coop_panel || N < list_min || N > 65536) return 0;
+  GPP_TRY(ensure_streams(h));
+  if (h->cu_split != 1) return 0;
+  if (!panel_fits(h, nb)) return 0;
+  const int flags = DAG_INV | DAG_SHARD;
+  DagPlan* P = nullptr;
+  int slot = -1, lru = 0;
+  for (int i = 0; i < 4; ++i) {
+    DagPlan* q = h->dag_plans[i];
+    if (q && q->N == N && q->nb == nb && q->ld == ld && q->ldi == ldc && q->ldt == ldw && q->flags == flags && q->rank == rank &&
+        q->nranks == nranks && q->workers == workers)
+      slot = i;
+    if (!q) lru = i;
+    else if (h->dag_plans[lru] && q->stamp < h->dag_plans[lru]->stamp) lru = i;
+  }
+  const int nworkers = workers > 0 ? workers : 2 * (h->ncu - h->panel_cus);
+  if (slot >= 0) P = h->dag_plans[slot];
+  else {
+    DagTuning tune = gpp_dag_default_tuning();
+    tune.workers = nworkers;
+    tune.fill = 0;
+    tune.inv_rows = 0;
+    if (!getenv("GPP_DAG_FUSE")) tune.fuse = N >= 14336 ? 4 : N >= 11264 ? 2 : 1;
+    P = gpp_dag_plan(N, nb, ld, ldc, ldw, 0, flags, tune, rank, nranks);
+    if (!P) return 0;
+    P->workers = workers;
+    if (gpp_dag_upload(P) != hipSuccess) {
+      (void)hipGetLastError();
+      gpp_dag_free(P);
+      return 0;
+    }
+    if (h->dag_plans[lru]) gpp_dag_free(h->dag_plans[lru]);
+    h->dag_plans[lru] = P;
+  }
+  P->stamp = ++h->dag_clock;
+  hipStream_t sm = h->stream, sp = h->panel_stream, su = h->upd_stream;
+  GPP_TRY(gpp_launch_fill_i32(sm, P->d_counters, P->ncounters, 0));
+  DagBases bases{{reinterpret_cast<char*>(A), reinterpret_cast<char*>(Kc), reinterpret_cast<char*>(Lc), reinterpret_cast<char*>(D),
+                  reinterpret_cast<char*>(W0), reinterpret_cast<char*>(W1), reinterpret_cast<char*>(W2), nullptr}};
+  GPP_TRY(gpp_launch_dag_bind(sm, P->d_groups, P->d_groups_abs, (int)P->groups.size(), bases));
+  hipEvent_t ev = next_event(h);
+  GPP_TRY(hipEventRecord(ev, sm));
+  GPP_TRY(hipStreamWaitEvent(sp, ev, 0));
+  GPP_TRY(hipStreamWaitEvent(su, ev, 0));
+  const long long budget = shard_budget(h);
+  DagLaunch dl{};
+  dl.groups = P->d_groups_abs; dl.tasks = P->d_tasks; dl.ntasks = (int)P->tasks.size();
+  dl.counters = P->d_counters; dl.info = info; dl.budget = budget;
+  dl.max_tasks = 0; dl.quit_id = -1; dl.quit_val = 0; dl.ticket_limit = 0;
+  dl.trace = P->d_trace; dl.tag = 0;
+  if (dl.ntasks > 0) GPP_TRY(gpp_launch_dag(su, nworkers, dl));
+  Ctx cp{sp, A, ld, D, nb, info};
+  for (const DagPlan::Op& op : P->stream_ops) {
+    const int b = op.arg;
+    const int64_t o = (int64_t)b * nb, rows = std::min(nb, N - o);
+    if (op.kind == 0) {
+      GPP_TRY(gpp_launch_exec_gate(sp, P->d_counters, P->c_g1d + b, P->gate_target[b], info, budget));
+    } else if (op.kind == 1) {
+      // the diagonal block's factor in place, its inverse (+ mirror) into D[b]
+      Ctx cb = cp;
+      cb.A = A + o * ld + o;
+      cb.Li = D + (int64_t)b * nb * nb;
+      GPP_TRY(launch_panel_at(h, cb, o, rows, h->panel_cus));
+    } else if (op.kind == 2) {
+      GPP_TRY(gpp_launch_exec_signal(sp, P->d_counters, P->c_pd + b));
+    }
+  }
+  h->shard_cur = P;
+  h->shard_info = info;
+  *used = 1;
+  return 0;
+}
+
+/* tail == 0: `stream` waits until this rank's panel of block row k is done and its copies of the head's strips (the columns of block
+ * k + 1) are in A — the head message (diagonal block, D[k], head) can be packed; tail != 0: the same for the columns behind. */
+int gpp_shard_list_gate(gpp_handle_t h, void* stream, int tail, int k) {
+  if (!h || !h->shard_cur) return -1;
+  const DagPlan* P = h->shard_cur;
+  if (k < 0 || k >= P->B || k % P->nranks != P->rank) return -4;
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  const long long budget = shard_budget(h);
+  GPP_TRY(gpp_launch_exec_gate(s, P->d_counters, P->c_pd + k, 1, h->shard_info, budget));
+  const int target = tail ? P->cpt_target[k] : P->cph_target[k];
+  if (target > 0) GPP_TRY(gpp_launch_exec_gate(s, P->d_counters, (tail ? P->c_cpt : P->c_cph) + k, target, h->shard_info, budget));
+  return 0;
+}
+
+/* Behind the unpacked head (tail == 0) / tail message of another rank's block row k on `stream`: its tasks may run. */
+int gpp_shard_list_signal(gpp_handle_t h, void* stream, int tail, int k) {
+  if (!h || !h->shard_cur) return -1;
+  const DagPlan* P = h->shard_cur;
+  if (k < 0 || k >= P->B || k % P->nranks == P->rank) return -4;
+  return rc(gpp_launch_exec_signal(reinterpret_cast<hipStream_t>(stream), P->d_counters, (tail ? P->c_art : P->c_pd) + k));
+}
+
+/* The handle's stream waits for the list (its executor and its panels). */
+int gpp_shard_list_end(gpp_handle_t h) {
+  if (!h || !h->shard_cur) return -1;
+  DagPlan* P = h->shard_cur;
+  h->shard_cur = nullptr;
+  hipEvent_t E = next_event(h), F = next_event(h);
+  GPP_TRY(hipEventRecord(E, h->upd_stream));
+  GPP_TRY(hipEventRecord(F, h->panel_stream));
+  GPP_TRY(hipStreamWaitEvent(h->stream, E, 0));
+  GPP_TRY(hipStreamWaitEvent(h->stream, F, 0));
+  GPP_TRY(hipEventRecord(P->last_use, h->stream));
   return 0;
 }
 

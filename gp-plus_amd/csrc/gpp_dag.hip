@@ -60,6 +60,15 @@ struct Planner {
   std::vector<std::vector<int>> incs;     // per counter: incrementing nodes in generation order
   int c_pd = 0, c_g1d = 0, c_ur = 0, c_ss = 0, c_xr = 0, c_xs = 0, c_va = 0, c_vt = 0;
   int cur_lvl = 0;
+  // DAG_SHARD: this rank's list of the sharded evaluation
+  int rank = 0, nranks = 1;
+  int c_cpd = 0, c_cph = 0, c_cpt = 0, c_art = 0;
+  std::vector<int> cph_n, cpt_n;  // copies that raise CPH(k) / CPT(k)
+  bool own(int b) const { return b % nranks == rank; }
+  int CPD(int b, int c) const { return c_cpd + b * nt + c; }
+  int CPH(int b) const { return c_cph + b; }
+  int CPT(int b) const { return c_cpt + b; }
+  int ART(int b) const { return c_art + b; }
 
   int blk_of(int tile) const { return (int)(std::upper_bound(tb.begin(), tb.end(), tile) - tb.begin()) - 1; }
   int64_t rows_of(int b) const { return std::min<int64_t>((int64_t)tb[b + 1] * 128, N) - (int64_t)tb[b] * 128; }
@@ -155,13 +164,28 @@ struct Planner {
     if (flags & DAG_INV) {
       c_vt = ncounters; ncounters += (int)((int64_t)nt * (nt - 1) / 2);
     }
+    const int n_ver = ncounters;
+    if (flags & DAG_SHARD) {
+      // (uniform blocks: the sharded buffers address block k at k * nb; a last block too short for the panel is the caller's to avoid)
+      if (B != (nt + bt - 1) / bt || rank < 0 || rank >= nranks || rank >= B) return false;
+      c_cpd = ncounters; ncounters += B * nt;
+      c_cph = ncounters; ncounters += B;
+      c_cpt = ncounters; ncounters += B;
+      c_art = ncounters; ncounters += B;
+      cph_n.assign(B, 0);
+      cpt_n.assign(B, 0);
+    }
     chain.assign(ncounters, 0);
-    for (int c = c_va; c < ncounters; ++c) chain[c] = 1;  // VA, VT
+    for (int c = c_va; c < n_ver; ++c) chain[c] = 1;  // VA, VT
     incs.assign(ncounters, {});
     return true;
   }
 
   void generate() {
+    if (flags & DAG_SHARD) {
+      generate_sharded();
+      return;
+    }
     const int ct = tune.chain_tile == 64 ? 64 : 128;  // (a 32 x 32 body beside the two others made the kernel spill 26 VGPRs)
     for (int k = 0; k < B; ++k) {
       const int lo = tb[k + 1], btk = tb[k + 1] - tb[k];
@@ -405,6 +429,318 @@ struct Planner {
     }
   }
 
+  // ---- one rank's list of the SHARDED evaluation (gp-plus_amd/sharded.py; DAG_SHARD) ------------------------------------------------
+  // 1-D block-cyclic: block row k of the factor AND column block k of X = L^-1 belong to rank k % P.  Buffers (DagBases):
+  // 0 A (N x N: the replicated factor, upper), 1 Kc (N x owned columns, compact: X), 2 Lc (the same shape: the forward sweep's running
+  // sums), 3 D (per block nb x nb: the diagonal blocks' inverses + mirrors), 4-6 W (three nb x N scratch rows of the row solves).
+  // The plan's ldi is the compact buffers' leading dimension, ldt the scratch rows'.
+  //   own k:     P(k) on the panel stream (inverse into D[k]);  S(k; r, c) into W[q % 3], q = k's ordinal among the owned blocks;
+  //              CP(k; c): the solved strip into A's block row, raising CPD(k, c) and CPH(k) / CPT(k) — the gates of the head / tail
+  //              broadcasts, which the caller packs from A on its communication stream
+  //   other k:   the caller signals PD(k) behind the unpacked head message (diagonal block, D[k], the columns of block k+1) and
+  //              ART(k) behind the tail's
+  //   U(k; i, j) for the block rows i this rank owns, reading block row k of the factor from A: available for column tile c at
+  //              CPD(k, c) on its owner, PD(k) (head) / ART(k) (tail) elsewhere.  Where one rank owns k and k+1 (P = 1) the chain's
+  //              tiles — diagonal block k+1 and the rest of block row k+1 — read the solve's output in W instead (no copy on the
+  //              chain); W[.][., c] is rewritten by S(k + 3P; ., c), which follows U(k; k+1, c) through the chain of column c's
+  //              strips and waits for CP(k; c) explicitly.
+  //   XB(k; i, j) / XA(m; r, j) for the column blocks j this rank owns: the owned blocks left of any block sit side by side at the
+  //              start of Kc / Lc, so the products address compact tiles directly; their counters keep the global tile numbers.
+  //   Fused steps: the last step's availability implies the earlier ones' on every rank (messages arrive in order; a block row's
+  //              solves follow the updates that needed the previous slab), as in the one-GPU list.
+  // For the ORDER the remote events are nodes of a serial "communication stream" with estimated costs (kind -2: head, -3: tail);
+  // they are not tasks.
+  int glob_tile(int jc) const {  // compact tile -> global tile
+    const int bt = (int)(nb / GPP_TILE);
+    return (rank + (jc / bt) * nranks) * bt + jc % bt;
+  }
+  int nleft(int k) const { return k > rank ? (k - rank + nranks - 1) / nranks : 0; }  // owned blocks left of block k
+  void generate_sharded() {
+    const int ct = tune.chain_tile == 64 ? 64 : 128;
+    const int P = nranks, me = rank;
+    const int bt = (int)(nb / GPP_TILE);
+    const int64_t ldc = ldi, ldw = ldt;
+    auto avail = [&](int node, int k, int c) {  // block row k of the factor, column tile c, is in A
+      if (own(k)) wait(node, CPD(k, c), 1);
+      else wait(node, c < tb[std::min(k + 2, B)] ? PD(k) : ART(k), 1);
+    };
+    auto avail2 = [&](int node, int k, int i, int j) {
+      if (own(k)) {
+        wait(node, CPD(k, i), 1);
+        if (j != i) wait(node, CPD(k, j), 1);
+      } else {
+        const int hi2 = tb[std::min(k + 2, B)];
+        wait(node, (i < hi2 && j < hi2) ? PD(k) : ART(k), 1);  // (the tail arrives behind the head)
+      }
+    };
+    auto fuse_of = [&](int bi, int kk) {
+      for (int f = std::min(tune.fuse, 4); f >= 2; f >>= 1) {
+        const int g0 = kk - kk % f;
+        if (g0 + f - 1 <= B - 2 && bi >= g0 + f + 1) return f;
+      }
+      return 1;
+    };
+    int last_comm = -1;  // the communication stream's previous event
+    for (int k = 0; k < B; ++k) {
+      const int lo = tb[k + 1], btk = tb[k + 1] - tb[k];
+      const int64_t o = (int64_t)tb[k] * 128, nbk = rows_of(k), c0 = (int64_t)lo * 128, rem = N - c0;
+      const int hi = tb[std::min(k + 2, B)];
+      const int64_t dk = (int64_t)k * nb * nb;  // D[k]
+      const int nl = nleft(k);                  // owned column blocks left of block k: compact tiles [0, nl * bt)
+      cur_lvl = k;
+      if (own(k)) {
+        const int p = add_node(-1, k, 0, -1, tune.t_gate + tune.t_panel0 + tune.t_panel_leaf * (double)((nbk + 127) / 128));
+        if (k > 0) wait(p, G1D(k), ALL);
+        inc(p, PD(k));
+      } else {
+        // the head of a remote slab: its owner needed the previous slab's head first
+        const double mb_head = 1e-6 * 8.0 * (double)(nbk * (std::min<int64_t>(c0 + nb, N) - o + nbk));
+        const int h = add_node(-1, k, 0, -2, 1300.0 + mb_head / 0.05);  // update + panel + head solve + copy, the message at ~50 GB/s
+        // (the stream's order: behind the previous message — a remote one's arrival, or the gates of this rank's own)
+        if (last_comm >= 0) wait(h, nodes[last_comm].inc[0], 1);
+        if (k > 0 && own(k - 1) && cph_n[k - 1] > 0) wait(h, CPH(k - 1), ALL);
+        if (k > 0 && own(k - 1) && cpt_n[k - 1] > 0) wait(h, CPT(k - 1), ALL);
+        inc(h, PD(k));
+        last_comm = h;
+        if ((int64_t)hi * 128 < N) {
+          const double mb_tail = 1e-6 * 8.0 * (double)(nbk * (N - (int64_t)hi * 128));
+          const int t = add_node(-1, k, 0, -3, 200.0 + mb_tail / 0.05);
+          wait(t, PD(k), 1);
+          inc(t, ART(k));
+          last_comm = t;
+        }
+      }
+      // XA(k; r, jc): X[k rows, j] = -W_kk^T S_k[., j] for the owned column blocks left of block k
+      if (k > 0 && nl > 0) {
+        GemmArgs g{};
+        g.A = off(dk); g.lda = nb; g.buf[0] = 3;
+        g.B = off(o * ldc); g.ldb = ldc; g.buf[1] = 2;
+        g.C = offw(o * ldc); g.ldc = ldc; g.buf[2] = 1;
+        g.buf[3] = -1;
+        g.M = (int)nbk; g.N = (int)(nl * nb); g.K = (int)nbk;
+        g.alpha = -1.0; g.beta = 0.0;
+        g.a_mask = 1; g.khi_mode = 1;
+        g.pad_ok = 1;  // (D[k] is a full nb x nb block, the compact buffers are whole blocks wide)
+        const int gi = add_group(g, DK_XA, k);
+        for (int r = btk - 1; r >= 0; --r)
+          for (int jc = 0; jc < nl * bt; ++jc) {
+            const int j = glob_tile(jc);
+            const int n = add_node(gi, r, jc, DK_XA, tile_cost(128, std::min<int64_t>(nbk, (int64_t)(r + 1) * 128)));
+            wait(n, PD(k), 1);
+            wait(n, XR(k, j), ALL);
+            inc(n, XS(k, j));
+          }
+      }
+      if (rem <= 0) continue;
+      const int nbk1 = (int)rows_of(k + 1);
+      const bool chain_here = own(k) && own(k + 1);  // this rank's next panel reads this solve's output directly
+      const int slot = 4 + ((k - me) / P) % 3;
+      // ---- S(k), CP(k): the owner's row solve into the scratch row, then into place ------------------------------------------------
+      if (own(k)) {
+        GemmArgs s{};
+        s.A = off(dk); s.lda = nb; s.buf[0] = 3;
+        s.B = off(o * ld + c0); s.ldb = ld; s.buf[1] = 0;
+        s.C = offw(c0); s.ldc = ldw; s.buf[2] = slot;
+        s.buf[3] = -1;
+        s.M = (int)nbk; s.N = (int)rem; s.K = (int)nbk;
+        s.alpha = 1.0; s.beta = 0.0;
+        s.a_mask = 1; s.khi_mode = 1;
+        s.pad_ok = 1;
+        const int gS = add_group(s, DK_S, k);
+        int gSh = -1;
+        if (ct != 128) {
+          GemmArgs sh = s;
+          sh.N = nbk1;
+          sh.etile = ct;
+          gSh = add_group(sh, DK_SH, k);
+        }
+        auto solve_waits = [&](int n, int c128) {
+          wait(n, PD(k), 1);
+          if (k > 0) wait(n, UR(k, c128), ALL);
+          if (k >= 3 * P) wait(n, CPD(k - 3 * P, c128), 1);  // the scratch row's previous strip has been copied out
+          inc(n, SS(k, c128));
+        };
+        if (gSh >= 0) {
+          const int rt = (int)((nbk + ct - 1) / ct), ctiles = (nbk1 + ct - 1) / ct;
+          for (int r = rt - 1; r >= 0; --r)
+            for (int c = 0; c < ctiles; ++c) {
+              const int n = add_node(gSh, r, c, DK_SH, tile_cost(ct, std::min<int64_t>(nbk, (int64_t)(r + 1) * ct)));
+              solve_waits(n, lo + c * ct / 128);
+            }
+        }
+        for (int r = btk - 1; r >= 0; --r)
+          for (int c = lo; c < nt; ++c) {
+            if (gSh >= 0 && c < hi) continue;
+            const int n = add_node(gS, r, c - lo, DK_S, tile_cost(128, std::min<int64_t>(nbk, (int64_t)(r + 1) * 128)));
+            solve_waits(n, c);
+          }
+        GemmArgs cp{};
+        cp.A = off(0); cp.buf[0] = slot;
+        cp.B = off(c0); cp.ldb = ldw; cp.buf[1] = slot;
+        cp.C = offw(o * ld + c0); cp.ldc = ld; cp.buf[2] = 0;
+        cp.buf[3] = -1;
+        cp.M = (int)nbk; cp.N = (int)rem;
+        cp.op = 1;
+        const int gC = add_group(cp, DK_CP, k);
+        for (int c = lo; c < nt; ++c) {
+          const int n = add_node(gC, 0, c - lo, DK_CP, tune.t_copy);
+          wait(n, SS(k, c), ALL);
+          // one rank owning consecutive blocks: a column's strips are copied in step order, so that "block row k is in A" implies
+          // the same of the rows above it (fused tasks wait for their last step only); with P > 1 the messages' order does that
+          if (k > 0 && own(k - 1)) wait(n, CPD(k - 1, c), 1);
+          inc(n, CPD(k, c));
+          inc(n, c < hi ? CPH(k) : CPT(k));
+          ++(c < hi ? cph_n : cpt_n)[k];
+        }
+      }
+      // ---- U(k): the trailing update of the block rows this rank owns -----------------------------------------------------------
+      GemmArgs u{};
+      u.A = off(o * ld + c0); u.lda = ld; u.buf[0] = 0;
+      u.B = u.A; u.ldb = ld; u.buf[1] = 0;
+      u.C = offw(c0 * ld + c0); u.ldc = ld; u.buf[2] = 0;
+      u.buf[3] = -1;
+      u.M = u.N = (int)rem; u.K = (int)nbk;
+      u.alpha = -1.0; u.beta = 1.0;
+      u.c_lower = 2;
+      u.pad_ok = 1;
+      const int gU = add_group(u, DK_U, k);
+      GemmArgs uw = u;  // the chain's tiles on the rank that owns k and k+1: operands from the scratch row
+      uw.A = off(c0); uw.lda = ldw; uw.buf[0] = slot;
+      uw.B = uw.A; uw.ldb = ldw; uw.buf[1] = slot;
+      const int gUw = chain_here ? add_group(uw, DK_U, k) : -1;
+      auto chain_waits = [&](int n, int i, int j) {
+        if (chain_here) {
+          wait(n, SS(k, i), ALL);
+          if (j != i) wait(n, SS(k, j), ALL);
+        } else {
+          avail2(n, k, i, j);
+        }
+      };
+      int gUd = -1;
+      if (ct != 128 && own(k + 1)) {
+        GemmArgs ud = chain_here ? uw : u;
+        ud.M = ud.N = nbk1;
+        ud.etile = ct;
+        gUd = add_group(ud, DK_UD, k);
+        const int rt = (nbk1 + ct - 1) / ct;
+        for (int a = 0; a < rt; ++a)
+          for (int b = a; b < rt; ++b) {
+            const int i = lo + a * ct / 128, j = lo + b * ct / 128;
+            const int n = add_node(gUd, a, b, DK_UD, tile_cost(ct, nbk));
+            if (k > 0) wait(n, VA(i, j), k);
+            chain_waits(n, i, j);
+            inc(n, G1D(k + 1));
+          }
+      }
+      int gUf[5] = {-1, -1, -1, -1, -1};
+      int64_t Kf[5] = {0, 0, 0, 0, 0};
+      for (int f = 2; f <= std::min(tune.fuse, 4); f <<= 1) {
+        if (k % f != f - 1 || k - (f - 1) < 0) continue;
+        GemmArgs uf = u;
+        const int64_t o_first = (int64_t)tb[k - (f - 1)] * 128;
+        Kf[f] = (int64_t)tb[k + 1] * 128 - o_first;
+        uf.A = off(o_first * ld + c0);
+        uf.B = uf.A;
+        uf.K = (int)Kf[f];
+        gUf[f] = add_group(uf, DK_U, k);
+      }
+      for (int i = lo; i < nt; ++i) {
+        if (!own(blk_of(i))) continue;
+        const int f = fuse_of(blk_of(i), k);
+        for (int j = i; j < nt; ++j) {
+          const bool in_next = i < hi, diag = in_next && j < hi;
+          if (diag && gUd >= 0) continue;
+          if (f > 1) {
+            const int g0 = k - k % f;
+            if (k != g0 + f - 1) continue;
+            const int n = add_node(gUf[f], i - lo, j - lo, DK_U, tile_cost(128, Kf[f]));
+            if (g0 > 0) wait(n, VA(i, j), g0);
+            avail2(n, k, i, j);
+            inc(n, VA(i, j), f);
+            continue;
+          }
+          const int n = add_node(in_next && chain_here ? gUw : gU, i - lo, j - lo, DK_U, tile_cost(128, nbk));
+          if (k > 0) wait(n, VA(i, j), k);
+          if (in_next) chain_waits(n, i, j);
+          else avail2(n, k, i, j);
+          if (diag) inc(n, G1D(k + 1));
+          else if (in_next) inc(n, UR(k + 1, j));
+          else inc(n, VA(i, j));
+        }
+      }
+      // ---- XB(k): the running sums of the owned column blocks -------------------------------------------------------------------
+      int gx0 = -1, gx1 = -1;
+      if (own(k)) {  // this rank's own column block k: the first contribution, X_kk from D[k] (lower triangular)
+        GemmArgs x0{};
+        x0.A = off(o * ld + c0); x0.lda = ld; x0.buf[0] = 0;
+        x0.B = off(dk); x0.ldb = nb; x0.buf[1] = 3;
+        x0.C = offw(c0 * ldc + (int64_t)nl * nb); x0.ldc = ldc; x0.buf[2] = 2;
+        x0.buf[3] = -1;
+        x0.M = (int)rem; x0.N = (int)nbk; x0.K = (int)nbk;
+        x0.alpha = 1.0; x0.beta = 0.0;
+        x0.b_mask = 2; x0.klo_mode = 2;
+        x0.pad_ok = 1;
+        gx0 = add_group(x0, DK_XB, k);
+      }
+      if (nl > 0) {
+        GemmArgs x1{};
+        x1.A = off(o * ld + c0); x1.lda = ld; x1.buf[0] = 0;
+        x1.B = off(o * ldc); x1.ldb = ldc; x1.buf[1] = 1;
+        x1.C = offw(c0 * ldc); x1.ldc = ldc; x1.buf[2] = 2;
+        x1.buf[3] = -1;
+        x1.M = (int)rem; x1.N = (int)(nl * nb); x1.K = (int)nbk;
+        x1.alpha = 1.0; x1.beta = 1.0;
+        x1.pad_ok = 1;
+        gx1 = add_group(x1, DK_XB, k);
+      }
+      int gXf[5] = {-1, -1, -1, -1, -1};
+      int nlf[5] = {0, 0, 0, 0, 0};
+      for (int f = 2; f <= std::min(tune.fuse, 4); f <<= 1) {
+        if (k % f != f - 1 || k - (f - 1) < 1) continue;
+        const int q0 = k - (f - 1);
+        nlf[f] = nleft(q0);
+        if (nlf[f] == 0) continue;
+        const int64_t o_first = (int64_t)tb[q0] * 128;
+        GemmArgs y1{};
+        y1.A = off(o_first * ld + c0); y1.lda = ld; y1.buf[0] = 0;
+        y1.B = off(o_first * ldc); y1.ldb = ldc; y1.buf[1] = 1;
+        y1.C = offw(c0 * ldc); y1.ldc = ldc; y1.buf[2] = 2;
+        y1.buf[3] = -1;
+        y1.M = (int)rem; y1.N = (int)(nlf[f] * nb); y1.K = (int)Kf[f];
+        y1.alpha = 1.0; y1.beta = 1.0;
+        y1.pad_ok = 1;
+        gXf[f] = add_group(y1, DK_XB, k);
+      }
+      const int ncols = (nl + (own(k) ? 1 : 0)) * bt;  // compact tiles of the owned column blocks up to block k
+      for (int i = lo; i < nt; ++i) {
+        const bool fin = i < hi;
+        const int fz = fuse_of(blk_of(i), k), q0 = k - k % fz;
+        for (int jc = 0; jc < ncols; ++jc) {
+          const int j = glob_tile(jc), bj = blk_of(j);
+          if (j >= lo) continue;  // (a ragged last block cannot be k here: rem > 0)
+          const bool ownb = bj == k;
+          if (fz > 1 && bj < q0) {  // columns left of the GROUP's first block: f blocks of X's rows at once, with the group's last step
+            if (k != q0 + fz - 1) continue;
+            const int n = add_node(gXf[fz], i - lo, jc, DK_XB, tile_cost(128, Kf[fz]));
+            avail(n, k, i);
+            wait(n, XS(k, j), ALL);
+            if (q0 - bj > 0) wait(n, VT(i, j), q0 - bj);
+            inc(n, VT(i, j), fz);
+            continue;
+          }
+          const int64_t K = ownb ? nbk - (int64_t)(j - tb[k]) * 128 : nbk;
+          const int n = add_node(ownb ? gx0 : gx1, i - lo, ownb ? j - tb[k] : jc, DK_XB, tile_cost(128, K));
+          avail(n, k, i);
+          if (ownb) wait(n, PD(k), 1);
+          else wait(n, XS(k, j), ALL);
+          if (k - bj > 0) wait(n, VT(i, j), k - bj);
+          if (fin) inc(n, XR(k + 1, j));
+          else inc(n, VT(i, j));
+        }
+      }
+    }
+  }
+
   // ALL -> the number of incrementers; predecessor lists; bottom levels.  False when the graph is not a DAG (a planner bug).
   std::vector<std::vector<int>> preds;
   bool resolve() {
@@ -490,7 +826,7 @@ struct Planner {
     };
     std::priority_queue<Ev, std::vector<Ev>, std::greater<Ev>> events;
     std::vector<int> panel_ready;
-    double now = 0, panel_free = 0;
+    double now = 0, panel_free = 0, comm_free = 0;
     int wfree = W;
     std::vector<int> fbudget(F, 0), ffree;  // filler workers of the current launch: tasks left, ids of the idle ones
     int falive = 0;                         // filler workers that have not left yet
@@ -501,7 +837,11 @@ struct Planner {
     p_end.assign(B, 0);
     g_open.assign(B, 0);
     auto make_ready = [&](int t) {
-      if (nodes[t].kind < 0) panel_ready.push_back(t);
+      if (nodes[t].kind <= -2) {  // a remote slab's arrival (sharded lists): the communication stream, serial
+        comm_free = std::max(now, comm_free) + nodes[t].cost;
+        events.push({comm_free, t, -1});
+        order.push_back(t);
+      } else if (nodes[t].kind < 0) panel_ready.push_back(t);
       else ready.push(t);
     };
     auto start_panel = [&](int t) {
@@ -552,7 +892,8 @@ struct Planner {
         continue;
       }
       const int t = e.node;
-      if (nodes[t].kind < 0) {
+      if (nodes[t].kind <= -2) {
+      } else if (nodes[t].kind < 0) {
         const int b = nodes[t].tm;
         p_end[b] = now;
         fquit = false;
@@ -620,6 +961,9 @@ DagPlan* emit(Planner& pl) {
   P->ncounters = pl.ncounters;
   P->c_pd = pl.c_pd; P->c_g1d = pl.c_g1d;
   P->gate_target.assign(pl.B, 0);
+  P->rank = pl.rank; P->nranks = pl.nranks;
+  P->c_cph = pl.c_cph; P->c_cpt = pl.c_cpt; P->c_art = pl.c_art;
+  P->cph_target = pl.cph_n; P->cpt_target = pl.cpt_n;
   P->sim_ms = pl.makespan * 1e-3;
   P->sim_busy = pl.busy;
   // first ticket of each level: a filler launch behind panel b stops in front of the first task that needs panel b + 1
@@ -637,6 +981,7 @@ DagPlan* emit(Planner& pl) {
   P->level_first = first_of;
   for (int t : pl.order) {
     const Node& n = pl.nodes[t];
+    if (n.kind <= -2) continue;  // (a remote slab's arrival: the caller's communication stream signals it)
     if (n.kind < 0) {
       const int b = n.tm;
       if (b > 0) {
@@ -691,8 +1036,10 @@ DagTuning gpp_dag_default_tuning() {
   return t;
 }
 
-DagPlan* gpp_dag_plan(int64_t N, int64_t nb, int64_t ld, int64_t ldi, int64_t ldt, int64_t ldk, int flags, const DagTuning& tune) {
+DagPlan* gpp_dag_plan(int64_t N, int64_t nb, int64_t ld, int64_t ldi, int64_t ldt, int64_t ldk, int flags, const DagTuning& tune, int rank,
+                      int nranks) {
   Planner pl;
+  pl.rank = rank; pl.nranks = std::max(nranks, 1);
   pl.N = N; pl.nb = nb; pl.ld = ld; pl.ldi = ldi; pl.ldt = ldt; pl.ldk = ldk;
   pl.flags = flags;
   pl.tune = tune;
@@ -1067,4 +1414,398 @@ extern "C" int gpp_debug_dag_sim(int64_t N, int64_t nb, int flags, int chain_til
   stats[3] = P->B;
   gpp_dag_free(P);
   return 0;
+}
+
+// ---- host-side verification of the SHARDED lists (tests/test_host_cpu.py) ------------------------------------------------------------
+// The lists of all `nranks` ranks executed TOGETHER on the host: per rank W workers taking tickets in list order, the panel stream
+// (gate / panel / signal of the owned blocks) and the communication stream as gp-plus_amd/sharded.py drives it — for k = 0, 1, ...: the
+// head message of block row k, then its tail; the owner's side waits at the gates (panel done + its copies of the head's / tail's strips
+// counted), a receiver's side completes only after the owner's has, and then raises PD(k) / ART(k).  Interleavings are random or
+// adversarial as in gpp_debug_dag_check, and so are the checks: what the arithmetic needs, from the tasks' geometry alone — the
+// operands' buffers and offsets — never from their counters.  Returns 0 or a code naming the first violation (+ 1000 * rank).
+// stats: tasks run, waits, increments, (with `mutate` > 0, which removes the mutate-th wait over all ranks' lists: the check must
+// then fail) kind * 10 + counter family of the task that lost its wait.
+extern "C" int gpp_debug_shard_check(int64_t N, int64_t nb, int nranks, int chain_tile, int W, unsigned seed, int64_t* stats, int mutate) {
+  DagTuning tune = gpp_dag_default_tuning();
+  if (chain_tile >= 1000) {
+    tune.fuse = chain_tile / 1000;
+    chain_tile %= 1000;
+  }
+  tune.chain_tile = chain_tile;
+  tune.fill = 0;
+  tune.workers = std::max(W, 1);
+  const int P = std::max(nranks, 1);
+  const int64_t nblk = (N + nb - 1) / nb;
+  struct Rank {
+    DagPlan* plan = nullptr;
+    std::vector<int> counters, a_upd, ud_done, ud_need, t_done, t_need, t_acc, w_content;
+    std::vector<char> x_done, copied, panel_done, arr_head, arr_tail, sent_head, sent_tail, lazy;
+    std::vector<int64_t> cur;
+    size_t op = 0, cop = 0;
+    int64_t head = 0, finished = 0;
+    int64_t ldc = 0;
+  };
+  std::vector<Rank> R(P);
+  auto cleanup = [&]() {
+    for (Rank& r : R)
+      if (r.plan) gpp_dag_free(r.plan);
+  };
+  for (int r = 0; r < P; ++r) {
+    int64_t nq = 0;
+    for (int64_t b = r; b < nblk; b += P) ++nq;
+    R[r].ldc = std::max<int64_t>(nq, 1) * nb;
+    R[r].plan = gpp_dag_plan(N, nb, N, R[r].ldc, N, N, DAG_INV | DAG_SHARD, tune, r, P);
+    if (!R[r].plan) {
+      cleanup();
+      return 1;
+    }
+  }
+  const int nt = R[0].plan->nt, B = R[0].plan->B;
+  const std::vector<int> tb = R[0].plan->tb;
+  const int bt = (int)(nb / GPP_TILE);
+  auto blk_of = [&](int tile) { return (int)(std::upper_bound(tb.begin(), tb.end(), tile) - tb.begin()) - 1; };
+  auto tixU = [&](int i, int j) { return (size_t)((int64_t)i * nt - (int64_t)i * (i - 1) / 2 + (j - i)); };
+  auto hi_of = [&](int k) { return tb[std::min(k + 2, B)]; };
+  auto has_tail = [&](int k) { return (int64_t)hi_of(k) * 128 < N; };
+  auto elems = [](const void* p) { return (int64_t)(reinterpret_cast<uintptr_t>(p) / 8); };
+  for (int r = 0; r < P; ++r) {
+    Rank& q = R[r];
+    q.counters.assign(q.plan->ncounters, 0);
+    q.a_upd.assign((size_t)nt * (nt + 1) / 2, 0);
+    q.ud_done.assign((size_t)nt * (nt + 1) / 2, 0);
+    q.ud_need.assign((size_t)nt * (nt + 1) / 2, 0);
+    q.t_done.assign((size_t)nt * nt, 0);
+    q.t_need.assign((size_t)nt * nt, 0);
+    q.t_acc.assign((size_t)nt * nt, 0);
+    q.w_content.assign((size_t)3 * nt, -1);
+    q.x_done.assign((size_t)nt * nt, 0);
+    q.copied.assign((size_t)B * nt, 0);
+    q.panel_done.assign(B, 0);
+    q.arr_head.assign(B, 0); q.arr_tail.assign(B, 0); q.sent_head.assign(B, 0); q.sent_tail.assign(B, 0);
+    q.cur.assign(std::max(W, 1), -1);
+    q.lazy.assign(q.plan->tasks.size(), 0);
+  }
+  // a task's kind and blocks from its group's operands
+  struct GInfo { int kind, k, f, slot; bool from_w, own0; };
+  auto ginfo = [&](const Rank& q, const GemmArgs& a) {
+    GInfo g{-1, 0, 1, -1, false, false};
+    const int64_t ld = q.plan->ld, ldc = q.plan->ldi;
+    if (a.op == 1) {
+      g.kind = DK_CP;
+      g.k = (int)(elems(a.C) / ld / nb);
+      g.slot = a.buf[1] - 4;
+    } else if (a.buf[2] == 0) {
+      g.kind = a.etile && a.etile != 128 ? DK_UD : DK_U;
+      const int64_t c0 = elems(a.C) / ld;
+      g.f = (int)((a.K + nb - 1) / nb);
+      g.k = (int)(c0 / nb) - g.f;  // FIRST step of the group
+      g.from_w = a.buf[0] >= 4;
+      g.slot = a.buf[0] - 4;
+    } else if (a.buf[2] == 1) {
+      g.kind = DK_XA;
+      g.k = (int)(elems(a.A) / (nb * nb));
+    } else if (a.buf[2] == 2) {
+      g.kind = DK_XB;
+      const int64_t c0 = elems(a.C) / ldc;
+      g.f = (int)((a.K + nb - 1) / nb);
+      g.k = (int)(c0 / nb) - g.f;
+      g.own0 = a.beta == 0.0;
+    } else if (a.buf[2] >= 4) {
+      g.kind = a.etile && a.etile != 128 ? DK_SH : DK_S;
+      g.k = (int)(elems(a.A) / (nb * nb));
+      g.slot = a.buf[2] - 4;
+    }
+    return g;
+  };
+  // the wait to remove
+  int mutated = -1, lazy_rank = -1, lazy_counter = -1;
+  const int mutate_in = mutate;
+  if (mutate > 0) {
+    int seen = 0;
+    for (int r = 0; r < P && mutate > 0; ++r)
+      for (auto& t : R[r].plan->tasks)
+        for (int z = 0; z < 3 && mutate > 0; ++z)
+          if (t.wait_id[z] >= 0 && ++seen == mutate) {
+            const DagPlan* pl = R[r].plan;
+            const int c = t.wait_id[z];
+            int fam;
+            if (c >= pl->c_art) fam = 9;
+            else if (c >= pl->c_cph) fam = 8;          // CPH / CPT (never waited for by tasks)
+            else if (c >= pl->c_cph - B * nt) fam = 7;  // CPD
+            else fam = c < pl->c_g1d ? 0 : c < pl->c_g1d + B ? 1 : 2 + (int)std::min<int64_t>(((int64_t)c - (pl->c_g1d + B)) / ((int64_t)B * nt), 4);
+            mutated = 10 * ginfo(R[r], pl->groups[t.group]).kind + fam;
+            if (getenv("GPP_DAG_CHECK_VERBOSE"))
+              fprintf(stderr, "mutate: rank %d task %ld kind %d tile (%d, %d) loses wait %d (counter %d >= %d, family %d)\n", r,
+                      (long)(&t - pl->tasks.data()), mutated / 10, (int)t.tm, (int)t.tn, z, c, t.wait_val[z], fam);
+            t.wait_id[z] = -1;
+            mutate = 0;
+            lazy_rank = r;
+            lazy_counter = c;
+          }
+    if (lazy_rank >= 0)
+      for (size_t t = 0; t < R[lazy_rank].plan->tasks.size(); ++t) {
+        const DagTask& d = R[lazy_rank].plan->tasks[t];
+        R[lazy_rank].lazy[t] = d.inc_id[0] == lazy_counter || d.inc_id[1] == lazy_counter;
+      }
+  }
+  for (int r = 0; r < P; ++r)
+    for (const DagTask& t : R[r].plan->tasks) {
+      const GemmArgs& a = R[r].plan->groups[t.group];
+      const GInfo g = ginfo(R[r], a);
+      const int et = a.etile ? a.etile : 128;
+      if (g.kind == DK_S || g.kind == DK_SH) ++R[r].t_need[(size_t)(tb[g.k] + t.tm * et / 128) * nt + tb[g.k + 1] + t.tn * et / 128];
+      else if (g.kind == DK_UD) ++R[r].ud_need[tixU(tb[g.k + 1] + t.tm * et / 128, tb[g.k + 1] + t.tn * et / 128)];
+    }
+  uint64_t rng = 0x9E3779B97F4A7C15ull ^ seed;
+  auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+  int rc = 0;
+  int64_t ran = 0, waits = 0, nincs = 0;
+  auto fail = [&](int r, int code) { if (!rc) rc = code + 1000 * r; };
+  auto own = [&](int r, int b) { return b % P == r; };
+  auto glob = [&](int r, int jc) { return (r + (jc / bt) * P) * bt + jc % bt; };
+  auto solved = [&](const Rank& q, int k, int c) {
+    for (int i = tb[k]; i < tb[k + 1]; ++i)
+      if (q.t_need[(size_t)i * nt + c] == 0 || q.t_done[(size_t)i * nt + c] != q.t_need[(size_t)i * nt + c]) return false;
+    return true;
+  };
+  auto in_a = [&](int r, const Rank& q, int k, int c) {  // block row k of the factor, column tile c, is in this rank's A
+    if (own(r, k)) return (bool)q.copied[(size_t)k * nt + c];
+    return (bool)(c < hi_of(k) ? q.arr_head[k] : q.arr_tail[k]);
+  };
+  auto d_here = [&](int r, const Rank& q, int k) { return (bool)(own(r, k) ? q.panel_done[k] : q.arr_head[k]); };
+  auto try_task = [&](int r, const DagTask& t) -> bool {
+    Rank& q = R[r];
+    for (int z = 0; z < 3; ++z)
+      if (t.wait_id[z] >= 0 && q.counters[t.wait_id[z]] < t.wait_val[z]) return false;
+    const GemmArgs& a = q.plan->groups[t.group];
+    const GInfo g = ginfo(q, a);
+    const int et = a.etile ? a.etile : 128, k = g.k;
+    if (g.kind == DK_S || g.kind == DK_SH) {
+      const int lo = tb[k + 1];
+      const int i = tb[k] + t.tm * et / 128, c = lo + t.tn * et / 128;
+      if (!own(r, k) || g.slot != ((k - r) / P) % 3) fail(r, 14);
+      if (!q.panel_done[k]) fail(r, 10);
+      if (q.copied[(size_t)k * nt + c]) fail(r, 11);
+      const int rmax = std::min(tb[k + 1] - 1, tb[k] + ((t.tm + 1) * et - 1) / 128);
+      for (int rr = tb[k]; rr <= rmax; ++rr)
+        if (q.a_upd[tixU(rr, c)] != k || q.ud_done[tixU(rr, c)] != 0) fail(r, 12);
+      if (q.t_done[(size_t)i * nt + c] >= q.t_need[(size_t)i * nt + c]) fail(r, 13);
+      // the scratch row's strip: free of its previous user (copied out, and no update of the chain still reads it)
+      int& wc = q.w_content[(size_t)g.slot * nt + c];
+      if (wc != k) {
+        if (wc >= 0) {
+          const int kp = wc;
+          if (!q.copied[(size_t)kp * nt + c]) fail(r, 15);
+          if (own(r, kp + 1))  // the chain's tiles of step kp read W: block row kp+1 against column c
+            for (int ii = tb[kp + 1]; ii < tb[kp + 2]; ++ii)
+              if (ii <= c && q.a_upd[tixU(ii, c)] < kp + 1) fail(r, 16);
+        }
+        wc = k;
+      }
+      ++q.t_done[(size_t)i * nt + c];
+    } else if (g.kind == DK_U || g.kind == DK_UD) {
+      const int f = g.f, lo = tb[k + f];
+      const int i = lo + t.tm * et / 128, j = lo + t.tn * et / 128;
+      if (i > j || j >= nt) fail(r, 20);
+      else {
+        if (!own(r, blk_of(i))) fail(r, 26);
+        if (g.from_w) {
+          if (f != 1 || !own(r, k) || !solved(q, k, i) || !solved(q, k, j)) fail(r, 21);
+          if (q.w_content[(size_t)g.slot * nt + i] != k || q.w_content[(size_t)g.slot * nt + j] != k || g.slot != ((k - r) / P) % 3) fail(r, 27);
+          if (blk_of(i) != k + 1) fail(r, 28);  // only the chain's tiles may read the scratch row (its reuse is ordered for those alone)
+        } else {
+          for (int z = 0; z < f; ++z)
+            if (!in_a(r, q, k + z, i) || !in_a(r, q, k + z, j)) fail(r, z == f - 1 ? 21 : 24);
+        }
+        if (q.a_upd[tixU(i, j)] != k) fail(r, 22);
+        if (g.kind == DK_U) {
+          if (q.ud_need[tixU(i, j)] != 0 && blk_of(i) == k + 1 && blk_of(j) == k + 1) fail(r, 23);
+          if (f > 1 && blk_of(i) < k + f + 1) fail(r, 25);
+          q.a_upd[tixU(i, j)] = k + f;
+        } else {
+          if (++q.ud_done[tixU(i, j)] == q.ud_need[tixU(i, j)]) {
+            q.ud_done[tixU(i, j)] = 0;
+            q.a_upd[tixU(i, j)] = k + 1;
+          }
+        }
+      }
+    } else if (g.kind == DK_CP) {
+      const int c = tb[k + 1] + t.tn;
+      if (!own(r, k) || !solved(q, k, c) || q.w_content[(size_t)g.slot * nt + c] != k) fail(r, 30);
+      if (q.copied[(size_t)k * nt + c]) fail(r, 31);
+      q.copied[(size_t)k * nt + c] = 1;
+    } else if (g.kind == DK_XB) {
+      const int f = g.f, lo = tb[k + f];
+      const int i = lo + t.tm;
+      const int j = g.own0 ? tb[k] + t.tn : glob(r, t.tn);
+      const int bj = j < nt ? blk_of(j) : B;
+      if (i >= nt || j >= nt || !own(r, bj)) fail(r, 46);
+      else {
+        if (g.own0 ? (bj != k || f != 1) : bj >= k) fail(r, 42);
+        if (f > 1 && blk_of(i) < k + f + 1) fail(r, 45);
+        for (int z = 0; z < f; ++z) {
+          if (!in_a(r, q, k + z, i)) fail(r, 40);
+          if (k + z == bj) {
+            if (!q.panel_done[k + z]) fail(r, 41);
+          } else {
+            for (int rr = tb[k + z]; rr < tb[k + z + 1]; ++rr)
+              if (!q.x_done[(size_t)rr * nt + j]) fail(r, 43);
+          }
+        }
+        if (q.t_acc[(size_t)i * nt + j] != k - bj) fail(r, 44);
+        q.t_acc[(size_t)i * nt + j] += f;
+      }
+    } else if (g.kind == DK_XA) {
+      const int i = tb[k] + t.tm, j = glob(r, t.tn), bj = j < nt ? blk_of(j) : B;
+      if (i >= nt || j >= nt || !own(r, bj) || bj >= k) fail(r, 51);
+      else {
+        if (!d_here(r, q, k)) fail(r, 50);
+        for (int rr = tb[k]; rr <= i; ++rr)
+          if (q.t_acc[(size_t)rr * nt + j] != k - bj) fail(r, 52);
+        if (q.x_done[(size_t)i * nt + j]) fail(r, 53);
+        q.x_done[(size_t)i * nt + j] = 1;
+      }
+    } else {
+      fail(r, 60);
+    }
+    for (int z = 0; z < 3; ++z)
+      if (t.wait_id[z] >= 0) ++waits;
+    for (int z = 0; z < 2; ++z)
+      if (t.inc_id[z] >= 0) {
+        q.counters[t.inc_id[z]] += t.inc_val[z];
+        ++nincs;
+      }
+    ++ran;
+    return true;
+  };
+  bool allow_lazy_g = true;
+  auto stream_step = [&](int r) -> bool {  // the panel stream of rank r
+    Rank& q = R[r];
+    const DagPlan* pl = q.plan;
+    if (q.op >= pl->stream_ops.size()) return false;
+    const DagPlan::Op o = pl->stream_ops[q.op];
+    if (o.kind == 0) {
+      if (q.counters[pl->c_g1d + o.arg] < pl->gate_target[o.arg]) return false;
+    } else if (o.kind == 1) {
+      const int b = o.arg;
+      if (r == lazy_rank && pl->c_pd + b == lazy_counter && !allow_lazy_g) return false;  // (a slow panel)
+      if (!own(r, b)) fail(r, 73);
+      for (int i = tb[b]; i < tb[b + 1]; ++i)
+        for (int j = i; j < tb[b + 1]; ++j)
+          if (q.a_upd[tixU(i, j)] != b || q.ud_done[tixU(i, j)] != 0) fail(r, 70);
+      if (q.panel_done[b]) fail(r, 71);
+      q.panel_done[b] = 1;
+    } else if (o.kind == 2) {
+      if (!q.panel_done[o.arg]) fail(r, 72);
+      if (r == lazy_rank && pl->c_pd + o.arg == lazy_counter && !allow_lazy_g) return false;  // (slow, not stuck)
+      ++q.counters[pl->c_pd + o.arg];
+    } else {
+      fail(r, 74);  // no filler launches in sharded lists
+    }
+    ++q.op;
+    return true;
+  };
+  // the communication stream of rank r: operation 2k = head of block row k, 2k + 1 = its tail
+  auto comm_step = [&](int r) -> bool {
+    Rank& q = R[r];
+    const DagPlan* pl = q.plan;
+    if (P == 1) return false;
+    while (q.cop < (size_t)2 * B && (q.cop & 1) && !has_tail((int)(q.cop / 2))) ++q.cop;
+    if (q.cop >= (size_t)2 * B) return false;
+    const int k = (int)(q.cop / 2);
+    const bool tail = q.cop & 1;
+    if (own(r, k)) {
+      // gates: the panel's signal, then the copies counted
+      if (q.counters[pl->c_pd + k] < 1) return false;
+      if (!tail && q.counters[pl->c_cph + k] < pl->cph_target[k]) return false;
+      if (tail && q.counters[pl->c_cpt + k] < pl->cpt_target[k]) return false;
+      if (!q.panel_done[k]) fail(r, 90);
+      for (int c = tail ? hi_of(k) : tb[k + 1]; c < (tail ? nt : hi_of(k)); ++c)
+        if (!q.copied[(size_t)k * nt + c]) fail(r, 91);
+      (tail ? q.sent_tail : q.sent_head)[k] = 1;
+    } else {
+      const Rank& ow = R[k % P];
+      if (!(tail ? ow.sent_tail : ow.sent_head)[k]) return false;
+      if (r == lazy_rank && (tail ? pl->c_art : pl->c_pd) + k == lazy_counter && !allow_lazy_g) return false;
+      (tail ? q.arr_tail : q.arr_head)[k] = 1;
+      ++q.counters[(tail ? pl->c_art : pl->c_pd) + k];
+    }
+    ++q.cop;
+    return true;
+  };
+  auto comm_done = [&](int r) {
+    if (P == 1) return true;
+    size_t c = R[r].cop;
+    while (c < (size_t)2 * B && (c & 1) && !has_tail((int)(c / 2))) ++c;
+    return c >= (size_t)2 * B;
+  };
+  const int mode = (lazy_counter >= 0 && (seed & 3u) == 0) ? 1 : (int)(seed & 3u);
+  allow_lazy_g = lazy_counter < 0;
+  const int Wn = std::max(W, 1);
+  while (!rc) {
+    bool progressed = false;
+    const int r0 = (int)(rnd() % P);
+    for (int rq = 0; rq < P && !rc; ++rq) {
+      const int r = (r0 + rq) % P;
+      Rank& q = R[r];
+      const int64_t ntasks = (int64_t)q.plan->tasks.size();
+      bool prog_r = false;
+      if (mode == 0 && rnd() % 8 == 0) prog_r = stream_step(r) || comm_step(r);
+      const int w0 = mode >= 2 ? 0 : (int)(rnd() % Wn);
+      for (int z = 0; z < Wn && !prog_r; ++z) {
+        const int w = mode == 2 ? Wn - 1 - z : (w0 + z) % Wn;
+        const int burst = (mode >= 2 || rnd() % 16 == 0) ? (1 << 30) : 1 + (int)(rnd() % 3);
+        for (int b = 0; b < burst; ++b) {
+          if (q.cur[w] < 0) {
+            if (q.head >= ntasks) break;
+            q.cur[w] = q.head++;
+            prog_r = true;
+            if (mode < 2 && rnd() % 4 != 0) break;
+            continue;
+          }
+          if (q.lazy[q.cur[w]] && !allow_lazy_g) break;
+          if (!try_task(r, q.plan->tasks[q.cur[w]])) break;
+          q.cur[w] = -1;
+          ++q.finished;
+          prog_r = true;
+        }
+      }
+      // a rank's streams move when its workers made no progress in this round
+      if (!prog_r) prog_r = stream_step(r);
+      if (!prog_r) prog_r = comm_step(r);
+      progressed |= prog_r;
+    }
+    bool all_done = true;
+    for (int r = 0; r < P; ++r)
+      all_done &= R[r].finished == (int64_t)R[r].plan->tasks.size() && R[r].op >= R[r].plan->stream_ops.size() && comm_done(r);
+    if (all_done) break;
+    if (!progressed && !allow_lazy_g) {
+      allow_lazy_g = true;  // nothing else can run: one round with the slow tasks / signals
+      continue;
+    }
+    if (lazy_counter >= 0) allow_lazy_g = false;
+    if (!progressed) fail(0, 2);  // deadlock
+  }
+  if (!rc)
+    for (int r = 0; r < P && !rc; ++r) {
+      const Rank& q = R[r];
+      for (int b = 0; b < B && !rc; ++b) {
+        if (own(r, b)) {
+          if (!q.panel_done[b]) fail(r, 80);
+          for (int c = tb[b + 1]; c < nt && !rc; ++c)
+            if (!q.copied[(size_t)b * nt + c]) fail(r, 81);
+        } else if (P > 1 && (!q.arr_head[b] || (has_tail(b) && !q.arr_tail[b]))) fail(r, 83);
+        for (int i = tb[b]; i < tb[b + 1] && !rc; ++i)
+          for (int j = 0; j < tb[b]; ++j)
+            if (own(r, blk_of(j)) && !q.x_done[(size_t)i * nt + j]) { fail(r, 82); break; }
+      }
+    }
+  if (stats) {
+    stats[0] = ran;
+    stats[1] = waits;
+    stats[2] = nincs;
+    stats[3] = mutate_in > 0 ? mutated : 0;
+  }
+  cleanup();
+  return rc;
 }

@@ -580,7 +580,10 @@ __global__ __launch_bounds__(64) void gpp_dag_bind(const GemmArgs* rel, GemmArgs
   const int g = blockIdx.x * 64 + threadIdx.x;
   if (g >= n) return;
   GemmArgs a = rel[g];
-  auto base = [&](int b) { return b == 0 ? bases.p[0] : b == 1 ? bases.p[1] : b == 2 ? bases.p[2] : bases.p[3]; };
+  auto base = [&](int b) {
+    return b == 0 ? bases.p[0] : b == 1 ? bases.p[1] : b == 2 ? bases.p[2] : b == 3 ? bases.p[3] : b == 4 ? bases.p[4] : b == 5 ? bases.p[5]
+                                                                                                     : b == 6 ? bases.p[6] : bases.p[7];
+  };
   a.A = reinterpret_cast<const double*>(base(a.buf[0]) + reinterpret_cast<uintptr_t>(a.A));
   a.B = reinterpret_cast<const double*>(base(a.buf[1]) + reinterpret_cast<uintptr_t>(a.B));
   a.C = reinterpret_cast<double*>(base(a.buf[2]) + reinterpret_cast<uintptr_t>(a.C));

@@ -42,6 +42,8 @@ struct gpp_handle_s {
   int panel_timeout_ms;      // GPP_OPT_PANEL_TIMEOUT_MS: budget of a wait inside the panel kernel (100 MHz constant clock)
   struct DagPlan* dag_plans[4];     // small LRU of DAG-executor plans (gpp_dag.hip), keyed by (N, nb, leading dimensions, flags)
   uint64_t dag_clock;
+  struct DagPlan* shard_cur;  // the sharded list between gpp_shard_list_begin and _end
+  int32_t* shard_info;
   int dag_sched;             // GPP_OPT_DAG_SCHED
 };
 constexpr int GPP_PANEL_RING = 8;
@@ -186,7 +188,8 @@ struct DagLaunch {
   int tag;
 };
 hipError_t gpp_launch_dag(hipStream_t s, int nworkers, const DagLaunch& e);
-struct DagBases { char* p[4]; };  // operand bases the groups' byte offsets refer to: A, Linv, T (a fourth is unused)
+struct DagBases { char* p[8]; };  // operand bases the groups' byte offsets refer to — single GPU: A, Linv, T; sharded list
+                                  // (DAG_SHARD): A, Kc, Lc, D, W0, W1, W2 (gp-plus_amd/sharded.py's buffers)
 hipError_t gpp_launch_dag_bind(hipStream_t s, const GemmArgs* rel, GemmArgs* abs, int n, const DagBases& bases);
 
 enum { DK_S = 0, DK_U = 1, DK_CP = 2, DK_XB = 3, DK_XA = 4, DK_SH = 5, DK_UD = 6, DK_NKINDS = 7 };
@@ -207,6 +210,11 @@ struct DagTuning {
 };
 struct DagPlan {
   int64_t N = 0, nb = 0, ld = 0, ldi = 0, ldt = 0, ldk = 0, inv_rows = 0;
+  int rank = 0, nranks = 1, workers = 0;            // DAG_SHARD: block-cyclic owner of block k is k % nranks; ldi = the compact buffers' leading
+                                       // dimension, ldt = the scratch rows'
+  int c_cph = 0, c_cpt = 0, c_art = 0; // DAG_SHARD: first ids of "head copied" / "tail copied" (gates of the owner's broadcasts) and
+                                       // "tail arrived" (signalled behind a received broadcast; the head's arrival raises c_pd + k)
+  std::vector<int> cph_target, cpt_target;
   int flags = 0;                       // DAG_INV: also the inverse (right-looking; all of it or its leading inv_rows block)
   int B = 0, nt = 0;
   std::vector<int> tb;                 // first tile of block b (tb[B] = nt)
@@ -228,8 +236,9 @@ struct DagPlan {
   hipEvent_t last_use = nullptr;       // recorded behind the launches that read the device copies
   uint64_t stamp = 0;                  // LRU
 };
-enum { DAG_INV = 1 };
-DagPlan* gpp_dag_plan(int64_t N, int64_t nb, int64_t ld, int64_t ldi, int64_t ldt, int64_t ldk, int flags, const DagTuning& tune);
+enum { DAG_INV = 1, DAG_SHARD = 4 };  // DAG_SHARD: one rank's list of the sharded evaluation (factor + forward sweep of its column blocks)
+DagPlan* gpp_dag_plan(int64_t N, int64_t nb, int64_t ld, int64_t ldi, int64_t ldt, int64_t ldk, int flags, const DagTuning& tune,
+                      int rank = 0, int nranks = 1);
 DagTuning gpp_dag_default_tuning();
 hipError_t gpp_dag_upload(DagPlan* P);
 void gpp_dag_free(DagPlan* P);

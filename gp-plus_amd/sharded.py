@@ -413,6 +413,83 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
     return int(info.item())
 
 
+#: GPP_SHARD_LIST=0: the launch-per-product factorisation and forward sweep of rounds 2-4 (also the library's own knob)
+_USE_LIST = os.environ.get("GPP_SHARD_LIST", "1") not in ("", "0")
+#: evaluations whose factorisation + forward sweep ran as a ticket list (tests)
+LIST_EVALS = 0
+#: work-groups of the list's executor (0 = two per throughput CU); tests in which several ranks share one GPU pass fewer
+_LIST_WORKERS = int(os.environ.get("GPP_SHARD_WORKERS", "0"))
+
+
+def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, grp, kind, d_split, jitter: float) -> Optional[int]:
+    """Build + Cholesky + the forward sweep (the owned column blocks of L^-1 into ``Kc``) as ONE ticket list per rank
+    (gpp_shard_list_begin in gpp.h; gp-plus_amd/csrc/gpp_dag.hip): tile tasks in dependency order taken by persistent work-groups,
+    the rank's diagonal blocks on the panel stream, and the messages of ``_factor`` — per block row a head (diagonal block, its
+    inverse, the columns of the next block) and a tail, in the same formats — on the communication stream, each behind a gate on
+    its owner (the list has copied those strips into place) and in front of a signal on its receivers (the list's tasks that read
+    them may run).  Returns the agreed info, or None when the list does not apply here (the caller runs ``_factor`` + ``_forward``)."""
+    N, offs, P, me, nb = ws.N, ws.offs, comm.world, comm.rank, ws.nb
+    nblk = len(offs) - 1
+    A = ws.A
+    if not ctx.dag_sched or me >= nblk:
+        return None
+    main = torch.cuda.current_stream(ctx.index)
+    cs = ws.comm_stream
+    ws.info.zero_()
+    for k in range(me, nblk, P):
+        ctx.kernel_build(U, w, sf2, tau, grp, A, jitter=jitter, kind=kind, d_split=d_split, uplo=UPLO_FULL, row0=offs[k],
+                         nrows=offs[k + 1] - offs[k])
+    if not ctx.shard_list_begin(N, nb, me, P, A, ws.Kc, ws.Lc, ws.D, ws.W2, ws.info[0:1], _LIST_WORKERS):
+        return None
+    try:
+        if comm.travel:
+            cs.wait_stream(main)
+            with torch.cuda.stream(cs):
+                for k in range(nblk):
+                    o, o1 = offs[k], offs[k + 1]
+                    o2 = offs[k + 2] if k + 2 <= nblk else N
+                    nbk, own = o1 - o, (k % P == me)
+                    Lkk = ws.dblk(k)
+                    wh = o2 - o
+                    head = ws.hbuf[:nbk * wh].view(nbk, wh)
+                    dblk = ws.hbuf[nbk * wh:nbk * (wh + nbk)].view(nbk, nbk)
+                    if own:
+                        ctx.shard_list_gate(cs, False, k)
+                        head.copy_(A[o:o1, o:o2])
+                        dblk.copy_(Lkk)
+                    comm.bcast(ws.hbuf[:nbk * (wh + nbk)], k % P)
+                    if not own:
+                        A[o:o1, o:o2].copy_(head)
+                        Lkk.copy_(dblk)
+                        ctx.shard_list_signal(cs, False, k)
+                    if N > o2:
+                        tail = ws.pack[:nbk * (N - o2)].view(nbk, N - o2)
+                        if own:
+                            ctx.shard_list_gate(cs, True, k)
+                            tail.copy_(A[o:o1, o2:N])
+                        comm.bcast(ws.pack[:nbk * (N - o2)], k % P)
+                        if not own:
+                            A[o:o1, o2:N].copy_(tail)
+                            ctx.shard_list_signal(cs, True, k)
+    finally:
+        ctx.shard_list_end()
+    main.wait_stream(cs)
+    global LIST_EVALS
+    LIST_EVALS += 1
+    # what the list leaves to the launches behind it: the owned diagonal blocks of L^-1 (lower triangles of D) into Kc, and the
+    # factor's mirror L = U^T into A's strict lower triangle, which the back-substitution reads row-contiguously
+    for c in range(me, nblk, P):
+        blk = ws.Kc[offs[c]:offs[c + 1], ws.col(c)]
+        blk.copy_(ws.dblk(c))
+        blk.tril_()
+    for k in range(nblk - 1):
+        o, o1 = offs[k], offs[k + 1]
+        ctx.transpose(A[o:o1, o1:N], A[o1:N, o:o1])
+    info = ws.info.max().to(torch.int32).reshape(1)
+    comm.allreduce(info, dist.ReduceOp.MAX)
+    return int(info.item())
+
+
 def _first_owned(ws: ShardedWorkspace, comm: _Comm) -> Optional[int]:
     return comm.rank if comm.rank < len(ws.offs) - 1 else None
 
@@ -556,7 +633,10 @@ class ShardedMLLFunction(torch.autograd.Function):
         while attempts:
             jit = attempts.pop(0)
             with _stage("shard_factor"):
-                info = _factor(gctx, comm, ws, Ud, wd, sd, td, grp, kind, d_split, jit)
+                info = _factor_list(gctx, comm, ws, Ud, wd, sd, td, grp, kind, d_split, jit) if _USE_LIST else None
+                swept = info is not None  # (the list builds the owned column blocks of L^-1 beside the factorisation)
+                if info is None:
+                    info = _factor(gctx, comm, ws, Ud, wd, sd, td, grp, kind, d_split, jit)
             if info >= INFO_PANEL_TIMEOUT:
                 # (the status is the MAX over the ranks: every rank sees it and repeats the attempt; the rank whose panel gave up —
                 #  or every rank, it costs 1-2 % — switches the panel off)
@@ -581,8 +661,9 @@ class ShardedMLLFunction(torch.autograd.Function):
         if used > 0:
             warnings.warn(f"A not p.d., added jitter of {used:.1e} to the diagonal", RuntimeWarning)
         need_grad = any(ctx.needs_input_grad[:6])
-        with _stage("shard_inverse"):
-            _forward(gctx, comm, ws)
+        if not swept:
+            with _stage("shard_inverse"):
+                _forward(gctx, comm, ws)
         torch.sub(f64(y), f64(mean), out=ws.r)
         comm.stage = "vectors"
         _vectors(gctx, comm, ws, need_alpha=need_grad)

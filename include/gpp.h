@@ -157,6 +157,28 @@ int gpp_gemm_lower_cols(gpp_handle_t h, const double* A, int64_t lda, const doub
                         int64_t M, int64_t K, double alpha, double beta, int64_t nb, int64_t first_block, int rank, int nranks,
                         int64_t row0, int64_t row1, int compact);
 
+/*
+ * The sharded evaluation's factorisation AND forward sweep of one rank as ONE ticket list of tile tasks (the executor of
+ * gpp_potrf_ws, gp-plus_amd/csrc/gpp_dag.hip, with the block-cyclic ownership built into the list): the rank's panels (diagonal blocks
+ * k % nranks == rank: factor in place in A, inverse + mirror into D[k]), row solves (through the scratch rows W0..W2, nb x N, ldw),
+ * its share of the trailing updates, and — right-looking beside them — the rows below the diagonal of ITS column blocks of
+ * X = L^-1 into Kc (compact, as in gpp_gemm_lower_cols; Lc: the running sums).  Block rows of other ranks arrive as messages the
+ * CALLER moves on a stream of its own (RCCL broadcasts in gp-plus_amd/sharded.py): per block row k a head (diagonal block, D[k], the
+ * columns of block k + 1) and a tail (the columns behind).  The owner enqueues gpp_shard_list_gate in front of packing each from A;
+ * a receiver enqueues gpp_shard_list_signal behind unpacking each into A / D.  Replaces the per-step launches of
+ * gp-plus_amd/sharded.py::_factor and ::_forward (reference counterpart: torch.linalg.cholesky + the solves of optim/mll_torch.py:114-117;
+ * the reference has no multi-GPU evaluation).  *used = 0: not applicable here (size, block height, options) — nothing was
+ * enqueued and the caller runs its launch-per-product path.  workers: work-groups of the executor (0 = two per throughput CU; tests
+ * that share one GPU between ranks pass fewer).  Between _begin and _end the handle runs nothing else.  A wait that exceeds
+ * GPP_SHARD_TIMEOUT_MS (default 60 000: it covers the other ranks' progress) sets GPP_INFO_EXEC_TIMEOUT in *info.
+ */
+int gpp_shard_list_begin(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nranks, double* A, int64_t ld, double* Kc, double* Lc,
+                         int64_t ldc, double* D, double* W0, double* W1, double* W2, int64_t ldw, int32_t* info, int workers,
+                         int* used);
+int gpp_shard_list_gate(gpp_handle_t h, void* stream, int tail, int k);
+int gpp_shard_list_signal(gpp_handle_t h, void* stream, int tail, int k);
+int gpp_shard_list_end(gpp_handle_t h);
+
 /* Products with a lower-triangular T of which only the block-cyclically owned COLUMN blocks (width nb, a multiple of 64; block
  * b owned when b % nranks == rank) exist on this rank:  trans = 0: y_i = sum over owned columns k <= i of T[i][k] x_k (this
  * rank's part of z = L^-1 r);  trans = 1: y_k = sum_{i >= k} T[i][k] x_i for the owned columns k and 0 for the others (this
