@@ -1036,7 +1036,10 @@ int gpp_shard_list_begin(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nr
   else {
     DagTuning tune = gpp_dag_default_tuning();
     tune.workers = nworkers;
-    tune.fill = 0;
+    // filler launches on the panel's CUs between this rank's panels (as in gpp_potrf_ws); not where ranks share one GPU (tests pass
+    // `workers`): another rank's panel needs those CUs while a filler here may be waiting for that very rank's message
+    static const int fill_env = getenv("GPP_SHARD_FILL") ? atoi(getenv("GPP_SHARD_FILL")) : -1;
+    tune.fill = fill_env >= 0 ? fill_env : (workers > 0 || tune.fill <= 0) ? 0 : 2 * h->panel_cus;
     tune.inv_rows = 0;
     if (!getenv("GPP_DAG_FUSE")) tune.fuse = N >= 14336 ? 4 : N >= 11264 ? 2 : 1;
     P = gpp_dag_plan(N, nb, ld, ldc, ldw, 0, flags, tune, rank, nranks);
@@ -1081,6 +1084,14 @@ int gpp_shard_list_begin(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nr
       GPP_TRY(launch_panel_at(h, cb, o, rows, h->panel_cus));
     } else if (op.kind == 2) {
       GPP_TRY(gpp_launch_exec_signal(sp, P->d_counters, P->c_pd + b));
+    } else {
+      DagLaunch fl = dl;
+      fl.max_tasks = op.arg;
+      fl.quit_id = op.n >= 0 ? P->c_g1d + op.n : -1;
+      fl.quit_val = 1;
+      fl.ticket_limit = op.lim;
+      fl.tag = op.n >= 0 ? op.n : P->B;
+      GPP_TRY(gpp_launch_dag(sp, 2 * h->panel_cus, fl));
     }
   }
   h->shard_cur = P;

@@ -933,15 +933,23 @@ struct Planner {
     const double t_tile = tile_cost(128, nb);
     fill_m.assign(B, 0);
     bool any = false;
-    for (int b = 0; b + 1 < B; ++b) {
-      const double idle = g_open[b + 1] - p_end[b] - 12.0;
+    std::vector<int> pb;  // the blocks whose panels run here, in order (a sharded list: the owned ones)
+    for (const Node& n : nodes)
+      if (n.kind == -1) pb.push_back(n.tm);
+    if (pb.empty()) {
+      fill_m.clear();
+      return;
+    }
+    for (size_t q = 0; q + 1 < pb.size(); ++q) {
+      const int b = pb[q], nx = pb[q + 1];
+      const double idle = g_open[nx] - p_end[b] - 12.0;
       const int m = (int)std::floor(idle / t_tile - 0.35);
-      fill_m[b] = std::max(0, std::min(m, 64));
+      fill_m[b] = std::max(0, std::min(m, 64 * (nx - b)));
       any |= fill_m[b] > 0;
     }
     // behind the LAST panel its CUs are free for good: a launch without a budget works the list to its end (the inverse's tasks)
-    if (makespan - p_end[B - 1] > 2.0 * t_tile) {
-      fill_m[B - 1] = 1 << 20;
+    if (makespan - p_end[pb.back()] > 2.0 * t_tile) {
+      fill_m[pb.back()] = 1 << 20;
       any = true;
     }
     if (any) simulate();
@@ -990,8 +998,11 @@ DagPlan* emit(Planner& pl) {
       }
       P->stream_ops.push_back({1, b, 0, 0});
       P->stream_ops.push_back({2, b, 0, 0});
-      if (!pl.fill_m.empty() && pl.fill_m[b] > 0 && (b + 1 == pl.B || first_of[b + 1] > 0))
-        P->stream_ops.push_back({3, b + 1 < pl.B ? pl.fill_m[b] : 0, b + 1 < pl.B ? b + 1 : -1, b + 1 < pl.B ? first_of[b + 1] : 0});
+      int nx = -1;  // the next block whose panel runs on this stream (a sharded list: the next owned one)
+      for (int c = b + 1; c < pl.B && nx < 0; ++c)
+        if (pl.own(c)) nx = c;
+      if (!pl.fill_m.empty() && pl.fill_m[b] > 0 && (nx < 0 || first_of[nx] > 0))
+        P->stream_ops.push_back({3, nx >= 0 ? pl.fill_m[b] : 0, nx, nx >= 0 ? first_of[nx] : 0});
       continue;
     }
     DagTask d;
@@ -1425,14 +1436,15 @@ extern "C" int gpp_debug_dag_sim(int64_t N, int64_t nb, int flags, int chain_til
 // operands' buffers and offsets — never from their counters.  Returns 0 or a code naming the first violation (+ 1000 * rank).
 // stats: tasks run, waits, increments, (with `mutate` > 0, which removes the mutate-th wait over all ranks' lists: the check must
 // then fail) kind * 10 + counter family of the task that lost its wait.
-extern "C" int gpp_debug_shard_check(int64_t N, int64_t nb, int nranks, int chain_tile, int W, unsigned seed, int64_t* stats, int mutate) {
+extern "C" int gpp_debug_shard_check(int64_t N, int64_t nb, int nranks, int chain_tile, int W, int fill, unsigned seed, int64_t* stats,
+                                     int mutate) {
   DagTuning tune = gpp_dag_default_tuning();
   if (chain_tile >= 1000) {
     tune.fuse = chain_tile / 1000;
     chain_tile %= 1000;
   }
   tune.chain_tile = chain_tile;
-  tune.fill = 0;
+  tune.fill = fill;
   tune.workers = std::max(W, 1);
   const int P = std::max(nranks, 1);
   const int64_t nblk = (N + nb - 1) / nb;
@@ -1442,8 +1454,12 @@ extern "C" int gpp_debug_shard_check(int64_t N, int64_t nb, int nranks, int chai
     std::vector<char> x_done, copied, panel_done, arr_head, arr_tail, sent_head, sent_tail, lazy;
     std::vector<int64_t> cur;
     size_t op = 0, cop = 0;
-    int64_t head = 0, finished = 0;
+    int64_t head = 0, finished = 0, fill_tasks = 0;
     int64_t ldc = 0;
+    // a filler launch in progress: its work-groups' current tickets (-1: none), tasks left
+    std::vector<int64_t> fcur;
+    std::vector<int> fleft;
+    bool in_fill = false;
   };
   std::vector<Rank> R(P);
   auto cleanup = [&]() {
@@ -1700,7 +1716,44 @@ extern "C" int gpp_debug_shard_check(int64_t N, int64_t nb, int nranks, int chai
       if (r == lazy_rank && pl->c_pd + o.arg == lazy_counter && !allow_lazy_g) return false;  // (slow, not stuck)
       ++q.counters[pl->c_pd + o.arg];
     } else {
-      fail(r, 74);  // no filler launches in sharded lists
+      // filler launch: `fill` work-groups, each takes up to o.arg tasks and none once the gate counter of block o.n has moved
+      const int64_t ntasks = (int64_t)pl->tasks.size();
+      if (!q.in_fill) {
+        q.in_fill = true;
+        q.fcur.assign(std::max(fill, 1), -1);
+        q.fleft.assign(std::max(fill, 1), o.arg > 0 ? o.arg : 1 << 30);
+      }
+      bool progressed = false, any_alive = false;
+      const size_t nf = q.fcur.size(), s0 = (size_t)(rnd() % nf);
+      for (size_t z = 0; z < nf; ++z) {
+        const size_t f = (s0 + z) % nf;
+        if (q.fcur[f] < 0) {
+          if (q.fleft[f] <= 0) continue;  // has left
+          if ((o.n >= 0 && q.counters[pl->c_g1d + o.n] >= 1) || q.head >= ntasks || (o.lim > 0 && q.head >= o.lim)) {
+            q.fleft[f] = 0;
+            progressed = true;
+            continue;
+          }
+          if (progressed) { any_alive = true; continue; }
+          q.fcur[f] = q.head++;
+          --q.fleft[f];
+          progressed = true;
+        }
+        any_alive = true;
+        if (!progressed || q.fcur[f] >= 0) {
+          if (q.lazy[q.fcur[f]] && !allow_lazy_g) continue;
+          if (try_task(r, pl->tasks[q.fcur[f]])) {
+            q.fcur[f] = -1;
+            ++q.finished;
+            ++q.fill_tasks;
+            progressed = true;
+          }
+        }
+      }
+      if (any_alive) return progressed;
+      for (size_t f = 0; f < nf; ++f)
+        if (q.fcur[f] >= 0 || q.fleft[f] > 0) return progressed;
+      q.in_fill = false;
     }
     ++q.op;
     return true;
@@ -1750,7 +1803,7 @@ extern "C" int gpp_debug_shard_check(int64_t N, int64_t nb, int nranks, int chai
       Rank& q = R[r];
       const int64_t ntasks = (int64_t)q.plan->tasks.size();
       bool prog_r = false;
-      if (mode == 0 && rnd() % 8 == 0) prog_r = stream_step(r) || comm_step(r);
+      if ((mode == 0 && rnd() % 8 == 0) || (q.in_fill && rnd() % 3 == 0)) prog_r = stream_step(r) || comm_step(r);
       const int w0 = mode >= 2 ? 0 : (int)(rnd() % Wn);
       for (int z = 0; z < Wn && !prog_r; ++z) {
         const int w = mode == 2 ? Wn - 1 - z : (w0 + z) % Wn;
@@ -1805,6 +1858,8 @@ extern "C" int gpp_debug_shard_check(int64_t N, int64_t nb, int nranks, int chai
     stats[1] = waits;
     stats[2] = nincs;
     stats[3] = mutate_in > 0 ? mutated : 0;
+    if (mutate_in <= 0)
+      for (const Rank& q : R) stats[3] += q.fill_tasks;
   }
   cleanup();
   return rc;

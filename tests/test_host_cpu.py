@@ -337,3 +337,66 @@ def test_dag_plan_check_notices_a_missing_wait():
                 panel[1] += any(rcs)
         assert caught >= need * total, (W, caught, total)
         assert panel[0] > 0 and panel[1] >= need_panel * panel[0], (W, panel)
+
+
+def _shard_check():
+    import ctypes
+
+    from gpplus_amd import _lib
+
+    lib = _lib.load()
+    f = lib.gpp_debug_shard_check
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint,
+                  ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
+    return f, (ctypes.c_int64 * 4)()
+
+
+@pytest.mark.parametrize("N,nb,P,chain_tile,W,fill", [
+    (9000, 1024, 1, 64, 448, 64), (9000, 512, 2, 4064, 448, 0), (10000, 1024, 3, 64, 144, 0), (20000, 1024, 2, 4064, 448, 64),
+    (20000, 1024, 8, 4064, 448, 64),   # as the C2 test case on 8 ranks: fused groups of 4 steps, fillers between the owned panels
+    (6100, 384, 4, 2064, 3, 2),        # P does not divide the block count (16 blocks), three workers per rank
+    (4200, 384, 3, 128, 1, 1),         # ONE worker per rank executes its list in order
+    (5000, 512, 12, 64, 5, 1),         # more ranks than blocks: planned for the ranks that own one (the others run the launches)
+    (30000, 1024, 5, 4064, 448, 64)])
+def test_sharded_lists_are_valid_schedules_under_any_interleaving(N, nb, P, chain_tile, W, fill):
+    """The per-rank ticket lists of the sharded evaluation (gpp_dag.hip, DAG_SHARD: each rank's panels, row solves, its share of the
+    trailing updates and its column blocks of L^-1), ALL ranks executed together on the host — W workers + filler launches per rank,
+    each rank's panel stream, and the communication streams as gp-plus_amd/sharded.py drives them (head then tail of every block
+    row, the owner behind its gates, a receiver's signal behind the owner's send) — in random and adversarial interleavings.  Checked
+    from the tasks' geometry alone: a task reads another rank's block row only after its message arrived, its own only after the
+    copy into place (or, on the chain, the complete solve in the scratch row it still holds), scratch rows are reused only when
+    copied out and no longer read, updates and the inverse's sums are applied in order and exactly once on tiles the rank owns, a
+    message is packed only from complete strips, nothing deadlocks, everything is complete on every rank at the end."""
+    f, st = _shard_check()
+    if P > -(-N // nb):
+        assert f(N, nb, P, chain_tile, W, fill, 0, st, 0) == 1  # (no plan for a rank without blocks: the caller's launch path)
+        return
+    by_fillers = 0
+    for seed in range(6):
+        rc = f(N, nb, P, chain_tile, W, fill, seed, st, 0)
+        assert rc == 0, (seed, rc)
+        by_fillers = max(by_fillers, int(st[3]))
+    assert st[0] > 0 and st[1] > 0 and st[2] > 0
+    assert (by_fillers > 0) == (fill > 0)
+
+
+def test_sharded_list_check_notices_a_missing_wait():
+    """With ONE wait removed from one rank's list — and what raises that counter made slow: its tasks, the panel, or the arrival of
+    the message — the joint execution must find a violation in most cases (some waits are implied by the others: the scratch row's
+    reuse behind the copy, the own panel behind the strip's copy)."""
+    f, st = _shard_check()
+    for P, W, need in ((3, 448, 0.8), (1, 448, 0.8), (2, 1024, 0.8)):
+        f(9000, 512, P, 4064, W, 0, 0, st, 0)
+        nwaits = int(st[1])
+        caught = total = 0
+        remote = [0, 0]
+        for mut in range(1, nwaits, 1613):
+            rcs = [f(9000, 512, P, 4064, W, 0, seed, st, mut) for seed in range(4)]
+            total += 1
+            caught += any(rcs)
+            if int(st[3]) % 10 == 9:  # the removed wait was for a tail message (ART)
+                remote[0] += 1
+                remote[1] += any(rcs)
+        assert caught >= need * total, (P, W, caught, total)
+        assert P == 1 or (remote[0] > 0 and remote[1] >= 0.7 * remote[0]), (P, remote)
