@@ -46,6 +46,8 @@ _SIGNATURES = {
     "gpp_shard_list_gate": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "gpp_shard_list_signal": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "gpp_shard_list_end": (c_int, [c_void_p]),
+    "gpp_shard_back_list": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
+                                    c_void_p, c_int, POINTER(c_int)]),
     "gpp_trmv_lower_cols": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int]),
     "gpp_mll_scalars": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p]),
     "gpp_grad_reduce_cols": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,

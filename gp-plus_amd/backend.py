@@ -275,6 +275,16 @@ class GppContext:
         check(self.lib.gpp_shard_list_end(self.h), "gpp_shard_list_end")
 
     @_on_own_device
+    def shard_back_list(self, N, nb, rank, nranks, A, Kc, Lc, D, info, workers=0) -> bool:
+        """The sharded back-substitution of this rank as one ticket list on the current stream (gpp_shard_back_list in gpp.h).
+        False: not applicable here, nothing was enqueued."""
+        self._stream()
+        used = ctypes.c_int(0)
+        check(self.lib.gpp_shard_back_list(self.h, N, nb, rank, nranks, A.data_ptr(), _ld(A), Kc.data_ptr(), Lc.data_ptr(), _ld(Kc),
+                                           D.data_ptr(), info.data_ptr(), int(workers), ctypes.byref(used)), "gpp_shard_back_list")
+        return bool(used.value)
+
+    @_on_own_device
     def gemm_lower_cols(self, A, B, C, alpha, beta, nb, first_block, rank, nranks, row0=0, row1=None, compact=False):
         """C(lower, owned column blocks of width nb) = beta C + alpha A^T B;  A, B: K x M row-contiguous, C: M x M; rows
         [row0, row1) of C only.  ``compact``: B (K rows) and C (M rows) hold only the owned column blocks, side by side."""

@@ -1136,6 +1136,73 @@ int gpp_shard_list_end(gpp_handle_t h) {
   return 0;
 }
 
+int gpp_shard_back_list(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nranks, const double* A, int64_t ld, double* Kc, double* Lc,
+                        int64_t ldc, const double* D, int32_t* info, int workers, int* used) {
+  if (!h) return -1;
+  if (!used) return -14;
+  *used = 0;
+  if (N < 2 || nb < 128 || nb % 128 != 0) return -2;
+  if (rank < 0 || nranks < 1 || rank >= nranks) return -4;
+  if (int e = check_mat(A, ld, N, 6)) return e;
+  if (!Kc || !aligned16(Kc)) return -8;
+  if (!Lc || !aligned16(Lc)) return -9;
+  const int64_t wc = ((N + nb - 1) / nb - rank + nranks - 1) / nranks * nb;
+  if ((ldc & 1) || ldc < wc) return -10;
+  if (!D || !aligned16(D)) return -11;
+  if (!info) return -12;
+  static const bool list_env = !(getenv("GPP_SHARD_LIST") && atoi(getenv("GPP_SHARD_LIST")) == 0) &&
+                               !(getenv("GPP_SHARD_BACK_LIST") && atoi(getenv("GPP_SHARD_BACK_LIST")) == 0);
+  static const int64_t list_min = getenv("GPP_SHARD_LIST_MIN_N") ? atol(getenv("GPP_SHARD_LIST_MIN_N")) : 4096;
+  if (!list_env || !h->dag_sched || N < list_min || N > 65536 || h->shard_cur) return 0;
+  GPP_TRY(ensure_streams(h));
+  const int flags = DAG_SHARD | DAG_BACK;
+  DagPlan* P = nullptr;
+  int slot = -1, lru = 0;
+  for (int i = 0; i < 4; ++i) {
+    DagPlan* q = h->dag_plans[i];
+    if (q && q->N == N && q->nb == nb && q->ld == ld && q->ldi == ldc && q->flags == flags && q->rank == rank && q->nranks == nranks &&
+        q->workers == workers)
+      slot = i;
+    if (!q) lru = i;
+    else if (h->dag_plans[lru] && q->stamp < h->dag_plans[lru]->stamp) lru = i;
+  }
+  const int nworkers = workers > 0 ? workers : 2 * h->ncu;
+  if (slot >= 0) P = h->dag_plans[slot];
+  else {
+    DagTuning tune = gpp_dag_default_tuning();
+    tune.workers = nworkers;
+    tune.fill = 0;
+    tune.inv_rows = 0;
+    if (!getenv("GPP_DAG_FUSE")) tune.fuse = N >= 14336 ? 4 : N >= 11264 ? 2 : 1;
+    P = gpp_dag_plan(N, nb, ld, ldc, ld, 0, flags, tune, rank, nranks);
+    if (!P) return 0;
+    P->workers = workers;
+    if (P->tasks.empty() || gpp_dag_upload(P) != hipSuccess) {
+      (void)hipGetLastError();
+      gpp_dag_free(P);
+      return 0;
+    }
+    if (h->dag_plans[lru]) gpp_dag_free(h->dag_plans[lru]);
+    h->dag_plans[lru] = P;
+  }
+  P->stamp = ++h->dag_clock;
+  hipStream_t sm = h->stream;
+  GPP_TRY(gpp_launch_fill_i32(sm, P->d_counters, P->ncounters, 0));
+  DagBases bases{{const_cast<char*>(reinterpret_cast<const char*>(A)), reinterpret_cast<char*>(Kc), reinterpret_cast<char*>(Lc),
+                  const_cast<char*>(reinterpret_cast<const char*>(D)), nullptr, nullptr, nullptr, nullptr}};
+  GPP_TRY(gpp_launch_dag_bind(sm, P->d_groups, P->d_groups_abs, (int)P->groups.size(), bases));
+  DagLaunch dl{};
+  dl.groups = P->d_groups_abs; dl.tasks = P->d_tasks; dl.ntasks = (int)P->tasks.size();
+  dl.counters = P->d_counters; dl.info = info;
+  dl.budget = (long long)(h->panel_timeout_ms > 0 ? h->panel_timeout_ms : 500) * 100000 * 4;  // (every wait is for this rank's own tasks)
+  dl.max_tasks = 0; dl.quit_id = -1; dl.quit_val = 0; dl.ticket_limit = 0;
+  dl.trace = P->d_trace; dl.tag = 0;
+  GPP_TRY(gpp_launch_dag(sm, nworkers, dl));
+  GPP_TRY(hipEventRecord(P->last_use, sm));
+  *used = 1;
+  return 0;
+}
+
 size_t gpp_workspace_bytes(gpp_handle_t h, int op, int64_t N, int64_t M, int D, int S) {
   (void)h;
   (void)M;

@@ -65,6 +65,10 @@ struct Planner {
   int c_cpd = 0, c_cph = 0, c_cpt = 0, c_art = 0;
   std::vector<int> cph_n, cpt_n;  // copies that raise CPH(k) / CPT(k)
   bool own(int b) const { return b % nranks == rank; }
+  int c_zs = 0, c_yr = 0, c_vy = 0;  // DAG_BACK
+  int ZS(int b, int c) const { return c_zs + b * nt + c; }
+  int YR(int b, int c) const { return c_yr + b * nt + c; }
+  int VY(int i, int j) const { return c_vy + (int)((int64_t)i * (i + 1) / 2 + j); }  // i >= j
   int CPD(int b, int c) const { return c_cpd + b * nt + c; }
   int CPH(int b) const { return c_cph + b; }
   int CPT(int b) const { return c_cpt + b; }
@@ -152,6 +156,16 @@ struct Planner {
         if (!aligned || tune.inv_rows % GPP_TILE != 0) return false;
       }
     }
+    if (flags & DAG_BACK) {
+      if (!(flags & DAG_SHARD) || B != (nt + bt - 1) / bt || rank < 0 || rank >= nranks || rank >= B) return false;
+      c_zs = ncounters; ncounters += B * nt;
+      c_yr = ncounters; ncounters += B * nt;
+      c_vy = ncounters; ncounters += (int)((int64_t)nt * (nt + 1) / 2);
+      chain.assign(ncounters, 0);
+      for (int c = c_vy; c < ncounters; ++c) chain[c] = 1;
+      incs.assign(ncounters, {});
+      return true;
+    }
     c_pd = ncounters; ncounters += B;
     c_g1d = ncounters; ncounters += B;
     c_ur = ncounters; ncounters += B * nt;
@@ -182,6 +196,10 @@ struct Planner {
   }
 
   void generate() {
+    if (flags & DAG_BACK) {
+      generate_back();
+      return;
+    }
     if (flags & DAG_SHARD) {
       generate_sharded();
       return;
@@ -736,6 +754,123 @@ struct Planner {
           if (k - bj > 0) wait(n, VT(i, j), k - bj);
           if (fin) inc(n, XR(k + 1, j));
           else inc(n, VT(i, j));
+        }
+      }
+    }
+  }
+
+  // ---- the sharded evaluation's BACK-substitution of one rank (gp-plus_amd/sharded.py::_backward; DAG_SHARD | DAG_BACK) -----------------
+  // The owned column blocks Y of L^-1 (Kc, compact) become the same column blocks of Ky^-1 = L^-T L^-1 (Lc), rows at and below each
+  // block's diagonal, right-looking from the last block row up:  Z_j = X_jj^T Y_j, then Y_i -= U[i, j] Z_j for the rows i above.
+  // Buffers: 0 A (the factor's mirror L in its strict lower triangle: L[j rows, i] = U[i, j]^T, row-contiguous), 1 Kc, 2 Lc, 3 D.
+  //   ZA(j; r, jc)  Lc[j rows, jc] = X_jj^T Kc[j rows, jc] for the owned column blocks left of block j (tile row r: K from its own rows
+  //                 down);  after the block row's last update (YR(j, .), raised by step j + 1's tasks on it);  raises ZS(j, jc)
+  //   ZD(j; r, c)   the owned diagonal block of Ky^-1: both operands lower triangular, lower tiles only; nothing depends on it
+  //   ZU(j; i, jc)  Kc[i, jc] -= L[j rows, i]^T Lc[j rows, jc] for the tiles i above block j, at and below the column's diagonal tile:
+  //                 after the strip (ZS) and the tile's previous update (VY); far tiles take f steps' updates at once (K = the f
+  //                 blocks' rows, adjacent in the mirror and in Lc), as in the factorisation's list
+  // No panels, no messages: one launch over every CU.
+  void generate_back() {
+    const int me = rank;
+    const int bt = (int)(nb / GPP_TILE);
+    const int64_t ldc = ldi;
+    cur_lvl = 0;
+    auto group_of = [&](int j, int f) {  // the aligned group of f steps that contains step j: (first processed = largest j, last)
+      const int t = B - 1 - j, tg0 = t - t % f;
+      return std::make_pair(B - 1 - tg0, B - 1 - tg0 - f + 1);
+    };
+    auto fuse_of = [&](int bi, int j) {
+      for (int f = std::min(tune.fuse, 4); f >= 2; f >>= 1) {
+        const auto g = group_of(j, f);
+        if (g.second >= me + 1 && bi <= g.second - 2) return f;
+      }
+      return 1;
+    };
+    for (int j = B - 1; j >= me; --j) {
+      const int btk = tb[j + 1] - tb[j];
+      const int64_t o = (int64_t)tb[j] * 128, nbj = rows_of(j);
+      const int64_t dk = (int64_t)j * nb * nb;
+      const int nl = nleft(j);
+      if (nl > 0) {
+        GemmArgs g{};
+        g.A = off(dk); g.lda = nb; g.buf[0] = 3;
+        g.B = off(o * ldc); g.ldb = ldc; g.buf[1] = 1;
+        g.C = offw(o * ldc); g.ldc = ldc; g.buf[2] = 2;
+        g.buf[3] = -1;
+        g.M = (int)nbj; g.N = (int)(nl * nb); g.K = (int)nbj;
+        g.alpha = 1.0; g.beta = 0.0;
+        g.a_mask = 2; g.klo_mode = 1;
+        g.pad_ok = 1;
+        const int gi = add_group(g, DK_XA, j);
+        for (int r = 0; r < btk; ++r)
+          for (int jc = 0; jc < nl * bt; ++jc) {
+            const int gj = glob_tile(jc);
+            const int n = add_node(gi, r, jc, DK_XA, tile_cost(128, nbj - (int64_t)r * 128));
+            if (j < B - 1) wait(n, YR(j, gj), ALL);
+            inc(n, ZS(j, gj));
+          }
+      }
+      if (own(j)) {
+        GemmArgs g{};
+        g.A = off(dk); g.lda = nb; g.buf[0] = 3;
+        g.B = off(o * ldc + (int64_t)nl * nb); g.ldb = ldc; g.buf[1] = 1;
+        g.C = offw(o * ldc + (int64_t)nl * nb); g.ldc = ldc; g.buf[2] = 2;
+        g.buf[3] = -1;
+        g.M = g.N = g.K = (int)nbj;
+        g.alpha = 1.0; g.beta = 0.0;
+        g.a_mask = 2; g.b_mask = 2; g.klo_mode = 3;
+        g.c_lower = 1;
+        g.pad_ok = 1;
+        const int gi = add_group(g, DK_S, j);
+        for (int r = 0; r < btk; ++r)
+          for (int c = 0; c <= r; ++c) {
+            const int n = add_node(gi, r, c, DK_S, tile_cost(128, nbj - (int64_t)r * 128));
+            if (j < B - 1) wait(n, YR(j, tb[j] + c), ALL);
+          }
+      }
+      if (nl == 0 || j <= me) continue;
+      GemmArgs u{};
+      u.A = off(o * ld); u.lda = ld; u.buf[0] = 0;
+      u.B = off(o * ldc); u.ldb = ldc; u.buf[1] = 2;
+      u.C = offw(0); u.ldc = ldc; u.buf[2] = 1;
+      u.buf[3] = -1;
+      u.M = (int)o; u.N = (int)(nl * nb); u.K = (int)nbj;
+      u.alpha = -1.0; u.beta = 1.0;
+      u.pad_ok = 1;
+      const int gU = add_group(u, DK_U, j);
+      int gUf[5] = {-1, -1, -1, -1, -1};
+      int64_t Kf[5] = {0, 0, 0, 0, 0};
+      int jg_of[5] = {0, 0, 0, 0, 0};
+      for (int f = 2; f <= std::min(tune.fuse, 4); f <<= 1) {
+        const auto g = group_of(j, f);
+        if (g.second != j || g.first > B - 1 || j < me + 1) continue;
+        GemmArgs uf = u;
+        Kf[f] = std::min<int64_t>((int64_t)tb[g.first + 1] * 128, N) - o;  // rows of blocks j .. j + f - 1
+        uf.K = (int)Kf[f];
+        gUf[f] = add_group(uf, DK_U, j);
+        jg_of[f] = g.first;
+      }
+      for (int i = tb[me]; i < tb[j]; ++i) {
+        const int bi = blk_of(i);
+        const int f = fuse_of(bi, j);
+        for (int jc = 0; jc < nl * bt; ++jc) {
+          const int gj = glob_tile(jc);
+          if (i < gj) continue;  // above the column's diagonal tile
+          if (f > 1) {
+            const auto g = group_of(j, f);
+            if (j != g.second) continue;  // taken with the group's last step
+            // (the columns of the group's own blocks take part from their own steps on: those tiles are never "far")
+            const int n = add_node(gUf[f], i, jc, DK_U, tile_cost(128, Kf[f]));
+            wait(n, ZS(j, gj), ALL);
+            if (B - 1 - g.first > 0) wait(n, VY(i, gj), B - 1 - g.first);
+            inc(n, VY(i, gj), f);
+            continue;
+          }
+          const int n = add_node(gU, i, jc, DK_U, tile_cost(128, nbj));
+          wait(n, ZS(j, gj), ALL);
+          if (B - 1 - j > 0) wait(n, VY(i, gj), B - 1 - j);
+          if (bi == j - 1) inc(n, YR(j - 1, gj));
+          else inc(n, VY(i, gj));
         }
       }
     }
@@ -1862,5 +1997,152 @@ extern "C" int gpp_debug_shard_check(int64_t N, int64_t nb, int nranks, int chai
       for (const Rank& q : R) stats[3] += q.fill_tasks;
   }
   cleanup();
+  return rc;
+}
+
+// The back-substitution's list of ONE rank (no messages, no panels) on the host, as above: W workers, random / adversarial
+// interleavings, the checks from the tasks' geometry: a row of Z is built from final rows of Y, an update reads complete rows of Z and
+// is applied in order and exactly once, only to tiles at and below the diagonal of column blocks the rank owns; everything complete.
+extern "C" int gpp_debug_shard_back_check(int64_t N, int64_t nb, int nranks, int rank, int fuse, int W, unsigned seed, int64_t* stats,
+                                          int mutate) {
+  DagTuning tune = gpp_dag_default_tuning();
+  tune.fuse = std::max(fuse, 1);
+  tune.fill = 0;
+  tune.workers = std::max(W, 1);
+  const int P = std::max(nranks, 1);
+  const int64_t nblk = (N + nb - 1) / nb;
+  int64_t nq = 0;
+  for (int64_t b = rank; b < nblk; b += P) ++nq;
+  const int64_t ldc = std::max<int64_t>(nq, 1) * nb;
+  DagPlan* pl = gpp_dag_plan(N, nb, N, ldc, N, N, DAG_SHARD | DAG_BACK, tune, rank, P);
+  if (!pl) return 1;
+  const int nt = pl->nt, B = pl->B, bt = (int)(nb / GPP_TILE);
+  const std::vector<int> tb = pl->tb;
+  auto blk_of = [&](int tile) { return (int)(std::upper_bound(tb.begin(), tb.end(), tile) - tb.begin()) - 1; };
+  auto elems = [](const void* p) { return (int64_t)(reinterpret_cast<uintptr_t>(p) / 8); };
+  auto glob = [&](int jc) { return (rank + (jc / bt) * P) * bt + jc % bt; };
+  auto own = [&](int b) { return b % P == rank; };
+  int mutated = -1, lazy_counter = -1;
+  const int mutate_in = mutate;
+  if (mutate > 0) {
+    int seen = 0;
+    for (auto& t : pl->tasks)
+      for (int z = 0; z < 3 && mutate > 0; ++z)
+        if (t.wait_id[z] >= 0 && ++seen == mutate) {
+          lazy_counter = t.wait_id[z];
+          mutated = 10 * t.kind + (lazy_counter < 2 + B * nt ? 0 : lazy_counter < 2 + 2 * B * nt ? 1 : 2);  // ZS, YR, VY
+          t.wait_id[z] = -1;
+          mutate = 0;
+        }
+  }
+  std::vector<char> lazy(pl->tasks.size(), 0);
+  if (lazy_counter >= 0)
+    for (size_t t = 0; t < pl->tasks.size(); ++t) lazy[t] = pl->tasks[t].inc_id[0] == lazy_counter || pl->tasks[t].inc_id[1] == lazy_counter;
+  std::vector<int> counters(pl->ncounters, 0), y_upd((size_t)nt * nt, 0);
+  std::vector<char> z_done((size_t)nt * nt, 0), zd_done((size_t)nt * nt, 0);
+  uint64_t rng = 0x9E3779B97F4A7C15ull ^ seed;
+  auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+  int rc = 0;
+  int64_t ran = 0, waits = 0, nincs = 0;
+  auto fail = [&](int code) { if (!rc) rc = code; };
+  auto try_task = [&](const DagTask& t) -> bool {
+    for (int z = 0; z < 3; ++z)
+      if (t.wait_id[z] >= 0 && counters[t.wait_id[z]] < t.wait_val[z]) return false;
+    const GemmArgs& a = pl->groups[t.group];
+    if (a.buf[2] == 2 && a.c_lower == 0) {  // ZA
+      const int j = (int)(elems(a.A) / (nb * nb)), i = tb[j] + t.tm, gj = glob(t.tn);
+      if (j < rank || j >= B || i >= tb[j + 1] || gj >= tb[j] || !own(blk_of(gj))) fail(10);
+      else {
+        for (int ii = i; ii < tb[j + 1]; ++ii)
+          if (y_upd[(size_t)ii * nt + gj] != B - 1 - j) fail(11);  // a row of Y still to be updated
+        if (z_done[(size_t)i * nt + gj]) fail(12);
+        z_done[(size_t)i * nt + gj] = 1;
+      }
+    } else if (a.buf[2] == 2) {  // ZD
+      const int j = (int)(elems(a.A) / (nb * nb)), i = tb[j] + t.tm, c = tb[j] + t.tn;
+      if (j >= B || !own(j) || i >= tb[j + 1] || c > i) fail(20);
+      else {
+        for (int ii = i; ii < tb[j + 1]; ++ii)
+          if (y_upd[(size_t)ii * nt + c] != B - 1 - j) fail(21);
+        if (zd_done[(size_t)i * nt + c]) fail(22);
+        zd_done[(size_t)i * nt + c] = 1;
+      }
+    } else if (a.buf[2] == 1) {  // ZU
+      const int jl = (int)(elems(a.A) / pl->ld / nb);
+      int f = 1;
+      while (jl + f < B && (int64_t)a.K > std::min<int64_t>((int64_t)tb[jl + f] * 128, N) - (int64_t)tb[jl] * 128) ++f;
+      const int i = t.tm, gj = glob(t.tn);
+      if (jl + f > B || i >= tb[jl] || gj > i || gj >= nt || !own(blk_of(gj))) fail(30);
+      else {
+        for (int z = 0; z < f; ++z)
+          for (int rr = tb[jl + z]; rr < tb[jl + z + 1]; ++rr)
+            if (!z_done[(size_t)rr * nt + gj]) fail(z == 0 ? 31 : 34);
+        if (y_upd[(size_t)i * nt + gj] != B - 1 - (jl + f - 1)) fail(32);
+        if (f > 1 && blk_of(i) > jl - 2) fail(33);
+        y_upd[(size_t)i * nt + gj] += f;
+      }
+    } else {
+      fail(60);
+    }
+    for (int z = 0; z < 3; ++z)
+      if (t.wait_id[z] >= 0) ++waits;
+    for (int z = 0; z < 2; ++z)
+      if (t.inc_id[z] >= 0) {
+        counters[t.inc_id[z]] += t.inc_val[z];
+        ++nincs;
+      }
+    ++ran;
+    return true;
+  };
+  const int mode = (lazy_counter >= 0 && (seed & 3u) == 0) ? 1 : (int)(seed & 3u);
+  const int Wn = std::max(W, 1);
+  std::vector<int64_t> cur(Wn, -1);
+  const int64_t ntasks = (int64_t)pl->tasks.size();
+  int64_t head = 0, finished = 0;
+  bool allow_lazy = lazy_counter < 0;
+  while (!rc && finished < ntasks) {
+    bool progressed = false;
+    const int w0 = mode >= 2 ? 0 : (int)(rnd() % Wn);
+    for (int z = 0; z < Wn && !progressed; ++z) {
+      const int w = mode == 2 ? Wn - 1 - z : (w0 + z) % Wn;
+      const int burst = (mode >= 2 || rnd() % 16 == 0) ? (1 << 30) : 1 + (int)(rnd() % 3);
+      for (int b = 0; b < burst; ++b) {
+        if (cur[w] < 0) {
+          if (head >= ntasks) break;
+          cur[w] = head++;
+          progressed = true;
+          if (mode < 2 && rnd() % 4 != 0) break;
+          continue;
+        }
+        if (lazy[cur[w]] && !allow_lazy) break;
+        if (!try_task(pl->tasks[cur[w]])) break;
+        cur[w] = -1;
+        ++finished;
+        progressed = true;
+      }
+    }
+    if (!progressed && !allow_lazy) {
+      allow_lazy = true;
+      continue;
+    }
+    if (lazy_counter >= 0) allow_lazy = false;
+    if (!progressed) fail(2);
+  }
+  if (!rc)
+    for (int j = rank; j < B && !rc; ++j)
+      for (int i = tb[j]; i < tb[j + 1] && !rc; ++i)
+        for (int gj = 0; gj <= i; ++gj) {
+          const int bj = blk_of(gj);
+          if (!own(bj)) continue;
+          if (y_upd[(size_t)i * nt + gj] != B - 1 - j) fail(80);
+          if (bj < j ? !z_done[(size_t)i * nt + gj] : !zd_done[(size_t)i * nt + gj]) fail(81);
+        }
+  if (stats) {
+    stats[0] = ran;
+    stats[1] = waits;
+    stats[2] = nincs;
+    stats[3] = mutate_in > 0 ? mutated : 0;
+  }
+  gpp_dag_free(pl);
   return rc;
 }

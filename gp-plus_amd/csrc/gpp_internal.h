@@ -236,7 +236,7 @@ struct DagPlan {
   hipEvent_t last_use = nullptr;       // recorded behind the launches that read the device copies
   uint64_t stamp = 0;                  // LRU
 };
-enum { DAG_INV = 1, DAG_SHARD = 4 };  // DAG_SHARD: one rank's list of the sharded evaluation (factor + forward sweep of its column blocks)
+enum { DAG_INV = 1, DAG_SHARD = 4, DAG_BACK = 8 };  // DAG_SHARD: one rank's list of the sharded evaluation (factor + forward sweep of its column blocks)
 DagPlan* gpp_dag_plan(int64_t N, int64_t nb, int64_t ld, int64_t ldi, int64_t ldt, int64_t ldk, int flags, const DagTuning& tune,
                       int rank = 0, int nranks = 1);
 DagTuning gpp_dag_default_tuning();

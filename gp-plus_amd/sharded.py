@@ -417,6 +417,7 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
 _USE_LIST = os.environ.get("GPP_SHARD_LIST", "1") not in ("", "0")
 #: evaluations whose factorisation + forward sweep ran as a ticket list (tests)
 LIST_EVALS = 0
+BACK_LIST_EVALS = 0
 #: work-groups of the list's executor (0 = two per throughput CU); tests in which several ranks share one GPU pass fewer
 _LIST_WORKERS = int(os.environ.get("GPP_SHARD_WORKERS", "0"))
 
@@ -573,6 +574,19 @@ def _backward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
     A, Lc, Kc = ws.A, ws.Lc, ws.Kc
     if _first_owned(ws, comm) is None:
         return
+    if _USE_LIST and ctx.dag_sched:
+        # the same sweep as ONE ticket list (gpp_shard_back_list in gpp.h).  The diagonal blocks of Ky^-1 are written as lower
+        # triangles: clear what the forward sweep's sums left above them first
+        for c in range(me, nblk, P):
+            Lc[offs[c]:offs[c + 1], ws.col(c)].zero_()
+        if ctx.shard_back_list(ws.N, nb, me, P, A, Kc, Lc, ws.D, ws.info[0:1], _LIST_WORKERS and 2 * _LIST_WORKERS):
+            global BACK_LIST_EVALS
+            BACK_LIST_EVALS += 1
+            st = int(ws.info[0].item())  # (a wait inside the list that ran out of its budget must not pass as a result)
+            if st:
+                from .backend import check_status
+                check_status(st)
+            return
     oc0 = offs[me]
     main = torch.cuda.current_stream(ctx.index)
     aux = ctx.internal_streams()[2] if _SWEEP_LOOKAHEAD else main

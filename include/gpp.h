@@ -179,6 +179,14 @@ int gpp_shard_list_gate(gpp_handle_t h, void* stream, int tail, int k);
 int gpp_shard_list_signal(gpp_handle_t h, void* stream, int tail, int k);
 int gpp_shard_list_end(gpp_handle_t h);
 
+/* The sharded evaluation's BACK-substitution of one rank as one ticket list on the handle's stream: the owned column blocks of L^-1 in
+ * Kc (compact; rows at and below each block's diagonal, destroyed) become the same column blocks of Ky^-1 = L^-T L^-1 in Lc, against
+ * the factor's mirror L in the strict lower triangle of A and the diagonal blocks' inverses D — gp-plus_amd/sharded.py::_backward's
+ * per-step launches (gpp_gemm_batched + gpp_gemm_lower_cols) as tile tasks in dependency order, far tiles taking several steps'
+ * updates at once.  No communication (bullet 4).  *used = 0: not applicable, nothing enqueued. */
+int gpp_shard_back_list(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nranks, const double* A, int64_t ld, double* Kc, double* Lc,
+                        int64_t ldc, const double* D, int32_t* info, int workers, int* used);
+
 /* Products with a lower-triangular T of which only the block-cyclically owned COLUMN blocks (width nb, a multiple of 64; block
  * b owned when b % nranks == rank) exist on this rank:  trans = 0: y_i = sum over owned columns k <= i of T[i][k] x_k (this
  * rank's part of z = L^-1 r);  trans = 1: y_k = sum_{i >= k} T[i][k] x_i for the owned columns k and 0 for the others (this

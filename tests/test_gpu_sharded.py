@@ -9,6 +9,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def _run(args, world=2, port=29531, **extra_env):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    if world > 1:  # the ranks share the one GPU: the ticket lists' persistent work-groups of all ranks must fit on it together
+        env.setdefault("GPP_SHARD_WORKERS", str(448 // world))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "workers", "sharded_worker.py")] + [str(a) for a in args]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
@@ -57,6 +59,26 @@ def test_sharded_more_ranks_and_block_counts(world, N, D, nb, kind, S, dU):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,N,D,nb,kind,S,dU,env", [
+    (1, 9000, 6, 1024, 0, 1, 0, {}),                       # one rank: panels, fillers, the chain's tiles from the scratch rows
+    (1, 9000, 6, 1024, 0, 3, 2, {"GPP_TEST_BACKEND": "nccl", "GPP_SHARDED_FORCE_COLLECTIVES": "1"}),  # + gates, packing, RCCL beside the executor
+    (2, 9000, 6, 1024, 0, 1, 0, {}),                       # two ranks: every block row arrives as a message on one of them
+    (3, 10000, 5, 1024, 2, 1, 0, {}),                      # 10 blocks on 3 ranks; Matern 5/2
+    (4, 13000, 6, 1024, 0, 2, 2, {}),                      # fused groups of 2 steps, 13 blocks on 4 ranks, per-group noise, manifold gradients
+    (2, 15000, 8, 1024, 0, 1, 0, {}),                      # fused groups of 4 steps
+    (1, 7000, 6, 512, 0, 1, 0, {"GPP_SHARD_LIST": "0"}),   # the switch: launches per product (rounds 2-4)
+])
+def test_sharded_ticket_lists_match_single_gpu(world, N, D, nb, kind, S, dU, env):
+    """Factorisation + forward sweep of every rank as ONE ticket list (gpp_shard_list_begin; gp-plus_amd/csrc/gpp_dag.hip DAG_SHARD),
+    messages gated / signalled on the communication stream: loss and gradients against the single-GPU path (1e-5 relative is
+    BASELINE's bar; observed 1e-13), identical on every rank, and the list really ran."""
+    out = _run([N, D, nb, kind, S, dU], world=world, port=30100 + (N * 3 + world * 17 + S) % 300, **env)
+    for name, e in out["err"].items():
+        assert e < 1e-9, (name, e, out)
+    assert out["list_evals"] == (0 if env.get("GPP_SHARD_LIST") == "0" else 1), out
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,D,nb,kind,S,dU", [
     (20000, 8, 1024, 0, 1, 0),   # the C2 size: 20 slab broadcasts of up to 164 MB, the split updates and the panel stream around them
     (3000, 6, 256, 0, 2, 2),     # ragged last block, per-group noise, manifold gradients (the all-reduce carries N dU doubles)
@@ -99,6 +121,8 @@ def _config_values(name, nb, world, n=None, nograd=False, port=29977, timeout=15
 
     worker = os.path.join(ROOT, "tests", "workers", "sharded_worker.py")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if world > 1:
+        env.setdefault("GPP_SHARD_WORKERS", str(448 // world))
     extra = ([str(n)] if n else []) + (["nograd"] if nograd else [])
     if nograd and not n:
         extra = ["0", "nograd"]
@@ -158,14 +182,15 @@ def test_sharded_c5_size_two_ranks():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("backend,force", [("gloo", "0"), ("nccl", "1")])
-def test_sharded_choreography_is_bitwise_repeatable(backend, force):
+@pytest.mark.parametrize("backend,force,N,nb", [("gloo", "0", 4300, 256), ("nccl", "1", 4300, 256), ("nccl", "1", 9000, 512), ("gloo", "0", 9000, 512)])
+def test_sharded_choreography_is_bitwise_repeatable(backend, force, N, nb):
     """The sharded evaluation enqueues on five streams (panel, throughput, bulk, collectives, the caller's) tied by events; every
     kernel is deterministic, so repeating one evaluation must reproduce loss and gradients BIT FOR BIT — any difference is a race
-    (tools/stress_sharded.py; 17 block rows, per-group noise, manifold gradients, 20 repetitions)."""
+    (tools/stress_sharded.py; 17 block rows, per-group noise, manifold gradients, 20 repetitions; N = 9000 with nb = 512 runs the
+    ticket lists, 4300 with 256 — a last block too short for the panel — the launches)."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPP_SHARDED_FORCE_COLLECTIVES=force,
-               MASTER_PORT=str(29720 + (backend == "nccl")))
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_sharded.py"), "4300", "256", "20", backend],
+               MASTER_PORT=str(29720 + (backend == "nccl") + 2 * (N == 9000)))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "stress_sharded.py"), str(N), str(nb), "20", backend],
                        capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     assert "20 repetitions, 0 differ" in p.stdout, p.stdout[-1000:]

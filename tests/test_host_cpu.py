@@ -400,3 +400,43 @@ def test_sharded_list_check_notices_a_missing_wait():
                 remote[1] += any(rcs)
         assert caught >= need * total, (P, W, caught, total)
         assert P == 1 or (remote[0] > 0 and remote[1] >= 0.7 * remote[0]), (P, remote)
+
+
+def _shard_back_check():
+    import ctypes
+
+    from gpplus_amd import _lib
+
+    lib = _lib.load()
+    f = lib.gpp_debug_shard_back_check
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint,
+                  ctypes.POINTER(ctypes.c_int64), ctypes.c_int]
+    return f, (ctypes.c_int64 * 4)()
+
+
+@pytest.mark.parametrize("N,nb,P,fuse,W", [(3400, 512, 1, 1, 7), (9000, 512, 3, 4, 448), (6100, 384, 4, 2, 3), (4200, 384, 3, 1, 1),
+                                           (20000, 1024, 1, 4, 512), (20000, 1024, 8, 4, 512), (30000, 1024, 5, 4, 512)])
+def test_sharded_back_substitution_list_is_a_valid_schedule(N, nb, P, fuse, W):
+    """The back-substitution's ticket list of every rank (gpp_dag.hip, DAG_BACK), executed on the host by W workers in random and
+    adversarial interleavings: a row of Z is built from rows of Y that have taken every update, an update reads complete rows of Z
+    and is applied in order and exactly once (fused: f steps at once, only on tiles no step of the group reads), only at and below
+    the diagonal of column blocks the rank owns; nothing deadlocks; every owned tile of Ky^-1 is complete at the end."""
+    f, st = _shard_back_check()
+    for rank in range(P):
+        for seed in range(4):
+            rc = f(N, nb, P, rank, fuse, W, seed, st, 0)
+            assert rc == 0, (rank, seed, rc)
+        assert st[0] > 0 and st[1] > 0 and st[2] > 0
+
+
+def test_sharded_back_list_check_notices_a_missing_wait():
+    f, st = _shard_back_check()
+    for P, rank, fuse in ((1, 0, 4), (3, 1, 2)):
+        f(9000, 512, P, rank, fuse, 448, 0, st, 0)
+        nwaits = int(st[1])
+        caught = total = 0
+        for mut in range(1, nwaits, 211 if P == 1 else 67):
+            total += 1
+            caught += any(f(9000, 512, P, rank, fuse, 448, seed, st, mut) for seed in range(4))
+        assert total > 20 and caught >= 0.9 * total, (P, caught, total)

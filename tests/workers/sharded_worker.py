@@ -180,7 +180,7 @@ def main():
         wsx = next(iter(_sh._workspaces.values()))
         emit("RESULT " + json.dumps({"err": err, "mll": float(res["single"][0]), "backend": dist.get_backend(), "collectives": calls,
                                      "matrix_bytes": wsx.nbytes(), "full_matrix_bytes": 8 * N * wsx.A.stride(0),
-                                     "owned_cols": wsx.Lc.shape[1], "nb": nb, "world": world, "list_evals": _sh.LIST_EVALS}))
+                                     "owned_cols": wsx.Lc.shape[1], "nb": nb, "world": world, "list_evals": _sh.LIST_EVALS, "back_list_evals": _sh.BACK_LIST_EVALS}))
     emit(f"RANK{rank} same_as_rank0={same}")
     dist.barrier()
     dist.destroy_process_group()

@@ -37,6 +37,8 @@ for rep in range(reps):
     elif not torch.equal(flat, first):
         bad += 1
         print(f"rep {rep}: differs from rep 0, max |d| = {(flat - first).abs().max().item():.3e}", flush=True)
+from gpplus_amd import sharded as _sh
+print(f"ticket lists ran in {_sh.LIST_EVALS} of {reps} evaluations")
 print(f"N={N} nb={nb} backend={backend} force={os.environ.get('GPP_SHARDED_FORCE_COLLECTIVES', '0')}: {reps} repetitions, "
       f"{bad} differ from the first (mll = {first[0].item():.9f})")
 dist.destroy_process_group()
