@@ -849,6 +849,26 @@ int gpp_debug_dag_info(gpp_handle_t h, int64_t* info8) {
   info8[4] = P->ncounters; info8[5] = (int64_t)(P->sim_ms * 1000.0); info8[6] = (int64_t)(P->sim_busy * 1000.0); info8[7] = P->flags;
   return 0;
 }
+// (dev) progress of the most recent plan's list after a device synchronisation: out[0] = abort flag, out[1] = tickets taken, out[2] = B,
+// then B values each of PD, G1D and — sharded lists — CPH, CPT, ART
+int gpp_debug_dag_counters(gpp_handle_t h, int* out, int nmax) {
+  DagPlan* P = dag_mru(h);
+  if (!P || !P->d_counters) return -1;
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  std::vector<int> c(P->ncounters);
+  if (hipMemcpy(c.data(), P->d_counters, c.size() * sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return 2;
+  int n = 0;
+  auto put = [&](int v) { if (n < nmax) out[n++] = v; };
+  put(c[0]); put(c[1]); put(P->B);
+  for (int b = 0; b < P->B; ++b) put(c[P->c_pd + b]);
+  for (int b = 0; b < P->B; ++b) put(c[P->c_g1d + b]);
+  if (P->flags & DAG_SHARD) {
+    for (int b = 0; b < P->B; ++b) put(c[P->c_cph + b]);
+    for (int b = 0; b < P->B; ++b) put(c[P->c_cpt + b]);
+    for (int b = 0; b < P->B; ++b) put(c[P->c_art + b]);
+  }
+  return n;
+}
 int gpp_debug_dag_trace(gpp_handle_t h, int on) {
   DagPlan* P = dag_mru(h);
   if (!P) return -1;
@@ -906,6 +926,7 @@ int gpp_create(gpp_handle_t* out, int device) {
   for (int i = 0; i < 4; ++i) h->dag_plans[i] = nullptr;
   h->shard_cur = nullptr;
   h->shard_info = nullptr;
+  h->shard_ready = nullptr;
   h->dag_clock = 0;
   h->dag_sched = 1;
   h->ncu = 0;
@@ -921,6 +942,7 @@ int gpp_create(gpp_handle_t* out, int device) {
     (void)hipGetLastError();
     if (h->panel_flags) (void)hipFree(h->panel_flags);
   if (h->handoff) (void)hipEventDestroy(h->handoff);
+  if (h->shard_ready) (void)hipEventDestroy(h->shard_ready);
     h->panel_flags = nullptr;  // the leaf-step chain is used instead
   }
   *out = h;
@@ -1059,7 +1081,10 @@ int gpp_shard_list_begin(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nr
   DagBases bases{{reinterpret_cast<char*>(A), reinterpret_cast<char*>(Kc), reinterpret_cast<char*>(Lc), reinterpret_cast<char*>(D),
                   reinterpret_cast<char*>(W0), reinterpret_cast<char*>(W1), reinterpret_cast<char*>(W2), nullptr}};
   GPP_TRY(gpp_launch_dag_bind(sm, P->d_groups, P->d_groups_abs, (int)P->groups.size(), bases));
-  hipEvent_t ev = next_event(h);
+  // (recorded BEFORE the executor is launched: the caller's stream may be the legacy default stream, whose markers wait for every
+  //  blocking stream's earlier work — an event recorded on it behind the executor's launch would complete with the list)
+  if (!h->shard_ready) GPP_TRY(hipEventCreateWithFlags(&h->shard_ready, hipEventDisableTiming));
+  hipEvent_t ev = h->shard_ready;
   GPP_TRY(hipEventRecord(ev, sm));
   GPP_TRY(hipStreamWaitEvent(sp, ev, 0));
   GPP_TRY(hipStreamWaitEvent(su, ev, 0));
@@ -1108,6 +1133,7 @@ int gpp_shard_list_gate(gpp_handle_t h, void* stream, int tail, int k) {
   if (k < 0 || k >= P->B || k % P->nranks != P->rank) return -4;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const long long budget = shard_budget(h);
+  GPP_TRY(hipStreamWaitEvent(s, h->shard_ready, 0));  // the counters are cleared
   GPP_TRY(gpp_launch_exec_gate(s, P->d_counters, P->c_pd + k, 1, h->shard_info, budget));
   const int target = tail ? P->cpt_target[k] : P->cph_target[k];
   if (target > 0) GPP_TRY(gpp_launch_exec_gate(s, P->d_counters, (tail ? P->c_cpt : P->c_cph) + k, target, h->shard_info, budget));
@@ -1119,6 +1145,7 @@ int gpp_shard_list_signal(gpp_handle_t h, void* stream, int tail, int k) {
   if (!h || !h->shard_cur) return -1;
   const DagPlan* P = h->shard_cur;
   if (k < 0 || k >= P->B || k % P->nranks == P->rank) return -4;
+  GPP_TRY(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), h->shard_ready, 0));
   return rc(gpp_launch_exec_signal(reinterpret_cast<hipStream_t>(stream), P->d_counters, (tail ? P->c_art : P->c_pd) + k));
 }
 

@@ -1206,6 +1206,31 @@ DagPlan* gpp_dag_plan(int64_t N, int64_t nb, int64_t ld, int64_t ldi, int64_t ld
     fprintf(stderr, "libgpp_hip: dag plan N=%lld nb=%lld flags=%d: %d blocks, %zu tasks, %zu groups, %d counters; simulated %.2f ms, "
                     "%.0f %% busy on %d workers\n", (long long)N, (long long)nb, flags, P->B, P->tasks.size(), P->groups.size(), P->ncounters,
             P->sim_ms, 100.0 * P->sim_busy, tune.workers);
+  if (getenv("GPP_DAG_DUMP")) {
+    auto fam = [&](int c) {
+      static char buf[64];
+      if (c < 0) return (const char*)"-";
+      const char* nm = "?";
+      int base = 0;
+      struct { const char* n; int b; } fs[] = {{"PD", pl.c_pd}, {"G1D", pl.c_g1d}, {"UR", pl.c_ur}, {"SS", pl.c_ss}, {"XR", pl.c_xr}, {"XS", pl.c_xs},
+                                               {"VA", pl.c_va}, {"VT", pl.c_vt}, {"CPD", pl.c_cpd}, {"CPH", pl.c_cph}, {"CPT", pl.c_cpt}, {"ART", pl.c_art}};
+      for (auto& f : fs)
+        if (f.b > 0 && c >= f.b && f.b >= base) { nm = f.n; base = f.b; }
+      snprintf(buf, sizeof buf, "%s+%d", nm, c - base);
+      return (const char*)buf;
+    };
+    const int nd = atoi(getenv("GPP_DAG_DUMP"));
+    for (int t = 0; t < nd && t < (int)P->tasks.size(); ++t) {
+      const DagTask& d = P->tasks[t];
+      fprintf(stderr, "  r%d ticket %d kind %d blk %d tile (%d,%d) waits", rank, t, d.kind, pl.gmeta[d.group].second, d.tm, d.tn);
+      for (int q = 0; q < 3; ++q)
+        if (d.wait_id[q] >= 0) fprintf(stderr, " %s>=%d", fam(d.wait_id[q]), d.wait_val[q]);
+      fprintf(stderr, " incs");
+      for (int q = 0; q < 2; ++q)
+        if (d.inc_id[q] >= 0) fprintf(stderr, " %s", fam(d.inc_id[q]));
+      fprintf(stderr, "\n");
+    }
+  }
   if (getenv("GPP_EXEC_VERBOSE") && !pl.fill_m.empty()) {
     fprintf(stderr, "libgpp_hip: dag plan filler tasks per work-group and block:");
     for (int m : pl.fill_m) fprintf(stderr, " %d", m);

@@ -44,6 +44,7 @@ struct gpp_handle_s {
   uint64_t dag_clock;
   struct DagPlan* shard_cur;  // the sharded list between gpp_shard_list_begin and _end
   int32_t* shard_info;
+  hipEvent_t shard_ready;     // counters cleared + groups bound: what the caller's communication stream waits for before a gate / signal
   int dag_sched;             // GPP_OPT_DAG_SCHED
 };
 constexpr int GPP_PANEL_RING = 8;

@@ -440,11 +440,13 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
     for k in range(me, nblk, P):
         ctx.kernel_build(U, w, sf2, tau, grp, A, jitter=jitter, kind=kind, d_split=d_split, uplo=UPLO_FULL, row0=offs[k],
                          nrows=offs[k + 1] - offs[k])
+    # (ordered against the caller's stream BEFORE the list starts: with the legacy default stream as the caller's, an event recorded on
+    #  it behind the executor's launch completes only with the list — every blocking stream's earlier work precedes such a marker)
+    cs.wait_stream(main)
     if not ctx.shard_list_begin(N, nb, me, P, A, ws.Kc, ws.Lc, ws.D, ws.W2, ws.info[0:1], _LIST_WORKERS):
         return None
     try:
         if comm.travel:
-            cs.wait_stream(main)
             with torch.cuda.stream(cs):
                 for k in range(nblk):
                     o, o1 = offs[k], offs[k + 1]
@@ -475,8 +477,6 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
     finally:
         ctx.shard_list_end()
     main.wait_stream(cs)
-    global LIST_EVALS
-    LIST_EVALS += 1
     # what the list leaves to the launches behind it: the owned diagonal blocks of L^-1 (lower triangles of D) into Kc, and the
     # factor's mirror L = U^T into A's strict lower triangle, which the back-substitution reads row-contiguously
     for c in range(me, nblk, P):
@@ -488,7 +488,20 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
         ctx.transpose(A[o:o1, o1:N], A[o1:N, o:o1])
     info = ws.info.max().to(torch.int32).reshape(1)
     comm.allreduce(info, dist.ReduceOp.MAX)
-    return int(info.item())
+    st = int(info.item())
+    if st == 0:
+        global LIST_EVALS
+        LIST_EVALS += 1
+    elif st >= INFO_PANEL_TIMEOUT and os.environ.get("GPP_SHARD_DEBUG"):
+        import ctypes
+        buf = (ctypes.c_int * 1024)()
+        n = ctx.lib.gpp_debug_dag_counters(ctx.h, buf, 1024)
+        v = list(buf[:max(n, 0)])
+        Bk = v[2] if n > 3 else 0
+        names = ["PD", "G1D", "CPH", "CPT", "ART"]
+        rows = {names[q]: v[3 + q * Bk:3 + (q + 1) * Bk] for q in range(5)} if Bk else {}
+        print(f"[sharded rank {me}] ticket list: status {st:#x} (mine {int(ws.info[0].item()):#x}) abort {v[:1]} tickets {v[1:2]} {rows}", flush=True)
+    return st
 
 
 def _first_owned(ws: ShardedWorkspace, comm: _Comm) -> Optional[int]:

@@ -75,7 +75,9 @@ def test_sharded_ticket_lists_match_single_gpu(world, N, D, nb, kind, S, dU, env
     out = _run([N, D, nb, kind, S, dU], world=world, port=30100 + (N * 3 + world * 17 + S) % 300, **env)
     for name, e in out["err"].items():
         assert e < 1e-9, (name, e, out)
-    assert out["list_evals"] == (0 if env.get("GPP_SHARD_LIST") == "0" else 1), out
+    # (counted only when the list ran to completion with status 0: a time-out falls back to the launches and would pass unnoticed)
+    want = 0 if env.get("GPP_SHARD_LIST") == "0" else 1
+    assert out["list_evals"] == want and out["back_list_evals"] == want, out
 
 
 @pytest.mark.gpu
