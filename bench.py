@@ -441,7 +441,10 @@ def run_sharded(args, dist, dev, rank, world, n, steps, warmup):
 
     cfg_name = "C5" if n > 30000 else "C2"
     if not args.nb:
-        args.nb = 2048 if n >= 40000 else 1024
+        # (the ticket lists of round 5 need the cooperative panel: blocks of 1024 rows; the launch-per-product path of rounds 2-4 was
+        #  faster with 2048 from N = 40 000)
+        lists = os.environ.get("GPP_SHARD_LIST", "1") not in ("", "0")
+        args.nb = 1024 if (lists or n < 40000) else 2048
     X, y, kw, theta = make_config(cfg_name, n)
     model = GP_Plus(X, y, dtype=torch.float64, device=dev, **kw)
     apply_theta(model, theta)
@@ -467,6 +470,7 @@ def run_sharded(args, dist, dev, rank, world, n, steps, warmup):
     from gpplus_amd import sharded as _sh0
 
     run_steps(warmup)
+    lists0 = (_sh0.LIST_EVALS, _sh0.BACK_LIST_EVALS)
     linalg.STAGE_EVENTS = []
     _sh0.COMM_LOG = []  # every collective of the timed evaluations is bracketed by events on its stream
     elapsed, loss = _bracket(dist, dev, lambda: run_steps(steps))
@@ -506,6 +510,8 @@ def run_sharded(args, dist, dev, rank, world, n, steps, warmup):
                             "achieved": per_gpu_tf, "peak": PEAK_FP64_MFMA_TFLOPS, "unit": "TFLOP/s per GPU",
                             "frac": per_gpu_tf / PEAK_FP64_MFMA_TFLOPS, "traffic": None},
                "stages": {"ms": stage_ms, "tflops_per_gpu": stage_rate},
+               # timed evaluations whose factorisation + forward sweep / back-substitution ran as ticket lists to completion
+               "ticket_lists": {"factor_forward": _sh0.LIST_EVALS - lists0[0], "back": _sh0.BACK_LIST_EVALS - lists0[1], "of": steps},
                # per evaluation, rank 0's view: collectives issued, bytes they carried and the time they occupied their stream (the
                # factor's broadcasts run on the communication stream beside the updates: comm_ms is NOT all exposed time)
                "comm": comm}
@@ -582,8 +588,9 @@ def main():
                     help="auto (default): the replica leg, plus the sharded C5 leg when N > 1.  replicas / sharded: that "
                          "leg only (sharded with one rank measures the algorithm without communication)")
     ap.add_argument("--nb", type=int, default=0,
-                    help="block height of the sharded evaluation (0 = by size: 2048 from N = 40000 — one rank at C5: 3450 ms "
-                         "against 3554 with 1024 on the round-4 build —, 1024 below: 156.6 ms at N = 20000 against 164 with 2048)")
+                    help="block height of the sharded evaluation (0 = 1024, what the ticket lists of round 5 need — one rank at C5: "
+                         "3404 ms, at C2: 137 ms; with GPP_SHARD_LIST=0, the launches of rounds 2-4: 2048 from N = 40000 — 3450 ms "
+                         "against 3554 with 1024 —, 1024 below)")
     ap.add_argument("--sharded-n", type=int, default=60000, help="size of the sharded leg (C5)")
     ap.add_argument("--sharded-steps", type=int, default=2)
     ap.add_argument("--sharded-warmup", type=int, default=1)

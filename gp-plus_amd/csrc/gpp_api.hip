@@ -1221,7 +1221,7 @@ int gpp_shard_back_list(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nra
   DagLaunch dl{};
   dl.groups = P->d_groups_abs; dl.tasks = P->d_tasks; dl.ntasks = (int)P->tasks.size();
   dl.counters = P->d_counters; dl.info = info;
-  dl.budget = (long long)(h->panel_timeout_ms > 0 ? h->panel_timeout_ms : 500) * 100000 * 4;  // (every wait is for this rank's own tasks)
+  dl.budget = shard_budget(h);  // (every wait is for this rank's own tasks; generous all the same: ranks that share a GPU in tests)
   dl.max_tasks = 0; dl.quit_id = -1; dl.quit_val = 0; dl.ticket_limit = 0;
   dl.trace = P->d_trace; dl.tag = 0;
   GPP_TRY(gpp_launch_dag(sm, nworkers, dl));

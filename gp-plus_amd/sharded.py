@@ -592,10 +592,15 @@ def _backward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
         # triangles: clear what the forward sweep's sums left above them first
         for c in range(me, nblk, P):
             Lc[offs[c]:offs[c + 1], ws.col(c)].zero_()
-        if ctx.shard_back_list(ws.N, nb, me, P, A, Kc, Lc, ws.D, ws.info[0:1], _LIST_WORKERS and 2 * _LIST_WORKERS):
+        used = ctx.shard_back_list(ws.N, nb, me, P, A, Kc, Lc, ws.D, ws.info[0:1], _LIST_WORKERS and 2 * _LIST_WORKERS)
+        if not used and os.environ.get("GPP_SHARD_DEBUG"):
+            print(f"[sharded rank {me}] back-substitution list: not used", flush=True)
+        if used:
             global BACK_LIST_EVALS
             BACK_LIST_EVALS += 1
             st = int(ws.info[0].item())  # (a wait inside the list that ran out of its budget must not pass as a result)
+            if st and os.environ.get("GPP_SHARD_DEBUG"):
+                print(f"[sharded rank {me}] back-substitution list: status {st:#x}", flush=True)
             if st:
                 from .backend import check_status
                 check_status(st)

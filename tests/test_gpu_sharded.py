@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _run(args, world=2, port=29531, **extra_env):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPP_SHARD_DEBUG="1", **extra_env)  # (debug: a list's time-out status is printed)
     if world > 1:  # the ranks share the one GPU: the ticket lists' persistent work-groups of all ranks must fit on it together
         env.setdefault("GPP_SHARD_WORKERS", str(448 // world))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
@@ -21,6 +21,7 @@ def _run(args, world=2, port=29531, **extra_env):
     same = re.findall(r"same_as_rank0=(True|False)", p.stdout)
     assert len(res) == 1 and len(same) == world, p.stdout[-3000:]
     assert all(v == "True" for v in same), same
+    res[0]["status_lines"] = [l[:300] for l in p.stdout.splitlines() if l.startswith("[sharded rank")]
     return res[0]
 
 
@@ -77,7 +78,7 @@ def test_sharded_ticket_lists_match_single_gpu(world, N, D, nb, kind, S, dU, env
         assert e < 1e-9, (name, e, out)
     # (counted only when the list ran to completion with status 0: a time-out falls back to the launches and would pass unnoticed)
     want = 0 if env.get("GPP_SHARD_LIST") == "0" else 1
-    assert out["list_evals"] == want and out["back_list_evals"] == want, out
+    assert (out["list_evals"], out["back_list_evals"]) == (want, want), (out["list_evals"], out["back_list_evals"], out["status_lines"])
 
 
 @pytest.mark.gpu
