@@ -7,22 +7,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(args, world=2, port=29531, **extra_env):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPP_SHARD_DEBUG="1", **extra_env)  # (debug: a list's time-out status is printed)
-    if world > 1:  # the ranks share the one GPU: the ticket lists' persistent work-groups of all ranks must fit on it together
-        env.setdefault("GPP_SHARD_WORKERS", str(448 // world))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "workers", "sharded_worker.py")] + [str(a) for a in args]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
-    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    import re
-    # (robust against ranks sharing a line of the launcher's pipe: parse from the marker, not by lines)
-    res = [json.JSONDecoder().raw_decode(p.stdout, m.end())[0] for m in re.finditer(r"RESULT (?=\{)", p.stdout)]
-    same = re.findall(r"same_as_rank0=(True|False)", p.stdout)
-    assert len(res) == 1 and len(same) == world, p.stdout[-3000:]
-    assert all(v == "True" for v in same), same
-    res[0]["status_lines"] = [l[:300] for l in p.stdout.splitlines() if l.startswith("[sharded rank")]
-    return res[0]
+from sharded_launch import assert_close_values as _assert_close_values, config_values as _config_values, run_ranks as _run  # noqa: E402
 
 
 @pytest.mark.gpu
@@ -47,7 +32,8 @@ def test_sharded_matches_single_gpu(N, D, nb, kind, S, dU):
     (2, 20000, 8, 1024, 0, 1, 0),  # the C2 size on two ranks: 20 block rows of 1024, the grouped LAUUM pipeline with real groups
 ])
 def test_sharded_more_ranks_and_block_counts(world, N, D, nb, kind, S, dU):
-    out = _run([N, D, nb, kind, S, dU], world=world, port=29560 + (N * 7 + world * 13 + nb) % 400)  # distinct rendezvous ports
+    # (the launch-per-product choreography of rounds 2-4; the ticket lists have tests of their own in test_gpu_00_sharded_lists.py)
+    out = _run([N, D, nb, kind, S, dU], world=world, port=29560 + (N * 7 + world * 13 + nb) % 400, GPP_SHARD_LIST="0")
     for name, e in out["err"].items():
         assert e < 1e-9, (name, e, out)
     # storage per rank ("28.8 GB (3.6 GB/GPU sharded)"): only the factor is N x N; L^-1 and Ky^-1 exist as the owned
@@ -57,28 +43,6 @@ def test_sharded_more_ranks_and_block_counts(world, N, D, nb, kind, S, dU):
     if nblk >= 2 * world:
         # (factor + two compact matrices + five nb-row strips: diagonal inverses, three row-solve scratches, packing buffer)
         assert out["matrix_bytes"] < (1.0 + 2.0 * (-(-nblk // world)) / nblk + 5.0 * nb / N + 0.1) * out["full_matrix_bytes"], out
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("world,N,D,nb,kind,S,dU,env", [
-    (1, 9000, 6, 1024, 0, 1, 0, {}),                       # one rank: panels, fillers, the chain's tiles from the scratch rows
-    (1, 9000, 6, 1024, 0, 3, 2, {"GPP_TEST_BACKEND": "nccl", "GPP_SHARDED_FORCE_COLLECTIVES": "1"}),  # + gates, packing, RCCL beside the executor
-    (2, 9000, 6, 1024, 0, 1, 0, {}),                       # two ranks: every block row arrives as a message on one of them
-    (3, 10000, 5, 1024, 2, 1, 0, {}),                      # 10 blocks on 3 ranks; Matern 5/2
-    (4, 13000, 6, 1024, 0, 2, 2, {}),                      # fused groups of 2 steps, 13 blocks on 4 ranks, per-group noise, manifold gradients
-    (2, 15000, 8, 1024, 0, 1, 0, {}),                      # fused groups of 4 steps
-    (1, 7000, 6, 512, 0, 1, 0, {"GPP_SHARD_LIST": "0"}),   # the switch: launches per product (rounds 2-4)
-])
-def test_sharded_ticket_lists_match_single_gpu(world, N, D, nb, kind, S, dU, env):
-    """Factorisation + forward sweep of every rank as ONE ticket list (gpp_shard_list_begin; gp-plus_amd/csrc/gpp_dag.hip DAG_SHARD),
-    messages gated / signalled on the communication stream: loss and gradients against the single-GPU path (1e-5 relative is
-    BASELINE's bar; observed 1e-13), identical on every rank, and the list really ran."""
-    out = _run([N, D, nb, kind, S, dU], world=world, port=30100 + (N * 3 + world * 17 + S) % 300, **env)
-    for name, e in out["err"].items():
-        assert e < 1e-9, (name, e, out)
-    # (counted only when the list ran to completion with status 0: a time-out falls back to the launches and would pass unnoticed)
-    want = 0 if env.get("GPP_SHARD_LIST") == "0" else 1
-    assert (out["list_evals"], out["back_list_evals"]) == (want, want), (out["list_evals"], out["back_list_evals"], out["status_lines"])
 
 
 @pytest.mark.gpu
@@ -93,6 +57,8 @@ def test_sharded_rccl_branch_with_one_rank(N, D, nb, kind, S, dU):
     out = _run([N, D, nb, kind, S, dU], world=1, port=29900 + N % 50, GPP_TEST_BACKEND="nccl",
                GPP_SHARDED_FORCE_COLLECTIVES="1")
     assert out["backend"] == "nccl"
+    if N == 20000:  # the ticket lists at the C2 size, RCCL's kernels beside the executor's
+        assert (out["list_evals"], out["back_list_evals"]) == (1, 1), (out["list_evals"], out["back_list_evals"], out["status_lines"])
     nblk = -(-N // nb)
     assert out["collectives"] >= 2 * nblk + 2, out  # head + tail per block row (the last has no tail), info, z, alpha, gradient
     for name, e in out["err"].items():
@@ -116,41 +82,6 @@ def test_sharded_through_gp_plus_api():
     """settings.sharded_evaluation routes GP_Plus's own loss through the cooperative evaluation (mixed-input model)."""
     out = _run([700, 8, 256, 0, 1, 2, "model"], port=29547)
     assert out["err"]["loss_and_grads"] < 1e-8, out
-
-
-def _config_values(name, nb, world, n=None, nograd=False, port=29977, timeout=1500):
-    """Loss and gradients of a BASELINE config through GP_Plus: (single-GPU path, sharded over ``world`` ranks)."""
-    import re
-
-    worker = os.path.join(ROOT, "tests", "workers", "sharded_worker.py")
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    if world > 1:
-        env.setdefault("GPP_SHARD_WORKERS", str(448 // world))
-    extra = ([str(n)] if n else []) + (["nograd"] if nograd else [])
-    if nograd and not n:
-        extra = ["0", "nograd"]
-
-    def values(cmd):
-        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
-        assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-        res = [json.JSONDecoder().raw_decode(p.stdout, m.end())[0] for m in re.finditer(r"RESULT (?=\{)", p.stdout)]
-        assert len(res) == 1, p.stdout[-3000:]
-        same = re.findall(r"same_as_rank0=(True|False)", p.stdout)
-        assert all(v == "True" for v in same), same
-        return res[0]["values"]
-
-    single = values([sys.executable, worker, "config", name, "single", str(nb)] + extra)
-    shard = values([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
-                    "127.0.0.1", "--master-port", str(port), worker, "config", name, "sharded", str(nb)] + extra)
-    return single, shard
-
-
-def _assert_close_values(single, shard, tol):
-    assert set(single) == set(shard)
-    for k, ref in single.items():
-        a, b = (shard[k], ref) if isinstance(ref, list) else ([shard[k]], [ref])
-        scale = max(max(abs(v) for v in b), 1e-300)
-        assert max(abs(x - y) for x, y in zip(a, b)) <= tol * scale, (k, a, b)
 
 
 @pytest.mark.gpu
@@ -180,7 +111,7 @@ def test_sharded_c5_size_two_ranks():
 
     if torch.cuda.get_device_properties(0).total_memory < 200 * 2 ** 30:
         pytest.skip("needs ~175 GiB of device memory")
-    single, shard = _config_values("C5", 1024, 2, port=29977)
+    single, shard = _config_values("C5", 1024, 2, port=29977, GPP_SHARD_LIST="0")  # (the launches; the lists: test_gpu_00_sharded_lists.py)
     _assert_close_values(single, shard, 1e-8)
 
 

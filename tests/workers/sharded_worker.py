@@ -108,7 +108,8 @@ def config_case(name, sharded, nb, n=None, nograd=False):
         for n, p in m.named_parameters():
             if p.grad is not None:
                 vals[n] = p.grad.detach().cpu().reshape(-1).tolist()
-        emit("RESULT " + json.dumps({"values": vals}))
+        from gpplus_amd import sharded as _sh
+        emit("RESULT " + json.dumps({"values": vals, "list_evals": _sh.LIST_EVALS, "back_list_evals": _sh.BACK_LIST_EVALS}))
     if sharded:
         mine = torch.cat([loss.detach().reshape(1)] + [p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])
         emit(f"RANK{rank} same_as_rank0={same_as_rank0(mine, dev)}")

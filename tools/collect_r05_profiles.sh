@@ -38,7 +38,9 @@ STAGES_ONLY=build,potrf timeout 600 rocprofv3 --kernel-trace --output-format csv
 timeout 900 python3 tools/trace_window.py $OUT/trace10k gpp_cov_tile - 30 100 > $OUT/timeline_n10000.txt 2>&1
 # 5) sharded evaluation with one rank (algorithm without communication): timing at C2 and C5 size
 timeout 900 python3 tools/run_sharded.py 20000 8 1024 2 > $OUT/sharded_1rank_20000.txt 2>&1
-timeout 900 python3 tools/run_sharded.py 60000 16 2048 1 > $OUT/sharded_1rank_60000.txt 2>&1
+timeout 900 python3 tools/run_sharded.py 60000 16 1024 1 > $OUT/sharded_1rank_60000.txt 2>&1
+# ticket lists (default) against the launch-per-product path of rounds 2-4 (GPP_SHARD_LIST=0), one rank, C2 and C5, same box
+timeout 1500 bash tools/shard_list_bench.sh 20000 60000 > $OUT/sharded_lists_1rank.txt 2>&1
 GPP_SHARDED_FORCE_COLLECTIVES=1 timeout 600 python3 bench.py --mode sharded --n 20000 --steps 3 --warmup 1 > $OUT/sharded_bench_line_20000.json 2> $OUT/sharded_bench_line_20000.err
 # 6) all BASELINE configs on one GPU, stage tables
 timeout 900 python3 tools/run_configs.py > $OUT/configs.txt 2>&1

@@ -20,10 +20,14 @@ cp $R/pmc_fetch_write.txt $P/r05_pmc_fetch_write.txt
 (echo "Factorisation + inverse at N=10000 (the C3 size; STAGES_ONLY=build,potrf tools/bench_stages.py 10000 8 2 under rocprofv3 --kernel-trace; tools/trace_window.py, dispatches >= 30 us)."
  echo "q2 = panel stream (32 CUs): gates, panels, signals, filler launches of gpp_dag_f64; q3 = throughput stream (224 CUs): ONE launch of gpp_dag_f64 per factorisation."
  cat $R/timeline_n10000.txt) > $P/r05_timeline_n10000.txt
-(echo "Sharded evaluation with ONE rank (the algorithm without communication), tools/run_sharded.py; round 5 (consumers read the solve's output; copies off the critical path)"
+(echo "Sharded evaluation with ONE rank (the algorithm without communication), tools/run_sharded.py; round 5 (ticket lists, nb = 1024)"
  grep "^N=" $R/sharded_1rank_20000.txt; grep "^N=" $R/sharded_1rank_60000.txt
  echo; echo "== bench.py --mode sharded --n 20000 with GPP_SHARDED_FORCE_COLLECTIVES=1 on ONE rank over gloo (host-staged: the 'comm' block times the calls themselves)"
  grep "^{" $R/sharded_bench_line_20000.json) > $P/r05_restarts_and_sharded_1rank.txt
+(echo "Sharded evaluation, ONE rank, bench.py --mode sharded --nb 1024 (tools/shard_list_bench.sh): the per-rank ticket lists of round 5 (GPP_SHARD_LIST=1,"
+ echo "default: factor + forward sweep as one list = stage shard_factor; back-substitution as one list) against the launch-per-product path"
+ echo "of rounds 2-4 (GPP_SHARD_LIST=0), same box, same build ($(cat $R/lib_version.txt))"
+ cat $R/sharded_lists_1rank.txt) > $P/r05_sharded_lists_1rank.txt
 grep -v "amdgpu\|Warning" $R/configs.txt > $P/r05_configs_C1_C5_single_gpu.txt
 (grep -v amdgpu $R/hbm_probe.txt; echo; echo "per-stage times at N=20000 (tools/bench_stages.py 20000 8 5):"; grep -v amdgpu $R/stages_20000.txt
  echo; echo "C3 through the API (tools/c3_stages.py):"; grep -v "amdgpu\|Warning" $R/stages_c3.txt) > $P/r05_hbm_probe.txt

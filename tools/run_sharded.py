@@ -29,8 +29,15 @@ def main():
         torch.cuda.synchronize(); dist.barrier()
     for rep in range(reps + 1):
         sync(); t0 = time.perf_counter()
-        info = sharded._factor(ctx, comm, ws, U, w, sf2, tau, None, 0, 0, 0.0); sync(); t1 = time.perf_counter()
-        sharded._forward(ctx, comm, ws); sync(); t2 = time.perf_counter()
+        # (round 5: factorisation + forward sweep as ONE ticket list per rank where it applies: "forward" is then 0)
+        info = sharded._factor_list(ctx, comm, ws, U, w, sf2, tau, None, 0, 0, 0.0) if sharded._USE_LIST else None
+        swept = info is not None
+        if info is None:
+            info = sharded._factor(ctx, comm, ws, U, w, sf2, tau, None, 0, 0, 0.0)
+        sync(); t1 = time.perf_counter()
+        if not swept:
+            sharded._forward(ctx, comm, ws)
+        sync(); t2 = time.perf_counter()
         torch.sub(y, mean, out=ws.r); sharded._vectors(ctx, comm, ws, True); sync(); t3 = time.perf_counter()
         sharded._backward(ctx, comm, ws)  # this rank's column blocks of Ky^-1 by back-substitution: nothing travels
         sync(); t4 = time.perf_counter()
