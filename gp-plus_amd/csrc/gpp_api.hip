@@ -165,7 +165,8 @@ inline bool panel_fits(const gpp_handle_s* h, int64_t n) {
   static const int64_t nmax = getenv("GPP_PANEL_MAX_N") ? atol(getenv("GPP_PANEL_MAX_N")) : PANEL_MAX_N;  // experiment knob
   return h->coop_panel && h->panel_flags && h->ncu >= 2 && n > 2 * NBLK && n <= nmax && (n + NBLK - 1) / NBLK <= gpp_panel_max_leaves();
 }
-hipError_t launch_panel(gpp_handle_s* h, const Ctx& c, int64_t o, int64_t n, int max_wgs) {
+// The cooperative panel of an n x n diagonal block whose own addresses are c.A / c.Li (o: its first row, for the status word).
+hipError_t launch_panel_at(gpp_handle_s* h, const Ctx& c, int64_t o, int64_t n, int max_wgs) {
   if (h->panel_fault) {  // test hook: behave like a launch whose wait timed out
     h->panel_fault = 0;
     return gpp_launch_fill_i32(c.s, c.info, 1, GPP_INFO_PANEL_TIMEOUT);
@@ -179,22 +180,15 @@ hipError_t launch_panel(gpp_handle_s* h, const Ctx& c, int64_t o, int64_t n, int
   if (cap == hipStreamCaptureStatusActive) slot = GPP_PANEL_RING + (h->cap_next++ % GPP_PANEL_CAP_RING);  // (see gpp_internal.h)
   else slot = h->panel_next++ % GPP_PANEL_RING;
   int* fl = reinterpret_cast<int*>(h->panel_flags + (size_t)slot * gpp_panel_flag_bytes());
-  return gpp_launch_panel(c.s, c.A + o * c.ld + o, c.ld, c.Li + o * c.ldi + o, c.ldi, (int)n, c.info, (int)o, fl, max_wgs,
-                          h->panel_timeout_ms);
+  return gpp_launch_panel(c.s, c.A, c.ld, c.Li, c.ldi, (int)n, c.info, (int)o, fl, max_wgs, h->panel_timeout_ms);
 }
 
-// the same with the block's own addresses in c.A / c.Li (the sharded list: the inverses live in a buffer of their own)
-hipError_t launch_panel_at(gpp_handle_s* h, const Ctx& c, int64_t o, int64_t n, int max_wgs) {
-  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(c.s, &cap) != hipSuccess) {
-    (void)hipGetLastError();
-    cap = hipStreamCaptureStatusNone;
-  }
-  int slot;
-  if (cap == hipStreamCaptureStatusActive) slot = GPP_PANEL_RING + (h->cap_next++ % GPP_PANEL_CAP_RING);
-  else slot = h->panel_next++ % GPP_PANEL_RING;
-  int* fl = reinterpret_cast<int*>(h->panel_flags + (size_t)slot * gpp_panel_flag_bytes());
-  return gpp_launch_panel(c.s, c.A, c.ld, c.Li, c.ldi, (int)n, c.info, (int)o, fl, max_wgs, h->panel_timeout_ms);
+// ... of the block at (o, o) of c.A, its inverse into the same place of c.Li
+hipError_t launch_panel(gpp_handle_s* h, const Ctx& c, int64_t o, int64_t n, int max_wgs) {
+  Ctx b = c;
+  b.A = c.A + o * c.ld + o;
+  b.Li = c.Li + o * c.ldi + o;
+  return launch_panel_at(h, b, o, n, max_wgs);
 }
 
 // ---- triangular inverse by pair merging -------------------------------------------------------------------------
@@ -1061,12 +1055,16 @@ int gpp_shard_list_begin(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nr
     // filler launches on the panel's CUs between this rank's panels (as in gpp_potrf_ws); not where ranks share one GPU (tests pass
     // `workers`): another rank's panel needs those CUs while a filler here may be waiting for that very rank's message
     static const int fill_env = getenv("GPP_SHARD_FILL") ? atoi(getenv("GPP_SHARD_FILL")) : -1;
-    tune.fill = fill_env >= 0 ? fill_env : (workers > 0 || tune.fill <= 0) ? 0 : 2 * h->panel_cus;
+    // With messages on the wire (nranks > 1) ONE filler work-group per panel CU: the executor's work-groups fill their CUs to the last
+    // register, so the collectives' kernels, the packing copies and the gate / signal kernels live on the panel CUs — and a filler
+    // that waits for a message must never be what keeps that message's kernel from being scheduled.
+    tune.fill = fill_env >= 0 ? fill_env : (workers > 0 || tune.fill <= 0) ? 0 : (nranks > 1 ? h->panel_cus : 2 * h->panel_cus);
     tune.inv_rows = 0;
     if (!getenv("GPP_DAG_FUSE")) tune.fuse = N >= 14336 ? 4 : N >= 11264 ? 2 : 1;
     P = gpp_dag_plan(N, nb, ld, ldc, ldw, 0, flags, tune, rank, nranks);
     if (!P) return 0;
     P->workers = workers;
+    P->fill = tune.fill;
     if (gpp_dag_upload(P) != hipSuccess) {
       (void)hipGetLastError();
       gpp_dag_free(P);
@@ -1116,7 +1114,7 @@ int gpp_shard_list_begin(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nr
       fl.quit_val = 1;
       fl.ticket_limit = op.lim;
       fl.tag = op.n >= 0 ? op.n : P->B;
-      GPP_TRY(gpp_launch_dag(sp, 2 * h->panel_cus, fl));
+      GPP_TRY(gpp_launch_dag(sp, std::max(P->fill, 1), fl));
     }
   }
   h->shard_cur = P;

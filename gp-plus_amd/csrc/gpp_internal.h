@@ -211,7 +211,7 @@ struct DagTuning {
 };
 struct DagPlan {
   int64_t N = 0, nb = 0, ld = 0, ldi = 0, ldt = 0, ldk = 0, inv_rows = 0;
-  int rank = 0, nranks = 1, workers = 0;            // DAG_SHARD: block-cyclic owner of block k is k % nranks; ldi = the compact buffers' leading
+  int rank = 0, nranks = 1, workers = 0, fill = 0;            // DAG_SHARD: block-cyclic owner of block k is k % nranks; ldi = the compact buffers' leading
                                        // dimension, ldt = the scratch rows'
   int c_cph = 0, c_cpt = 0, c_art = 0; // DAG_SHARD: first ids of "head copied" / "tail copied" (gates of the owner's broadcasts) and
                                        // "tail arrived" (signalled behind a received broadcast; the head's arrival raises c_pd + k)

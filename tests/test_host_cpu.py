@@ -358,7 +358,8 @@ def _shard_check():
     (6100, 384, 4, 2064, 3, 2),        # P does not divide the block count (16 blocks), three workers per rank
     (4200, 384, 3, 128, 1, 1),         # ONE worker per rank executes its list in order
     (5000, 512, 12, 64, 5, 1),         # more ranks than blocks: planned for the ranks that own one (the others run the launches)
-    (30000, 1024, 5, 4064, 448, 64)])
+    (30000, 1024, 5, 4064, 448, 64),
+    (60000, 1024, 8, 4064, 448, 64)])  # C5 on 8 GPUs: 59 blocks, 1.8 million tasks over the ranks
 def test_sharded_lists_are_valid_schedules_under_any_interleaving(N, nb, P, chain_tile, W, fill):
     """The per-rank ticket lists of the sharded evaluation (gpp_dag.hip, DAG_SHARD: each rank's panels, row solves, its share of the
     trailing updates and its column blocks of L^-1), ALL ranks executed together on the host — W workers + filler launches per rank,
@@ -373,7 +374,7 @@ def test_sharded_lists_are_valid_schedules_under_any_interleaving(N, nb, P, chai
         assert f(N, nb, P, chain_tile, W, fill, 0, st, 0) == 1  # (no plan for a rank without blocks: the caller's launch path)
         return
     by_fillers = 0
-    for seed in range(6):
+    for seed in range(6 if N <= 40000 else 2):
         rc = f(N, nb, P, chain_tile, W, fill, seed, st, 0)
         assert rc == 0, (seed, rc)
         by_fillers = max(by_fillers, int(st[3]))
