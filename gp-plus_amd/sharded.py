@@ -415,6 +415,8 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
 
 #: GPP_SHARD_LIST=0: the launch-per-product factorisation and forward sweep of rounds 2-4 (also the library's own knob)
 _USE_LIST = os.environ.get("GPP_SHARD_LIST", "1") not in ("", "0")
+#: the factor's mirror beside the list on the copy stream (default) or behind it (GPP_SHARD_MIRROR_BESIDE=0)
+_MIRROR_BESIDE = os.environ.get("GPP_SHARD_MIRROR_BESIDE", "1") not in ("", "0")
 #: evaluations whose factorisation + forward sweep ran as a ticket list (tests)
 LIST_EVALS = 0
 BACK_LIST_EVALS = 0
@@ -442,9 +444,12 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
                          nrows=offs[k + 1] - offs[k])
     # (ordered against the caller's stream BEFORE the list starts: with the legacy default stream as the caller's, an event recorded on
     #  it behind the executor's launch completes only with the list — every blocking stream's earlier work precedes such a marker)
+    cpy = ws.copy_stream
     cs.wait_stream(main)
+    cpy.wait_stream(main)
     if not ctx.shard_list_begin(N, nb, me, P, A, ws.Kc, ws.Lc, ws.D, ws.W2, ws.info[0:1], _LIST_WORKERS):
         return None
+    arrived = {}  # per block row of another rank: the event behind its unpacked tail
     try:
         if comm.travel:
             with torch.cuda.stream(cs):
@@ -474,18 +479,33 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
                         if not own:
                             A[o:o1, o2:N].copy_(tail)
                             ctx.shard_list_signal(cs, True, k)
+                    if not own:
+                        arrived[k] = torch.cuda.Event()
+                        arrived[k].record(cs)
+        # Beside the list, on a stream of its own: the factor's mirror L = U^T into A's strict lower triangle, which the
+        # back-substitution reads row-contiguously — block row k as soon as it is in place (an owned one: behind the gates the packing
+        # uses; another rank's: behind its unpacking).  Nothing in the list reads or writes the strict lower triangle.
+        with torch.cuda.stream(cpy):
+            for k in range(nblk - 1 if _MIRROR_BESIDE else 0):
+                o, o1 = offs[k], offs[k + 1]
+                if k % P == me:
+                    ctx.shard_list_gate(cpy, False, k)
+                    ctx.shard_list_gate(cpy, True, k)
+                else:
+                    cpy.wait_event(arrived[k])
+                A[o1:N, o:o1].copy_(A[o:o1, o1:N].t())
     finally:
         ctx.shard_list_end()
     main.wait_stream(cs)
-    # what the list leaves to the launches behind it: the owned diagonal blocks of L^-1 (lower triangles of D) into Kc, and the
-    # factor's mirror L = U^T into A's strict lower triangle, which the back-substitution reads row-contiguously
+    main.wait_stream(cpy)
+    if not _MIRROR_BESIDE:  # (experiment knob: the mirror behind the list, as the library's transposition launches)
+        for k in range(nblk - 1):
+            ctx.transpose(A[offs[k]:offs[k + 1], offs[k + 1]:N], A[offs[k + 1]:N, offs[k]:offs[k + 1]])
+    # what the list leaves to the launches behind it: the owned diagonal blocks of L^-1 (lower triangles of D) into Kc
     for c in range(me, nblk, P):
         blk = ws.Kc[offs[c]:offs[c + 1], ws.col(c)]
         blk.copy_(ws.dblk(c))
         blk.tril_()
-    for k in range(nblk - 1):
-        o, o1 = offs[k], offs[k + 1]
-        ctx.transpose(A[o:o1, o1:N], A[o1:N, o:o1])
     info = ws.info.max().to(torch.int32).reshape(1)
     comm.allreduce(info, dist.ReduceOp.MAX)
     st = int(info.item())
