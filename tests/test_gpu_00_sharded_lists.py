@@ -47,3 +47,17 @@ def test_sharded_lists_at_c5_size_two_ranks():
     single, shard = config_values("C5", 1024, 2, port=29978, meta=meta, GPP_SHARD_TIMEOUT_MS="60000")
     assert_close_values(single, shard, 1e-8)
     assert (meta["list_evals"], meta["back_list_evals"]) == (1, 1), meta
+
+
+@pytest.mark.gpu
+def test_sharded_lists_jitter_retries_and_failure_are_collective():
+    """An indefinite covariance THROUGH the lists (N = 5000 on two / three ranks, blocks of 512): a panel reports the failing minor,
+    the list runs to its end on whatever the factor then holds (counters do not depend on data), every rank learns the status from
+    the all-reduce and retries with the same jitter — ending on the single-GPU path's values with both lists of the successful
+    attempt counted — or, when no jitter suffices, EVERY rank raises NotPSDError."""
+    out = _run([5000, 5, 512, 0, 1, 0, "jitter"], world=2, port=30490, GPP_SHARD_TIMEOUT_MS="20000")
+    for name, e in out["err"].items():
+        assert e < 1e-4, (name, e, out)  # (a matrix lifted by 5e-8: condition ~1e7, both paths round differently)
+    assert (out["list_evals"], out["back_list_evals"]) == (1, 1), (out["list_evals"], out["back_list_evals"], out["status_lines"])
+    out = _run([5000, 5, 512, 0, 1, 0, "notpsd"], world=3, port=30491, GPP_SHARD_TIMEOUT_MS="20000")
+    assert out["raised"] == {"sharded": "NotPSDError", "single": "NotPSDError"}, out
