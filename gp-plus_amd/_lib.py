@@ -46,6 +46,12 @@ _SIGNATURES = {
     "gpp_shard_list_gate": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "gpp_shard_list_signal": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "gpp_shard_list_end": (c_int, [c_void_p]),
+    "gpp_set_comm": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    "gpp_comm_unique_id": (c_int, [c_void_p]),
+    "gpp_comm_init_rccl": (c_int, [c_void_p, c_void_p, c_int, c_int]),
+    "gpp_shard_buffer_doubles": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int]),
+    "gpp_shard_eval": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                               c_double, c_int, c_int, c_void_p, POINTER(c_int)]),
     "gpp_shard_back_list": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                     c_void_p, c_int, POINTER(c_int)]),
     "gpp_trmv_lower_cols": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int]),

@@ -953,6 +953,7 @@ int gpp_destroy(gpp_handle_t h) {
   if (h->panel_flags) (void)hipFree(h->panel_flags);
   for (int i = 0; i < 4; ++i)
     if (h->dag_plans[i]) gpp_dag_free(h->dag_plans[i]);
+  gpp_shard_release_comm(h);
   delete h;
   return 0;
 }
@@ -1030,6 +1031,7 @@ int gpp_shard_list_begin(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nr
   if ((ldw & 1) || ldw < N) return -15;
   if (!info) return -16;
   if (h->shard_cur) return -1;  // a list is open on this handle
+  if (workers <= 0 && getenv("GPP_SHARD_WORKERS")) workers = atoi(getenv("GPP_SHARD_WORKERS"));  // (tests: ranks sharing one GPU)
   static const bool list_env = !(getenv("GPP_SHARD_LIST") && atoi(getenv("GPP_SHARD_LIST")) == 0);
   static const int64_t list_min = getenv("GPP_SHARD_LIST_MIN_N") ? atol(getenv("GPP_SHARD_LIST_MIN_N")) : 4096;
   if (!list_env || !h->dag_sched || !h->coop_panel || N < list_min || N > 65536) return 0;
@@ -1179,6 +1181,7 @@ int gpp_shard_back_list(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nra
                                !(getenv("GPP_SHARD_BACK_LIST") && atoi(getenv("GPP_SHARD_BACK_LIST")) == 0);
   static const int64_t list_min = getenv("GPP_SHARD_LIST_MIN_N") ? atol(getenv("GPP_SHARD_LIST_MIN_N")) : 4096;
   if (!list_env || !h->dag_sched || N < list_min || N > 65536 || h->shard_cur) return 0;
+  if (workers <= 0 && getenv("GPP_SHARD_WORKERS")) workers = 2 * atoi(getenv("GPP_SHARD_WORKERS"));
   GPP_TRY(ensure_streams(h));
   const int flags = DAG_SHARD | DAG_BACK;
   DagPlan* P = nullptr;

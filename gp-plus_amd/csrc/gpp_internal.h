@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stddef.h>
 #include <vector>
+#include "../../include/gpp.h"
 
 #define GPP_TILE 128 /* GEMM work-group tile edge and Cholesky leaf size */
 
@@ -46,7 +47,14 @@ struct gpp_handle_s {
   int32_t* shard_info;
   hipEvent_t shard_ready;     // counters cleared + groups bound: what the caller's communication stream waits for before a gate / signal
   int dag_sched;             // GPP_OPT_DAG_SCHED
+  // gpp_shard.hip: the collectives of gpp_shard_eval (the caller's callbacks, or RCCL opened at run time) and its own stream
+  gpp_comm_t comm;
+  int comm_rank, comm_nranks;
+  void* rccl_comm;
+  hipStream_t comm_stream;
+  hipEvent_t comm_event;
 };
+extern "C" void gpp_shard_release_comm(gpp_handle_s* h);
 constexpr int GPP_PANEL_RING = 8;
 constexpr int GPP_PANEL_CAP_RING = 16;
 

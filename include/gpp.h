@@ -187,6 +187,47 @@ int gpp_shard_list_end(gpp_handle_t h);
 int gpp_shard_back_list(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nranks, const double* A, int64_t ld, double* Kc, double* Lc,
                         int64_t ldc, const double* D, int32_t* info, int workers, int* used);
 
+/*
+ * The WHOLE sharded evaluation behind the C ABI (SURVEY.md §8(b) sketched `gpp_set_comm(handle, ncclComm_t, rank, nranks)`): what
+ * gp-plus_amd/sharded.py drives from Python — build of the owned block rows, the rank's ticket list with the block rows' messages
+ * around it, z / alpha, the back-substitution's list, the gradient reduction — as ONE call per rank, for C / Fortran / MPI callers.
+ * The collectives are the caller's (gpp_set_comm: two callbacks, each enqueued on or ordered against the given stream; they may
+ * block the host) or RCCL's own (gpp_comm_init_rccl: librccl.so is opened at run time; rank 0 creates the 128-byte id with
+ * gpp_comm_unique_id and hands it to the other ranks by any means).  gpp_shard_eval (reference counterpart: `mll(output, y)` +
+ * `loss.backward()`, optim/mll_torch.py:114-117) returns 0 with *info_host = the status every rank agrees on: 0, LAPACK's "leading
+ * minor not positive definite" (the caller adds jitter and calls again — gpytorch's policy stays with the caller), or a time-out's
+ * bits; GPP_SHARD_UNSUPPORTED when the lists do not apply (N < 4096, a block height the panel does not take, a last block of <= 256
+ * rows): nothing useful was computed.  On success b->out3 = {quad, logdet, mll}, b->alpha = Ky^-1 r, and with need_grad b->flat =
+ * {g_w[D], g_sf2, g_tau[S], g_U[N x dU]} summed over the ranks (the layout of gpp_grad_reduce).  The buffers are the caller's
+ * (sizes: gpp_shard_buffer_doubles); b->r = y - mean on entry; the handle's scratch workspace (gpp_set_workspace,
+ * GPP_OP_MLL_EVAL) must be set.
+ */
+enum { GPP_COMM_SUM_F64 = 0, GPP_COMM_MAX_I32 = 1 };
+#define GPP_SHARD_UNSUPPORTED 2000
+typedef struct gpp_comm {
+  void* user;
+  int (*bcast)(void* user, void* dev_buf, size_t bytes, int root, void* stream);          /* in place, from rank `root` */
+  int (*allreduce)(void* user, void* dev_buf, size_t count, int kind, void* stream);      /* in place; kind: GPP_COMM_* */
+} gpp_comm_t;
+typedef struct gpp_shard_buffers {
+  double* A; int64_t ld;                    /* N x N: the factor (upper) and its mirror (strict lower) */
+  double* Kc; double* Lc; int64_t ldc;      /* N x (owned blocks x nb) each: column blocks of L^-1, then of Ky^-1 (in Lc) */
+  double* D;                                /* nblk x nb x nb: the diagonal blocks' inverses */
+  double* W0; double* W1; double* W2; int64_t ldw;  /* three nb x N scratch rows */
+  double* msg;                              /* nb x (N + 2 nb): a message being packed / unpacked */
+  double* z; double* alpha; double* r;      /* N each */
+  double* flat;                             /* D + 1 + S + N dU */
+  double* out3; int32_t* info;              /* 3 doubles; 2 ints */
+} gpp_shard_buffers_t;
+int gpp_set_comm(gpp_handle_t h, const gpp_comm_t* comm, int rank, int nranks);
+int gpp_comm_unique_id(void* out128);
+int gpp_comm_init_rccl(gpp_handle_t h, const void* unique_id128, int rank, int nranks);
+/* which: 0 A, 1 Kc / Lc (each), 2 D, 3 W0 / W1 / W2 (each), 4 msg — with ld = ldw = N rounded up to 16, ldc = owned blocks x nb */
+size_t gpp_shard_buffer_doubles(int64_t N, int64_t nb, int rank, int nranks, int which);
+int gpp_shard_eval(gpp_handle_t h, int64_t N, int64_t nb, const double* U, int D, const double* w, const double* sf2, const double* tau,
+                   const int32_t* grp, int S, int kind, int d_split, double jitter, int dU, int need_grad, const gpp_shard_buffers_t* b,
+                   int32_t* info_host);
+
 /* Products with a lower-triangular T of which only the block-cyclically owned COLUMN blocks (width nb, a multiple of 64; block
  * b owned when b % nranks == rank) exist on this rank:  trans = 0: y_i = sum over owned columns k <= i of T[i][k] x_k (this
  * rank's part of z = L^-1 r);  trans = 1: y_k = sum_{i >= k} T[i][k] x_i for the owned columns k and 0 for the others (this

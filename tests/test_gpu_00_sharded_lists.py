@@ -61,3 +61,20 @@ def test_sharded_lists_jitter_retries_and_failure_are_collective():
     assert (out["list_evals"], out["back_list_evals"]) == (1, 1), (out["list_evals"], out["back_list_evals"], out["status_lines"])
     out = _run([5000, 5, 512, 0, 1, 0, "notpsd"], world=3, port=30491, GPP_SHARD_TIMEOUT_MS="20000")
     assert out["raised"] == {"sharded": "NotPSDError", "single": "NotPSDError"}, out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,variant,env", [
+    (1, "cdriver_rccl", {"GPP_TEST_BACKEND": "nccl", "GPP_SHARDED_FORCE_COLLECTIVES": "1"}),  # RCCL opened by the library itself (dlopen), every collective issued
+    (2, "cdriver", {}),   # collectives as callbacks (here: into torch.distributed over gloo, host-staged)
+    (3, "cdriver", {}),
+])
+def test_sharded_evaluation_through_the_c_driver(world, variant, env):
+    """``gpp_shard_eval`` (include/gpp.h; SURVEY.md §8(b)'s ``gpp_set_comm``): the WHOLE sharded evaluation — build, the rank's ticket
+    lists with the block rows' messages, z / alpha, back-substitution, gradient reduction — as one C call per rank, the collectives
+    either the caller's callbacks or RCCL's own.  Loss, all gradients (per-group noise, manifold gradients) and alpha against the
+    single-GPU path; identical on every rank."""
+    out = _run([9000, 6, 1024, 0, 2, 2, variant], world=world, port=30530 + world, GPP_SHARD_TIMEOUT_MS="20000", **env)
+    for name, e in out["err"].items():
+        assert e < 1e-9, (name, e, out)
+    assert not out["status_lines"], out["status_lines"]

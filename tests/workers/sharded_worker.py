@@ -152,6 +152,15 @@ def main():
         mean = torch.full((N,), 0.1, dtype=torch.float64, device=dev).requires_grad_(True)
         spec = KernelSpec(w=w, sf2=sf2, kind=kind, d_split=2 if kind else 0)
         cfg = {"group": None, "nb": nb} if mode == "sharded" else None
+        if mode == "sharded" and variant.startswith("cdriver"):
+            # the whole evaluation through the C driver gpp_shard_eval (collectives: callbacks into torch.distributed, or RCCL itself)
+            from gpplus_amd.sharded_c import sharded_eval_c
+            with torch.no_grad():
+                out = sharded_eval_c(Ud, w, sf2, tau, mean, y.to(dev), grp=None if grp is None else grp.to(dev), kind=kind,
+                                     d_split=2 if kind else 0, n_grad_dims=dU, group=None, nb=nb, rccl=variant == "cdriver_rccl")
+            m_, a_, gw_, gs_, gt_, gU_ = out
+            res[mode] = [m_.cpu().reshape(1), gw_.cpu(), gs_.cpu().reshape(1), gt_.cpu(), a_.cpu()] + ([gU_.cpu().reshape(-1)] if dU > 0 else [])
+            continue
         try:
             with settings.sharded_evaluation(cfg):
                 mll = exact_mll(Ud, spec, tau, mean, y.to(dev), grp=None if grp is None else grp.to(dev), n_grad_dims=dU)
@@ -178,10 +187,10 @@ def main():
         from gpplus_amd import sharded as _sh
         calls = sum(getattr(w, "comm_calls", 0) for w in _sh._workspaces.values())
         # storage: ONE N x N matrix per rank (the replicated factor), the inverse and Ky^-1 only as owned column blocks
-        wsx = next(iter(_sh._workspaces.values()))
+        wsx = next(iter(_sh._workspaces.values()), None)  # (none when the C driver ran: it has buffers of its own)
         emit("RESULT " + json.dumps({"err": err, "mll": float(res["single"][0]), "backend": dist.get_backend(), "collectives": calls,
-                                     "matrix_bytes": wsx.nbytes(), "full_matrix_bytes": 8 * N * wsx.A.stride(0),
-                                     "owned_cols": wsx.Lc.shape[1], "nb": nb, "world": world, "list_evals": _sh.LIST_EVALS, "back_list_evals": _sh.BACK_LIST_EVALS}))
+                                     "matrix_bytes": wsx.nbytes() if wsx else 0, "full_matrix_bytes": 8 * N * (wsx.A.stride(0) if wsx else N),
+                                     "owned_cols": wsx.Lc.shape[1] if wsx else 0, "nb": nb, "world": world, "list_evals": _sh.LIST_EVALS, "back_list_evals": _sh.BACK_LIST_EVALS}))
     emit(f"RANK{rank} same_as_rank0={same}")
     dist.barrier()
     dist.destroy_process_group()
