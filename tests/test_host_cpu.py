@@ -441,3 +441,27 @@ def test_sharded_back_list_check_notices_a_missing_wait():
             total += 1
             caught += any(f(9000, 512, P, rank, fuse, 448, seed, st, mut) for seed in range(4))
         assert total > 20 and caught >= 0.9 * total, (P, caught, total)
+
+
+def test_shard_eval_buffer_sizes_and_argument_checks():
+    """Host-only parts of the C driver of the sharded evaluation (gpp_shard.hip): the buffer sizes a caller allocates, and that bad
+    arguments are refused before anything touches a device."""
+    import ctypes
+
+    from gpplus_amd import _lib
+
+    lib = _lib.load()
+    N, nb = 60000, 1024
+    nblk = -(-N // nb)
+    assert lib.gpp_shard_buffer_doubles(N, nb, 0, 8, 0) == N * N              # A: ld = N (a multiple of 16)
+    assert lib.gpp_shard_buffer_doubles(10001, nb, 0, 8, 0) == 10001 * 10016   # ld rounded up to 16
+    for rank in range(8):
+        owned = len(range(rank, nblk, 8))
+        assert lib.gpp_shard_buffer_doubles(N, nb, rank, 8, 1) == N * owned * nb   # Kc / Lc: the owned column blocks, whole
+    assert lib.gpp_shard_buffer_doubles(N, nb, 3, 8, 2) == nblk * nb * nb
+    assert lib.gpp_shard_buffer_doubles(N, nb, 3, 8, 3) == nb * N
+    assert lib.gpp_shard_buffer_doubles(N, nb, 3, 8, 4) == nb * (N + 2 * nb)
+    assert lib.gpp_shard_buffer_doubles(N, nb, 3, 8, 9) == 0
+    assert lib.gpp_set_comm(None, None, 0, 1) == -1 and lib.gpp_comm_init_rccl(None, None, 0, 1) == -1
+    info = ctypes.c_int(0)
+    assert lib.gpp_shard_eval(None, N, nb, None, 8, None, None, None, None, 1, 0, 0, 0.0, 0, 1, None, ctypes.byref(info)) == -1
