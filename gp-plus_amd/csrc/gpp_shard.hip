@@ -172,33 +172,43 @@ int gpp_shard_eval(gpp_handle_t h, int64_t N, int64_t nb, const double* U, int D
   int used = 0;
   SH_TRY(gpp_shard_list_begin(h, N, nb, me, P, b->A, b->ld, b->Kc, b->Lc, b->ldc, b->D, b->W0, b->W1, b->W2, b->ldw, b->info, 0, &used));
   if (!used) return GPP_SHARD_UNSUPPORTED;
-  int comm_rc = 0;
+  // (from here to gpp_shard_list_end no early return: an open list would leave the handle unusable)
+  int comm_rc = 0, err = 0;
+  auto hip_ok = [&](hipError_t e) {
+    if (e != hipSuccess && !err) err = rc(e);
+    return e == hipSuccess;
+  };
+  auto api_ok = [&](int r) {
+    if (r != 0 && !err) err = r;
+    return r == 0;
+  };
   if (travel) {
-    for (int64_t k = 0; k < nblk && !comm_rc; ++k) {
+    for (int64_t k = 0; k < nblk && !comm_rc && !err; ++k) {
       const int64_t o = off(k), o1 = off(k + 1), o2 = off(k + 2), nbk = o1 - o;
       const bool own = k % P == me;
       double* Dk = b->D + k * nb * nb;
-      for (int tail = 0; tail < 2 && !comm_rc; ++tail) {
+      for (int tail = 0; tail < 2 && !comm_rc && !err; ++tail) {
         // head: block row k's columns [o, o2) (diagonal block + the next block's columns), then D[k]; tail: columns [o2, N)
         const int64_t c0 = tail ? o2 : o, wcols = (tail ? N : o2) - c0;
         if (wcols <= 0) continue;
         const size_t count = (size_t)(nbk * wcols + (tail ? 0 : nbk * nbk));
         if (own) {
-          SH_TRY(gpp_shard_list_gate(h, cs, tail, (int)k));
-          SH_HIP(hipMemcpy2DAsync(b->msg, wcols * 8, b->A + o * b->ld + c0, b->ld * 8, wcols * 8, nbk, hipMemcpyDeviceToDevice, cs));
-          if (!tail) SH_HIP(hipMemcpy2DAsync(b->msg + nbk * wcols, nbk * 8, Dk, nb * 8, nbk * 8, nbk, hipMemcpyDeviceToDevice, cs));
+          if (!api_ok(gpp_shard_list_gate(h, cs, tail, (int)k))) break;
+          if (!hip_ok(hipMemcpy2DAsync(b->msg, wcols * 8, b->A + o * b->ld + c0, b->ld * 8, wcols * 8, nbk, hipMemcpyDeviceToDevice, cs))) break;
+          if (!tail && !hip_ok(hipMemcpy2DAsync(b->msg + nbk * wcols, nbk * 8, Dk, nb * 8, nbk * 8, nbk, hipMemcpyDeviceToDevice, cs))) break;
         }
         comm_rc = h->comm.bcast(h->comm.user, b->msg, count * sizeof(double), (int)(k % P), cs);
         if (comm_rc) break;
         if (!own) {
-          SH_HIP(hipMemcpy2DAsync(b->A + o * b->ld + c0, b->ld * 8, b->msg, wcols * 8, wcols * 8, nbk, hipMemcpyDeviceToDevice, cs));
-          if (!tail) SH_HIP(hipMemcpy2DAsync(Dk, nb * 8, b->msg + nbk * wcols, nbk * 8, nbk * 8, nbk, hipMemcpyDeviceToDevice, cs));
-          SH_TRY(gpp_shard_list_signal(h, cs, tail, (int)k));
+          if (!hip_ok(hipMemcpy2DAsync(b->A + o * b->ld + c0, b->ld * 8, b->msg, wcols * 8, wcols * 8, nbk, hipMemcpyDeviceToDevice, cs))) break;
+          if (!tail && !hip_ok(hipMemcpy2DAsync(Dk, nb * 8, b->msg + nbk * wcols, nbk * 8, nbk * 8, nbk, hipMemcpyDeviceToDevice, cs))) break;
+          if (!api_ok(gpp_shard_list_signal(h, cs, tail, (int)k))) break;
         }
       }
     }
   }
-  SH_TRY(gpp_shard_list_end(h));
+  SH_TRY(gpp_shard_list_end(h));  // (a list whose messages stopped runs into its time-out: the status says so)
+  if (err) return err;
   if (comm_rc) return 3000 + comm_rc;
   SH_HIP(hipEventRecord(h->comm_event, cs));
   SH_HIP(hipStreamWaitEvent(main, h->comm_event, 0));
