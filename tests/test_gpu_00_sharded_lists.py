@@ -78,3 +78,12 @@ def test_sharded_evaluation_through_the_c_driver(world, variant, env):
     for name, e in out["err"].items():
         assert e < 1e-9, (name, e, out)
     assert not out["status_lines"], out["status_lines"]
+
+
+@pytest.mark.gpu
+def test_sharded_lists_through_gp_plus_api():
+    """``settings.sharded_evaluation`` routes GP_Plus's own loss (mixed inputs: two manifold-encoded categorical columns, gradients
+    w.r.t. the latent map through ∂/∂U) through the lists: N = 5000 on two ranks, blocks of 512."""
+    out = _run([5000, 8, 512, 0, 1, 2, "model"], world=2, port=30547, GPP_SHARD_TIMEOUT_MS="20000")
+    assert out["err"]["loss_and_grads"] < 1e-8, out
+    assert (out["list_evals"], out["back_list_evals"]) == (1, 1), (out["list_evals"], out["back_list_evals"], out["status_lines"])

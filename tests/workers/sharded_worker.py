@@ -71,7 +71,9 @@ def model_case(rank, world, dev, N, nb):
         out[mode] = torch.cat([loss.detach().reshape(1)] + [p.grad.reshape(-1) for p in m.parameters() if p.requires_grad]).cpu()
     if rank == 0:
         e = float((out["sharded"] - out["single"]).abs().max() / out["single"].abs().max())
-        emit("RESULT " + json.dumps({"err": {"loss_and_grads": e}, "mll": float(out["single"][0]), "backend": dist.get_backend()}))
+        from gpplus_amd import sharded as _sh
+        emit("RESULT " + json.dumps({"err": {"loss_and_grads": e}, "mll": float(out["single"][0]), "backend": dist.get_backend(),
+                                     "list_evals": _sh.LIST_EVALS, "back_list_evals": _sh.BACK_LIST_EVALS}))
     emit(f"RANK{rank} same_as_rank0={same_as_rank0(out['sharded'], dev)}")
     dist.barrier()
     dist.destroy_process_group()
