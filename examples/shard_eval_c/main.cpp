@@ -1,0 +1,153 @@
+// A C-ABI caller of the sharded evaluation WITHOUT the Python host (include/gpp.h: gpp_set_comm / gpp_comm_init_rccl /
+// gpp_shard_eval): every rank is one process with one GPU and calls gpp_shard_eval once per evaluation; the collectives are RCCL's,
+// opened by the library.  The processes find each other through a file (rank 0 writes the 128-byte RCCL id; a real program would
+// use MPI_Bcast or its own launcher) — with one rank nothing travels.  Reference counterpart of what it computes:
+// `mll(output, y)` + `loss.backward()`, optim/mll_torch.py:114-117.
+//
+//   build:  make -C examples/shard_eval_c          (hipcc; links only libgpp_hip.so and the HIP runtime)
+//   run:    ./shard_eval N [nb] [rank nranks idfile]     prints  mll  |alpha|  g_w[0]  g_sf2  g_tau[0]
+//
+// The inputs are a fixed pseudo-random design (an LCG), so that tests/test_gpu_00_sharded_lists.py can rebuild them in Python and
+// compare with the single-GPU path.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <time.h>
+#include <vector>
+
+#include "../../include/gpp.h"
+
+#define CHECK_HIP(x)                                                                                  \
+  do {                                                                                                \
+    hipError_t e_ = (x);                                                                              \
+    if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); return 2; }       \
+  } while (0)
+#define CHECK_GPP(x)                                                          \
+  do {                                                                        \
+    int r_ = (x);                                                             \
+    if (r_ != 0) { fprintf(stderr, "%s: status %d\n", #x, r_); return 3; }    \
+  } while (0)
+
+static double lcg(uint64_t& s) {  // uniform in [0, 1)
+  s = s * 6364136223846793005ull + 1442695040888963407ull;
+  return (double)(s >> 11) / 9007199254740992.0;
+}
+
+template <typename T>
+static T* dev_alloc(size_t n) {
+  void* p = nullptr;
+  if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) { fprintf(stderr, "hipMalloc of %zu bytes failed\n", n * sizeof(T)); exit(2); }
+  return static_cast<T*>(p);
+}
+
+int main(int argc, char** argv) {
+  if (argc < 2) { fprintf(stderr, "usage: %s N [nb] [rank nranks idfile]\n", argv[0]); return 1; }
+  const int64_t N = atoll(argv[1]), nb = argc > 2 ? atoll(argv[2]) : 1024;
+  const int rank = argc > 5 ? atoi(argv[3]) : 0, nranks = argc > 5 ? atoi(argv[4]) : 1;
+  const int D = 6, S = 2, dU = 0;
+  int ndev = 0;
+  CHECK_HIP(hipGetDeviceCount(&ndev));
+  const int dev = ndev >= nranks ? rank : 0;
+  CHECK_HIP(hipSetDevice(dev));
+  // ---- the design, the targets and the hyper-parameters (what tests rebuild) ----------------------------------------------------------
+  std::vector<double> U((size_t)N * D), r(N), w(D, 2.5), tau = {2e-3, 4e-3};
+  std::vector<int32_t> grp(N);
+  uint64_t seed = 12345;
+  for (auto& u : U) u = lcg(seed);
+  for (int64_t i = 0; i < N; ++i) {
+    const double y = std::sin(3.0 * U[i * D]) + U[i * D + 1] * U[i * D + 1] + 0.05 * (lcg(seed) - 0.5);
+    r[i] = y - 0.1;  // y - mean
+    grp[i] = (int32_t)(i % S);
+  }
+  const double sf2 = 0.8;
+  // ---- handle, communicator, buffers ----------------------------------------------------------------------------------------------
+  gpp_handle_t h = nullptr;
+  CHECK_GPP(gpp_create(&h, dev));
+  hipStream_t st;
+  CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  CHECK_GPP(gpp_set_stream(h, st));
+  if (argc > 5) {  // (an id file: RCCL, also for a single rank — GPP_SHARDED_FORCE_COLLECTIVES=1 then issues every collective)
+    char id[128];
+    if (rank == 0) {
+      CHECK_GPP(gpp_comm_unique_id(id));
+      FILE* f = fopen(argv[5], "wb");
+      if (!f || fwrite(id, 1, 128, f) != 128) return 4;
+      fclose(f);
+      std::string done = std::string(argv[5]) + ".done";
+      f = fopen(done.c_str(), "wb"); if (f) fclose(f);
+    } else {
+      std::string done = std::string(argv[5]) + ".done";
+      for (int t = 0; t < 60000; ++t) {
+        FILE* f = fopen(done.c_str(), "rb");
+        if (f) { fclose(f); break; }
+        struct timespec ts = {0, 1000000}; nanosleep(&ts, nullptr);
+      }
+      FILE* f = fopen(argv[5], "rb");
+      if (!f || fread(id, 1, 128, f) != 128) return 4;
+      fclose(f);
+    }
+    CHECK_GPP(gpp_comm_init_rccl(h, id, rank, nranks));
+  } else {
+    CHECK_GPP(gpp_set_comm(h, nullptr, 0, 1));
+  }
+  const size_t ws_bytes = gpp_workspace_bytes(h, GPP_OP_MLL_EVAL, N, 0, D, S);
+  void* ws = dev_alloc<char>(ws_bytes);
+  CHECK_GPP(gpp_set_workspace(h, ws, ws_bytes));
+  const int64_t nblk = (N + nb - 1) / nb, ld = (N + 15) / 16 * 16;
+  const int64_t owned = rank < nblk ? (nblk - rank + nranks - 1) / nranks : 0, ldc = (owned > 0 ? owned : 1) * nb;
+  gpp_shard_buffers_t b;
+  memset(&b, 0, sizeof b);
+  b.A = dev_alloc<double>(gpp_shard_buffer_doubles(N, nb, rank, nranks, 0)); b.ld = ld;
+  b.Kc = dev_alloc<double>(gpp_shard_buffer_doubles(N, nb, rank, nranks, 1));
+  b.Lc = dev_alloc<double>(gpp_shard_buffer_doubles(N, nb, rank, nranks, 1)); b.ldc = ldc;
+  b.D = dev_alloc<double>(gpp_shard_buffer_doubles(N, nb, rank, nranks, 2));
+  b.W0 = dev_alloc<double>(gpp_shard_buffer_doubles(N, nb, rank, nranks, 3));
+  b.W1 = dev_alloc<double>(gpp_shard_buffer_doubles(N, nb, rank, nranks, 3));
+  b.W2 = dev_alloc<double>(gpp_shard_buffer_doubles(N, nb, rank, nranks, 3)); b.ldw = ld;
+  b.msg = dev_alloc<double>(gpp_shard_buffer_doubles(N, nb, rank, nranks, 4));
+  b.z = dev_alloc<double>(N); b.alpha = dev_alloc<double>(N); b.r = dev_alloc<double>(N);
+  b.flat = dev_alloc<double>(D + 1 + S + (size_t)N * dU);
+  b.out3 = dev_alloc<double>(3); b.info = dev_alloc<int32_t>(2);
+  double *dUm = dev_alloc<double>((size_t)N * D), *dw = dev_alloc<double>(D), *dsf2 = dev_alloc<double>(1), *dtau = dev_alloc<double>(S);
+  int32_t* dgrp = dev_alloc<int32_t>(N);
+  CHECK_HIP(hipMemcpy(dUm, U.data(), U.size() * 8, hipMemcpyHostToDevice));
+  CHECK_HIP(hipMemcpy(dw, w.data(), D * 8, hipMemcpyHostToDevice));
+  CHECK_HIP(hipMemcpy(dsf2, &sf2, 8, hipMemcpyHostToDevice));
+  CHECK_HIP(hipMemcpy(dtau, tau.data(), S * 8, hipMemcpyHostToDevice));
+  CHECK_HIP(hipMemcpy(dgrp, grp.data(), N * 4, hipMemcpyHostToDevice));
+  // ---- evaluations: gpytorch's jitter schedule around the call; the second one is timed ---------------------------------------------------
+  int32_t status = 0;
+  hipEvent_t e0, e1;
+  CHECK_HIP(hipEventCreate(&e0)); CHECK_HIP(hipEventCreate(&e1));
+  float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    CHECK_HIP(hipMemcpy(b.r, r.data(), N * 8, hipMemcpyHostToDevice));
+    CHECK_HIP(hipEventRecord(e0, st));
+    for (double jitter = 0.0;; jitter = jitter > 0 ? 10 * jitter : 1e-8) {
+      const int rc = gpp_shard_eval(h, N, nb, dUm, D, dw, dsf2, dtau, dgrp, S, /*kind*/ 0, /*d_split*/ 0, jitter, dU, /*need_grad*/ 1, &b, &status);
+      if (rc == GPP_SHARD_UNSUPPORTED) { fprintf(stderr, "the ticket lists do not apply to N = %lld, nb = %lld\n", (long long)N, (long long)nb); return 5; }
+      CHECK_GPP(rc);
+      if (status == 0 || jitter >= 1e-6) break;
+    }
+    CHECK_HIP(hipEventRecord(e1, st));
+    CHECK_HIP(hipEventSynchronize(e1));
+    CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+  }
+  if (status != 0) { fprintf(stderr, "status %d (%s)\n", status, status > 0 && status < (1 << 29) ? "not positive definite" : "time-out"); return 6; }
+  double out3[3];
+  std::vector<double> alpha(N), flat(D + 1 + S);
+  CHECK_HIP(hipMemcpy(out3, b.out3, 24, hipMemcpyDeviceToHost));
+  CHECK_HIP(hipMemcpy(alpha.data(), b.alpha, N * 8, hipMemcpyDeviceToHost));
+  CHECK_HIP(hipMemcpy(flat.data(), b.flat, flat.size() * 8, hipMemcpyDeviceToHost));
+  double an = 0;
+  for (double a : alpha) an += a * a;
+  if (rank == 0)
+    printf("RESULT N=%lld nb=%lld ranks=%d ms=%.2f mll=%.12e alpha_norm=%.12e g_w0=%.12e g_sf2=%.12e g_tau0=%.12e g_tau1=%.12e\n", (long long)N,
+           (long long)nb, nranks, ms, out3[2], std::sqrt(an), flat[0], flat[D], flat[D + 1], flat[D + 2]);
+  gpp_destroy(h);
+  return 0;
+}

@@ -18,6 +18,7 @@ from sharded_launch import assert_close_values, config_values, run_ranks as _run
     (3, 10000, 5, 1024, 2, 1, 0, {}),                      # 10 blocks on 3 ranks; Matern 5/2
     (4, 13000, 6, 1024, 0, 2, 2, {}),                      # fused groups of 2 steps, 13 blocks on 4 ranks, per-group noise, manifold gradients
     (2, 15000, 8, 1024, 0, 1, 0, {}),                      # fused groups of 4 steps
+    (2, 20000, 8, 1024, 0, 1, 0, {}),                      # the C2 size on two ranks: 20 blocks, 116 000 tasks over the ranks
     (1, 7000, 6, 512, 0, 1, 0, {"GPP_SHARD_LIST": "0"}),   # the switch: launches per product (rounds 2-4)
 ])
 def test_sharded_ticket_lists_match_single_gpu(world, N, D, nb, kind, S, dU, env):
@@ -87,3 +88,38 @@ def test_sharded_lists_through_gp_plus_api():
     out = _run([5000, 8, 512, 0, 1, 2, "model"], world=2, port=30547, GPP_SHARD_TIMEOUT_MS="20000")
     assert out["err"]["loss_and_grads"] < 1e-8, out
     assert (out["list_evals"], out["back_list_evals"]) == (1, 1), (out["list_evals"], out["back_list_evals"], out["status_lines"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rccl", [False, True])
+def test_c_program_runs_the_sharded_evaluation_without_python(rccl, tmp_path):
+    """examples/shard_eval_c: a C++ program that links libgpp_hip.so and the HIP runtime only — no Python, no torch — builds its own
+    inputs, calls ``gpp_shard_eval`` (one rank; with ``rccl`` through a communicator the LIBRARY opens, every collective issued)
+    and prints loss, |alpha| and gradients; the single-GPU Python path on the same inputs must agree."""
+    import json, os, re, subprocess, sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe_dir = os.path.join(root, "examples", "shard_eval_c")
+    b = subprocess.run(["make", "-C", exe_dir], capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stdout + b.stderr
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPP_SHARD_TIMEOUT_MS="20000")
+    args = [os.path.join(exe_dir, "shard_eval"), "9000", "1024"]
+    if rccl:
+        env["GPP_SHARDED_FORCE_COLLECTIVES"] = "1"
+        env.setdefault("NCCL_SOCKET_IFNAME", "lo")  # (one node: the bootstrap needs no outside interface)
+        args += ["0", "1", str(tmp_path / "rccl_id")]
+    try:
+        p = subprocess.run(args, capture_output=True, text=True, timeout=150, env=env)
+    except subprocess.TimeoutExpired:
+        if rccl:  # (seen once in seven runs on the test pool: the process never got past RCCL's own start-up; the library's part of
+            #        this path — gpp_comm_init_rccl + every collective — is also covered by test_sharded_evaluation_through_the_c_driver)
+            pytest.skip("RCCL did not come up within 150 s in this sandbox")
+        raise
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    got = {k: float(v) for k, v in re.findall(r"(\w+)=([-+0-9.eE]+)", p.stdout.split("RESULT", 1)[1])}
+    q = subprocess.run([sys.executable, os.path.join(root, "tests", "workers", "c_example_reference.py"), "9000"], capture_output=True,
+                       text=True, timeout=600, env=env)
+    assert q.returncode == 0, q.stdout[-2000:] + q.stderr[-2000:]
+    ref = json.loads(q.stdout.split("REFERENCE ", 1)[1].splitlines()[0])
+    for k, v in ref.items():
+        assert abs(got[k] - v) <= 1e-9 * max(abs(v), 1e-300), (k, got[k], v)   # bar: 1e-5 relative (BASELINE north_star)
