@@ -132,10 +132,12 @@ size_t gpp_shard_buffer_doubles(int64_t N, int64_t nb, int rank, int nranks, int
   const int64_t nblk = (N + nb - 1) / nb, ld = (N + 15) / 16 * 16;
   const int64_t wc = std::max<int64_t>(owned_blocks(nblk, rank, nranks), 1) * nb;
   switch (which) {
-    case 0: return (size_t)(N * ld);            /* A (ld = N rounded up to 16) */
-    case 1: return (size_t)(N * wc);            /* Kc, Lc each (ldc = owned blocks x nb) */
+    /* (+ GPP_TILE: the tile kernels READ — never write — up to the next multiple of 128 columns past N along a row; in the last
+       row that is past the matrix: a buffer that ends exactly on a page would fault, as hipMalloc'ed ones of N = 20 000 do) */
+    case 0: return (size_t)(N * ld + GPP_TILE); /* A (ld = N rounded up to 16) */
+    case 1: return (size_t)(N * wc + GPP_TILE); /* Kc, Lc each (ldc = owned blocks x nb) */
     case 2: return (size_t)(nblk * nb * nb);    /* D */
-    case 3: return (size_t)(nb * ld);           /* each scratch row W0..W2 (ldw = ld) */
+    case 3: return (size_t)(nb * ld + GPP_TILE); /* each scratch row W0..W2 (ldw = ld) */
     case 4: return (size_t)(nb * (N + 2 * nb)); /* msg */
     default: return 0;
   }

@@ -222,7 +222,10 @@ typedef struct gpp_shard_buffers {
 int gpp_set_comm(gpp_handle_t h, const gpp_comm_t* comm, int rank, int nranks);
 int gpp_comm_unique_id(void* out128);
 int gpp_comm_init_rccl(gpp_handle_t h, const void* unique_id128, int rank, int nranks);
-/* which: 0 A, 1 Kc / Lc (each), 2 D, 3 W0 / W1 / W2 (each), 4 msg — with ld = ldw = N rounded up to 16, ldc = owned blocks x nb */
+/* which: 0 A, 1 Kc / Lc (each), 2 D, 3 W0 / W1 / W2 (each), 4 msg — with ld = ldw = N rounded up to 16, ldc = owned blocks x nb.
+ * The sizes of A, Kc / Lc and W include 128 doubles of slack behind the last row: the tile kernels read (never write) up to the next
+ * multiple of 128 columns past N along a row, and a buffer that ends exactly on a page boundary must not fault there.  (The same holds
+ * for the N x N operands of gpp_potrf_ws & co. when a caller allocates them with hipMalloc instead of a pooling allocator.) */
 size_t gpp_shard_buffer_doubles(int64_t N, int64_t nb, int rank, int nranks, int which);
 int gpp_shard_eval(gpp_handle_t h, int64_t N, int64_t nb, const double* U, int D, const double* w, const double* sf2, const double* tau,
                    const int32_t* grp, int S, int kind, int d_split, double jitter, int dU, int need_grad, const gpp_shard_buffers_t* b,

@@ -91,8 +91,9 @@ def test_sharded_lists_through_gp_plus_api():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rccl", [False, True])
-def test_c_program_runs_the_sharded_evaluation_without_python(rccl, tmp_path):
+@pytest.mark.parametrize("N,rccl", [(9000, False), (9000, True),
+                                    (20000, False)])  # 20 000: hipMalloc'ed operands that end exactly on a page (the slack of gpp_shard_buffer_doubles)
+def test_c_program_runs_the_sharded_evaluation_without_python(N, rccl, tmp_path):
     """examples/shard_eval_c: a C++ program that links libgpp_hip.so and the HIP runtime only — no Python, no torch — builds its own
     inputs, calls ``gpp_shard_eval`` (one rank; with ``rccl`` through a communicator the LIBRARY opens, every collective issued)
     and prints loss, |alpha| and gradients; the single-GPU Python path on the same inputs must agree."""
@@ -103,7 +104,7 @@ def test_c_program_runs_the_sharded_evaluation_without_python(rccl, tmp_path):
     b = subprocess.run(["make", "-C", exe_dir], capture_output=True, text=True, timeout=600)
     assert b.returncode == 0, b.stdout + b.stderr
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPP_SHARD_TIMEOUT_MS="20000")
-    args = [os.path.join(exe_dir, "shard_eval"), "9000", "1024"]
+    args = [os.path.join(exe_dir, "shard_eval"), str(N), "1024"]
     if rccl:
         env["GPP_SHARDED_FORCE_COLLECTIVES"] = "1"
         env.setdefault("NCCL_SOCKET_IFNAME", "lo")  # (one node: the bootstrap needs no outside interface)
@@ -117,7 +118,7 @@ def test_c_program_runs_the_sharded_evaluation_without_python(rccl, tmp_path):
         raise
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
     got = {k: float(v) for k, v in re.findall(r"(\w+)=([-+0-9.eE]+)", p.stdout.split("RESULT", 1)[1])}
-    q = subprocess.run([sys.executable, os.path.join(root, "tests", "workers", "c_example_reference.py"), "9000"], capture_output=True,
+    q = subprocess.run([sys.executable, os.path.join(root, "tests", "workers", "c_example_reference.py"), str(N)], capture_output=True,
                        text=True, timeout=600, env=env)
     assert q.returncode == 0, q.stdout[-2000:] + q.stderr[-2000:]
     ref = json.loads(q.stdout.split("REFERENCE ", 1)[1].splitlines()[0])

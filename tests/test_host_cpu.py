@@ -453,13 +453,13 @@ def test_shard_eval_buffer_sizes_and_argument_checks():
     lib = _lib.load()
     N, nb = 60000, 1024
     nblk = -(-N // nb)
-    assert lib.gpp_shard_buffer_doubles(N, nb, 0, 8, 0) == N * N              # A: ld = N (a multiple of 16)
-    assert lib.gpp_shard_buffer_doubles(10001, nb, 0, 8, 0) == 10001 * 10016   # ld rounded up to 16
+    assert lib.gpp_shard_buffer_doubles(N, nb, 0, 8, 0) == N * N + 128        # A: ld = N (a multiple of 16) + the read slack
+    assert lib.gpp_shard_buffer_doubles(10001, nb, 0, 8, 0) == 10001 * 10016 + 128   # ld rounded up to 16
     for rank in range(8):
         owned = len(range(rank, nblk, 8))
-        assert lib.gpp_shard_buffer_doubles(N, nb, rank, 8, 1) == N * owned * nb   # Kc / Lc: the owned column blocks, whole
+        assert lib.gpp_shard_buffer_doubles(N, nb, rank, 8, 1) == N * owned * nb + 128   # Kc / Lc: the owned column blocks, whole
     assert lib.gpp_shard_buffer_doubles(N, nb, 3, 8, 2) == nblk * nb * nb
-    assert lib.gpp_shard_buffer_doubles(N, nb, 3, 8, 3) == nb * N
+    assert lib.gpp_shard_buffer_doubles(N, nb, 3, 8, 3) == nb * N + 128
     assert lib.gpp_shard_buffer_doubles(N, nb, 3, 8, 4) == nb * (N + 2 * nb)
     assert lib.gpp_shard_buffer_doubles(N, nb, 3, 8, 9) == 0
     assert lib.gpp_set_comm(None, None, 0, 1) == -1 and lib.gpp_comm_init_rccl(None, None, 0, 1) == -1
