@@ -124,3 +124,14 @@ def test_c_program_runs_the_sharded_evaluation_without_python(N, rccl, tmp_path)
     ref = json.loads(q.stdout.split("REFERENCE ", 1)[1].splitlines()[0])
     for k, v in ref.items():
         assert abs(got[k] - v) <= 1e-9 * max(abs(v), 1e-300), (k, got[k], v)   # bar: 1e-5 relative (BASELINE north_star)
+
+
+@pytest.mark.gpu
+def test_sharded_lists_are_bitwise_repeatable_across_runs():
+    """Which work-group runs a task, and when a message arrives, differ from run to run; the arithmetic of every tile does not (its
+    updates are applied in the order its version counter enforces): two runs of the 3-rank evaluation agree bit for bit in the loss
+    and in every error against the single-GPU path (i.e. in every gradient)."""
+    a = _run([10000, 5, 1024, 0, 2, 2], world=3, port=30611, GPP_SHARD_TIMEOUT_MS="20000")
+    b = _run([10000, 5, 1024, 0, 2, 2], world=3, port=30612, GPP_SHARD_TIMEOUT_MS="20000")
+    assert (a["list_evals"], a["back_list_evals"], b["list_evals"], b["back_list_evals"]) == (1, 1, 1, 1), (a["status_lines"], b["status_lines"])
+    assert a["mll"] == b["mll"] and a["err"] == b["err"], (a["err"], b["err"])
