@@ -13,12 +13,32 @@ above that one evaluation is long enough to hide the host, and the look-ahead dr
 """
 from __future__ import annotations
 
+import contextlib
+import gc
+
 from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 import torch
 
 from .linalg import LOOKAHEAD_MIN_N, get_context, get_workspace
+
+
+@contextlib.contextmanager
+def capture_without_gc():
+    """Around ``torch.cuda.graph``: no garbage collection WHILE a stream is capturing.  ``torch.cuda.graph`` collects once when it is
+    entered, but a collection triggered during the capture can still finalise an older ``CUDAGraph`` (they sit in reference cycles
+    with their closures): its destructor releases a memory pool, HIP refuses that while a stream is capturing, and an error thrown
+    from a destructor aborts the process ("Fatal Python error: Aborted ... Garbage-collecting" inside a capture: seen once in about
+    ten full GPU test runs)."""
+    was = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
 
 __all__ = ["GraphedObjective", "GraphedLossAndGrad"]
 
@@ -68,7 +88,7 @@ class GraphedObjective:
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with capture_without_gc(), torch.cuda.graph(self.graph):
             self.out = body()
         self._lib_scratch = self.gctx._ws  # (same reason: the library's scratch buffer is replaced when a larger one is needed)
         self.last_status = 0
@@ -134,7 +154,7 @@ class GraphedLossAndGrad:
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with capture_without_gc(), torch.cuda.graph(self.graph):
             self.head, self.grads = body()
         self._lib_scratch = self.gctx._ws
         self.replays = self.declined = 0

@@ -153,7 +153,9 @@ class _GraphedLossAndGrad:
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        from ..graphed import capture_without_gc
+
+        with capture_without_gc(), torch.cuda.graph(self.graph):
             self.loss, self.grads = body()
         self._scratch = get_context(dev)._ws
         self.replays = self.declined = 0
