@@ -159,6 +159,9 @@ int gpp_shard_eval(gpp_handle_t h, int64_t N, int64_t nb, const double* U, int D
   *info_host = 0;
   SH_HIP(hipSetDevice(h->device));
   const int64_t nblk = (N + nb - 1) / nb;
+  // (decided from the sizes alone, i.e. the same on every rank, BEFORE anything is enqueued: a rank without a block has no list, and
+  //  a rank that leaves while the others enter the first broadcast would hang them)
+  if (P > nblk) return GPP_SHARD_UNSUPPORTED;
   auto off = [&](int64_t k) { return std::min(k * nb, N); };
   hipStream_t main = h->stream;
   if (!h->comm_stream) SH_HIP(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
