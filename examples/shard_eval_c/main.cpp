@@ -32,6 +32,12 @@
     if (r_ != 0) { fprintf(stderr, "%s: status %d\n", #x, r_); return 3; }    \
   } while (0)
 
+static const bool g_verbose = getenv("SHARD_EVAL_VERBOSE") != nullptr;
+#define STAGE(msg)                                      \
+  do {                                                  \
+    if (g_verbose) { fprintf(stderr, "[stage] %s\n", msg); fflush(stderr); } \
+  } while (0)
+
 static double lcg(uint64_t& s) {  // uniform in [0, 1)
   s = s * 6364136223846793005ull + 1442695040888963407ull;
   return (double)(s >> 11) / 9007199254740992.0;
@@ -65,8 +71,10 @@ int main(int argc, char** argv) {
   }
   const double sf2 = 0.8;
   // ---- handle, communicator, buffers ----------------------------------------------------------------------------------------------
+  STAGE("inputs ready");
   gpp_handle_t h = nullptr;
   CHECK_GPP(gpp_create(&h, dev));
+  STAGE("handle created");
   hipStream_t st;
   CHECK_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
   CHECK_GPP(gpp_set_stream(h, st));
@@ -94,6 +102,7 @@ int main(int argc, char** argv) {
   } else {
     CHECK_GPP(gpp_set_comm(h, nullptr, 0, 1));
   }
+  STAGE("communicator set");
   const size_t ws_bytes = gpp_workspace_bytes(h, GPP_OP_MLL_EVAL, N, 0, D, S);
   void* ws = dev_alloc<char>(ws_bytes);
   CHECK_GPP(gpp_set_workspace(h, ws, ws_bytes));
@@ -119,6 +128,7 @@ int main(int argc, char** argv) {
   CHECK_HIP(hipMemcpy(dsf2, &sf2, 8, hipMemcpyHostToDevice));
   CHECK_HIP(hipMemcpy(dtau, tau.data(), S * 8, hipMemcpyHostToDevice));
   CHECK_HIP(hipMemcpy(dgrp, grp.data(), N * 4, hipMemcpyHostToDevice));
+  STAGE("buffers allocated and filled");
   // ---- evaluations: gpytorch's jitter schedule around the call; the second one is timed ---------------------------------------------------
   int32_t status = 0;
   hipEvent_t e0, e1;
@@ -128,19 +138,25 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipMemcpy(b.r, r.data(), N * 8, hipMemcpyHostToDevice));
     CHECK_HIP(hipEventRecord(e0, st));
     for (double jitter = 0.0;; jitter = jitter > 0 ? 10 * jitter : 1e-8) {
+      STAGE("calling gpp_shard_eval");
       const int rc = gpp_shard_eval(h, N, nb, dUm, D, dw, dsf2, dtau, dgrp, S, /*kind*/ 0, /*d_split*/ 0, jitter, dU, /*need_grad*/ 1, &b, &status);
       if (rc == GPP_SHARD_UNSUPPORTED) { fprintf(stderr, "the ticket lists do not apply to N = %lld, nb = %lld\n", (long long)N, (long long)nb); return 5; }
+      STAGE("gpp_shard_eval returned");
       CHECK_GPP(rc);
       if (status == 0 || jitter >= 1e-6) break;
     }
     CHECK_HIP(hipEventRecord(e1, st));
+    STAGE("event recorded");
     CHECK_HIP(hipEventSynchronize(e1));
+    STAGE("event synchronised");
     CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
   }
   if (status != 0) { fprintf(stderr, "status %d (%s)\n", status, status > 0 && status < (1 << 29) ? "not positive definite" : "time-out"); return 6; }
   double out3[3];
   std::vector<double> alpha(N), flat(D + 1 + S);
+  STAGE("reading results");
   CHECK_HIP(hipMemcpy(out3, b.out3, 24, hipMemcpyDeviceToHost));
+  STAGE("out3 read");
   CHECK_HIP(hipMemcpy(alpha.data(), b.alpha, N * 8, hipMemcpyDeviceToHost));
   CHECK_HIP(hipMemcpy(flat.data(), b.flat, flat.size() * 8, hipMemcpyDeviceToHost));
   double an = 0;
@@ -148,6 +164,9 @@ int main(int argc, char** argv) {
   if (rank == 0)
     printf("RESULT N=%lld nb=%lld ranks=%d ms=%.2f mll=%.12e alpha_norm=%.12e g_w0=%.12e g_sf2=%.12e g_tau0=%.12e g_tau1=%.12e\n", (long long)N,
            (long long)nb, nranks, ms, out3[2], std::sqrt(an), flat[0], flat[D], flat[D + 1], flat[D + 2]);
+  fflush(stdout);
+  STAGE("destroying the handle");
   gpp_destroy(h);
+  STAGE("done");
   return 0;
 }

@@ -945,10 +945,15 @@ int gpp_create(gpp_handle_t* out, int device) {
 
 int gpp_destroy(gpp_handle_t h) {
   if (!h) return -1;
-  if (h->panel_stream) (void)hipStreamDestroy(h->panel_stream);
-  if (h->upd_stream) (void)hipStreamDestroy(h->upd_stream);
-  if (h->fill_stream) (void)hipStreamDestroy(h->fill_stream);
+  // (every internal stream drained first, then destroyed in the reverse order of creation: fill_stream and upd_stream carry the SAME
+  //  CU mask, and destroying upd_stream first left hipStreamDestroy(fill_stream) hanging in ~3 of 20 runs of examples/shard_eval_c —
+  //  on an idle device)
+  for (hipStream_t s : {h->panel_stream, h->upd_stream, h->fill_stream, h->full_stream})
+    if (s) (void)hipStreamSynchronize(s);
   if (h->full_stream) (void)hipStreamDestroy(h->full_stream);
+  if (h->fill_stream) (void)hipStreamDestroy(h->fill_stream);
+  if (h->upd_stream) (void)hipStreamDestroy(h->upd_stream);
+  if (h->panel_stream) (void)hipStreamDestroy(h->panel_stream);
   for (int i = 0; i < h->n_events; ++i) (void)hipEventDestroy(h->events[i]);
   if (h->panel_flags) (void)hipFree(h->panel_flags);
   for (int i = 0; i < 4; ++i)
