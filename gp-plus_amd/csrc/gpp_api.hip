@@ -935,8 +935,6 @@ int gpp_create(gpp_handle_t* out, int device) {
       hipMemset(h->panel_flags, 0, (GPP_PANEL_RING + GPP_PANEL_CAP_RING) * gpp_panel_flag_bytes()) != hipSuccess) {
     (void)hipGetLastError();
     if (h->panel_flags) (void)hipFree(h->panel_flags);
-  if (h->handoff) (void)hipEventDestroy(h->handoff);
-  if (h->shard_ready) (void)hipEventDestroy(h->shard_ready);
     h->panel_flags = nullptr;  // the leaf-step chain is used instead
   }
   *out = h;
@@ -955,6 +953,8 @@ int gpp_destroy(gpp_handle_t h) {
   if (h->upd_stream) (void)hipStreamDestroy(h->upd_stream);
   if (h->panel_stream) (void)hipStreamDestroy(h->panel_stream);
   for (int i = 0; i < h->n_events; ++i) (void)hipEventDestroy(h->events[i]);
+  if (h->handoff) (void)hipEventDestroy(h->handoff);
+  if (h->shard_ready) (void)hipEventDestroy(h->shard_ready);
   if (h->panel_flags) (void)hipFree(h->panel_flags);
   for (int i = 0; i < 4; ++i)
     if (h->dag_plans[i]) gpp_dag_free(h->dag_plans[i]);
