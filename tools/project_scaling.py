@@ -20,8 +20,8 @@ import math
 
 ONE_RANK = {  # measured, one rank, ticket lists (profiles/r05_sharded_lists_1rank.txt), ms: factor + forward list (incl. build, mirror),
               # back-substitution list, vectors + gradient; chain pieces from the list's task traces (profiles/r05_dag_traces.txt)
-    "C5": dict(N=60000, nb=1024, ff=2243.5, back=1107.9, small=19.4, chain_ms=0.15 + 0.63 + 0.16 + 0.16 + 0.10),
-    "C2": dict(N=20000, nb=1024, ff=89.8, back=42.7, small=2.8, chain_ms=0.15 + 0.63 + 0.16 + 0.16 + 0.10),
+    "C5": dict(N=60000, nb=1024, ff=2272.2, back=1140.8, small=20.5, chain_ms=0.15 + 0.63 + 0.16 + 0.16 + 0.10),
+    "C2": dict(N=20000, nb=1024, ff=90.3, back=43.6, small=2.8, chain_ms=0.15 + 0.63 + 0.16 + 0.16 + 0.10),
 }
 SINGLE_GPU_EVALS = {"C2": 7.80, "C5": 1 / 3.21}  # evals/s of the single-GPU path (bench.py / tools/run_configs.py, round 5)
 
