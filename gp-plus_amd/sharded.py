@@ -35,6 +35,14 @@ plus what the rank OWNS of the other two: its column blocks of L^-1 and of Ky^-1
 blocks' inverses (N x nb) and an nb x N row of scratch: 28.8 + 2 x 3.6 + 1 GB = 37 GB at C5 on 8 GPUs where three full matrices took
 86 GB on every rank ("28.8 GB (3.6 GB/GPU sharded)") — what grows with N on a rank is the factor alone.
 
+Round 5: where they apply (N >= 4096, block height nb = 1024 or another the cooperative panel takes, a last block of more than 256
+rows) the factorisation + forward sweep and the back-substitution of a rank run as TICKET LISTS of the DAG executor
+(``_factor_list``, ``gpp_shard_back_list``; csrc/gpp_dag.hip DAG_SHARD / DAG_BACK): the launches described above become tile tasks
+in dependency order taken by persistent work-groups, the block rows of other ranks arrive as the same two messages and raise one
+counter each, and the factor's mirror is written beside the list.  ``GPP_SHARD_LIST=0`` keeps the launch-per-product choreography,
+which is also the fall-back (other sizes, a time-out).  One rank: 136 ms against 168 at C2, 3.4 s against 3.5 at C5.  The whole
+evaluation is also available as ONE C call per rank (``gpp_shard_eval``; ``sharded_c.py``).
+
 Without RCCL (tests: several processes sharing one GPU over "gloo") the collectives are staged through host memory.
 ``GPP_SHARDED_FORCE_COLLECTIVES=1`` issues every collective (and the packing around it) even in a group of one rank, so that
 the RCCL branch runs on a single GPU (tests/test_gpu_sharded.py).
