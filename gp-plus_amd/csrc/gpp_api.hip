@@ -626,7 +626,7 @@ hipError_t potrf_lookahead(gpp_handle_s* h, const Ctx& cm, int64_t N, int64_t NB
 // diagonal blocks: there every launch boundary (head solve -> diagonal update -> rest solve -> trailing update, in stream order)
 // and every bordering product's few long tiles cost idle CUs (profiles/r04_timeline_n10000.txt: 16.3 ms for 10 ms of tile work).
 // Plans depend on (N, nb, leading dimensions, flags) only — the operands' addresses are kernel arguments — and live in a small LRU
-// per handle; nothing here synchronises the device.  *used = false: not applicable, the caller continues with the older paths.
+// (GPP_DAG_PLANS) per handle; a plan that is HIT costs no synchronisation, an eviction does (gpp_dag_free: hipFree).  *used = false: not applicable, the caller continues with the older paths.
 // what gpp_trtri will find inverted: the leading block the list built (all of the matrix: nothing left to merge), and every
 // diagonal block behind it
 void dag_note_inverted(gpp_handle_s* h, const DagPlan* P, int64_t N) {
@@ -643,6 +643,15 @@ void dag_note_inverted(gpp_handle_s* h, const DagPlan* P, int64_t N) {
     h->inv_n[h->inv_nblocks] = rows;
     ++h->inv_nblocks;
   }
+}
+
+// Raise the abort word of a running list (counters[0]: every wait of the executor, its fillers and its gate kernels sees it and
+// leaves) from the handle's stream WITHOUT a CU mask, on which nothing of a list is ever queued — so the store is not ordered behind
+// the launches it is meant to end.
+hipError_t dag_abort(gpp_handle_s* h, const DagPlan* P) {
+  if (!h->full_stream || !P || !P->d_counters) return hipErrorInvalidValue;
+  HIP_TRY(gpp_launch_fill_i32(h->full_stream, P->d_counters, 1, 1));
+  return hipStreamSynchronize(h->full_stream);  // (an error path: the host may wait for one store)
 }
 
 hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64_t ldt, bool* used) {
@@ -686,7 +695,7 @@ hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64
   // the plan: a hit in the handle's LRU, or planned now (host only) and uploaded (a few MB, once per shape)
   DagPlan* P = nullptr;
   int slot = -1, lru = 0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < GPP_DAG_PLANS; ++i) {
     DagPlan* q = h->dag_plans[i];
     if (q && q->N == N && q->nb == nb && q->ld == cm.ld && q->ldi == cm.ldi && q->ldt == ldt && q->flags == flags && q->inv_rows == inv_rows) slot = i;
     if (!q) lru = i;
@@ -718,7 +727,7 @@ hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64
       h->dag_sched = 0;
       return hipSuccess;
     }
-    if (h->dag_plans[lru]) gpp_dag_free(h->dag_plans[lru]);  // (waits for that plan's own last launch only)
+    if (h->dag_plans[lru]) gpp_dag_free(h->dag_plans[lru]);  // (its own last launch, then hipFree: a device-wide wait, see gpp_dag_free)
     h->dag_plans[lru] = P;
   }
   P->stamp = ++h->dag_clock;
@@ -762,25 +771,35 @@ hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64
     return hipSuccess;
   }
   HIP_TRY(gpp_launch_dag(cu.s, dag_workers > 0 ? dag_workers : 2 * (h->ncu - h->panel_cus), dl));
-  for (const DagPlan::Op& op : P->stream_ops) {
-    const int64_t o = op.kind < 3 ? (int64_t)P->tb[op.arg] * NBLK : 0;
-    if (op.kind == 0) {
-      HIP_TRY(gpp_launch_exec_gate(cp.s, P->d_counters, P->c_g1d + op.arg, P->gate_target[op.arg], cm.info, budget));
-    } else if (op.kind == 1) {
-      const int64_t rows = std::min<int64_t>((int64_t)P->tb[op.arg + 1] * NBLK, N) - o;
-      HIP_TRY(launch_panel(h, cp, o, rows, h->panel_cus));
-    } else if (op.kind == 2) {
-      HIP_TRY(gpp_launch_exec_signal(cp.s, P->d_counters, P->c_pd + op.arg));
-    } else {
-      // filler: two work-groups per panel CU take tasks from the same list until the next diagonal block's update has begun
-      DagLaunch fl = dl;
-      fl.max_tasks = op.arg;  // (0 behind the last panel: until the list is exhausted)
-      fl.quit_id = op.n >= 0 ? P->c_g1d + op.n : -1;
-      fl.quit_val = 1;
-      fl.ticket_limit = op.lim;
-      fl.tag = op.n >= 0 ? op.n : P->B;
-      HIP_TRY(gpp_launch_dag(cp.s, 2 * h->panel_cus, fl));
+  // (the executor is running from here on: a failure below raises the abort word and still joins the streams — its work-groups
+  //  would otherwise spin for the whole budget behind a call that has already returned an error)
+  auto enqueue_panel_stream = [&]() -> hipError_t {
+    for (const DagPlan::Op& op : P->stream_ops) {
+      const int64_t o = op.kind < 3 ? (int64_t)P->tb[op.arg] * NBLK : 0;
+      if (op.kind == 0) {
+        HIP_TRY(gpp_launch_exec_gate(cp.s, P->d_counters, P->c_g1d + op.arg, P->gate_target[op.arg], cm.info, budget));
+      } else if (op.kind == 1) {
+        const int64_t rows = std::min<int64_t>((int64_t)P->tb[op.arg + 1] * NBLK, N) - o;
+        HIP_TRY(launch_panel(h, cp, o, rows, h->panel_cus));
+      } else if (op.kind == 2) {
+        HIP_TRY(gpp_launch_exec_signal(cp.s, P->d_counters, P->c_pd + op.arg));
+      } else {
+        // filler: two work-groups per panel CU take tasks from the same list until the next diagonal block's update has begun
+        DagLaunch fl = dl;
+        fl.max_tasks = op.arg;  // (0 behind the last panel: until the list is exhausted)
+        fl.quit_id = op.n >= 0 ? P->c_g1d + op.n : -1;
+        fl.quit_val = 1;
+        fl.ticket_limit = op.lim;
+        fl.tag = op.n >= 0 ? op.n : P->B;
+        HIP_TRY(gpp_launch_dag(cp.s, 2 * h->panel_cus, fl));
+      }
     }
+    return hipSuccess;
+  };
+  const hipError_t perr = enqueue_panel_stream();
+  if (perr != hipSuccess) {
+    (void)hipGetLastError();
+    (void)dag_abort(h, P);
   }
   hipEvent_t E = next_event(h), F = next_event(h);
   HIP_TRY(hipEventRecord(E, cu.s));
@@ -788,6 +807,7 @@ hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64
   HIP_TRY(hipStreamWaitEvent(cm.s, E, 0));
   HIP_TRY(hipStreamWaitEvent(cm.s, F, 0));
   HIP_TRY(hipEventRecord(P->last_use, cm.s));
+  if (perr != hipSuccess) return perr;
   dag_note_inverted(h, P, N);
   *used = true;
   return hipSuccess;
@@ -828,7 +848,7 @@ int gpp_debug_panel_flags(gpp_handle_t h, int* out, int nints, int* next_slot) {
 static DagPlan* dag_mru(gpp_handle_t h) {
   DagPlan* P = nullptr;
   if (h)
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < GPP_DAG_PLANS; ++i)
       if (h->dag_plans[i] && (!P || h->dag_plans[i]->stamp > P->stamp)) P = h->dag_plans[i];
   return P;
 }
@@ -917,7 +937,7 @@ int gpp_create(gpp_handle_t* out, int device) {
   h->coop_panel = panel_enabled() ? 1 : 0;
   h->panel_fault = 0;
   h->panel_timeout_ms = 500;
-  for (int i = 0; i < 4; ++i) h->dag_plans[i] = nullptr;
+  for (int i = 0; i < GPP_DAG_PLANS; ++i) h->dag_plans[i] = nullptr;
   h->shard_cur = nullptr;
   h->shard_info = nullptr;
   h->shard_ready = nullptr;
@@ -956,7 +976,7 @@ int gpp_destroy(gpp_handle_t h) {
   if (h->handoff) (void)hipEventDestroy(h->handoff);
   if (h->shard_ready) (void)hipEventDestroy(h->shard_ready);
   if (h->panel_flags) (void)hipFree(h->panel_flags);
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < GPP_DAG_PLANS; ++i)
     if (h->dag_plans[i]) gpp_dag_free(h->dag_plans[i]);
   gpp_shard_release_comm(h);
   delete h;
@@ -1046,7 +1066,7 @@ int gpp_shard_list_begin(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nr
   const int flags = DAG_INV | DAG_SHARD;
   DagPlan* P = nullptr;
   int slot = -1, lru = 0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < GPP_DAG_PLANS; ++i) {
     DagPlan* q = h->dag_plans[i];
     if (q && q->N == N && q->nb == nb && q->ld == ld && q->ldi == ldc && q->ldt == ldw && q->flags == flags && q->rank == rank &&
         q->nranks == nranks && q->workers == workers)
@@ -1100,32 +1120,44 @@ int gpp_shard_list_begin(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nr
   dl.max_tasks = 0; dl.quit_id = -1; dl.quit_val = 0; dl.ticket_limit = 0;
   dl.trace = P->d_trace; dl.tag = 0;
   if (dl.ntasks > 0) GPP_TRY(gpp_launch_dag(su, nworkers, dl));
+  // From here on the persistent executor is RUNNING: a failure below must not leave its work-groups spinning for the whole time-out
+  // with the handle unable to join them.  The list stays open (the caller's gpp_shard_list_end joins the streams and records the
+  // plan's last use) and the abort word is raised from a stream nothing of the list is queued on.
   Ctx cp{sp, A, ld, D, nb, info};
-  for (const DagPlan::Op& op : P->stream_ops) {
-    const int b = op.arg;
-    const int64_t o = (int64_t)b * nb, rows = std::min(nb, N - o);
-    if (op.kind == 0) {
-      GPP_TRY(gpp_launch_exec_gate(sp, P->d_counters, P->c_g1d + b, P->gate_target[b], info, budget));
-    } else if (op.kind == 1) {
-      // the diagonal block's factor in place, its inverse (+ mirror) into D[b]
-      Ctx cb = cp;
-      cb.A = A + o * ld + o;
-      cb.Li = D + (int64_t)b * nb * nb;
-      GPP_TRY(launch_panel_at(h, cb, o, rows, h->panel_cus));
-    } else if (op.kind == 2) {
-      GPP_TRY(gpp_launch_exec_signal(sp, P->d_counters, P->c_pd + b));
-    } else {
-      DagLaunch fl = dl;
-      fl.max_tasks = op.arg;
-      fl.quit_id = op.n >= 0 ? P->c_g1d + op.n : -1;
-      fl.quit_val = 1;
-      fl.ticket_limit = op.lim;
-      fl.tag = op.n >= 0 ? op.n : P->B;
-      GPP_TRY(gpp_launch_dag(sp, std::max(P->fill, 1), fl));
+  auto enqueue_panel_stream = [&]() -> int {
+    for (const DagPlan::Op& op : P->stream_ops) {
+      const int b = op.arg;
+      const int64_t o = (int64_t)b * nb, rows = std::min(nb, N - o);
+      if (op.kind == 0) {
+        GPP_TRY(gpp_launch_exec_gate(sp, P->d_counters, P->c_g1d + b, P->gate_target[b], info, budget));
+      } else if (op.kind == 1) {
+        // the diagonal block's factor in place, its inverse (+ mirror) into D[b]
+        Ctx cb = cp;
+        cb.A = A + o * ld + o;
+        cb.Li = D + (int64_t)b * nb * nb;
+        GPP_TRY(launch_panel_at(h, cb, o, rows, h->panel_cus));
+      } else if (op.kind == 2) {
+        GPP_TRY(gpp_launch_exec_signal(sp, P->d_counters, P->c_pd + b));
+      } else {
+        DagLaunch fl = dl;
+        fl.max_tasks = op.arg;
+        fl.quit_id = op.n >= 0 ? P->c_g1d + op.n : -1;
+        fl.quit_val = 1;
+        fl.ticket_limit = op.lim;
+        fl.tag = op.n >= 0 ? op.n : P->B;
+        GPP_TRY(gpp_launch_dag(sp, std::max(P->fill, 1), fl));
+      }
     }
-  }
+    return 0;
+  };
+  const int erc = enqueue_panel_stream();
   h->shard_cur = P;
   h->shard_info = info;
+  if (erc != 0) {
+    (void)hipGetLastError();
+    (void)dag_abort(h, P);
+    return erc;  // (*used stays 0; the list is open: gpp_shard_list_end must still be called)
+  }
   *used = 1;
   return 0;
 }
@@ -1191,7 +1223,7 @@ int gpp_shard_back_list(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nra
   const int flags = DAG_SHARD | DAG_BACK;
   DagPlan* P = nullptr;
   int slot = -1, lru = 0;
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < GPP_DAG_PLANS; ++i) {
     DagPlan* q = h->dag_plans[i];
     if (q && q->N == N && q->nb == nb && q->ld == ld && q->ldi == ldc && q->flags == flags && q->rank == rank && q->nranks == nranks &&
         q->workers == workers)

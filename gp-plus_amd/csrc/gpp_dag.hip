@@ -1254,9 +1254,11 @@ hipError_t gpp_dag_upload(DagPlan* P) {
 void gpp_dag_free(DagPlan* P) {
   if (!P) return;
   if (P->last_use) {
-    (void)hipEventSynchronize(P->last_use);  // the launches that read the device copies are over (no device-wide wait)
+    (void)hipEventSynchronize(P->last_use);  // the launches that read the device copies are over
     (void)hipEventDestroy(P->last_use);
   }
+  // (hipFree synchronises the DEVICE: an eviction from the handle's LRU — more than GPP_DAG_PLANS shapes alive — is not free of
+  //  device-wide waits; it happens in front of a re-plan that costs far more host time, before anything of that call is enqueued)
   if (P->d_groups) (void)hipFree(P->d_groups);
   if (P->d_groups_abs) (void)hipFree(P->d_groups_abs);
   if (P->d_tasks) (void)hipFree(P->d_tasks);

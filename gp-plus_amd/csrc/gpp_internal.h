@@ -7,6 +7,10 @@
 #include "../../include/gpp.h"
 
 #define GPP_TILE 128 /* GEMM work-group tile edge and Cholesky leaf size */
+/* Plans the DAG executor keeps per handle (LRU).  A sharded evaluation holds two (factor + forward sweep, back-substitution) beside
+ * the single-GPU plan of the same size, and a driver that plays every rank of a P = 8 run on one handle (tools/replay_rank.py) 16:
+ * evicting a plan costs a re-plan (~1.2 s of host time at N = 60 000) and its hipFree calls synchronise the device. */
+#define GPP_DAG_PLANS 20
 
 struct gpp_handle_s {
   int device;
@@ -41,7 +45,7 @@ struct gpp_handle_s {
   int coop_panel;            // GPP_OPT_COOP_PANEL
   int panel_fault;           // GPP_OPT_PANEL_FAULT: the next panel launch only reports the time-out status (tests)
   int panel_timeout_ms;      // GPP_OPT_PANEL_TIMEOUT_MS: budget of a wait inside the panel kernel (100 MHz constant clock)
-  struct DagPlan* dag_plans[4];     // small LRU of DAG-executor plans (gpp_dag.hip), keyed by (N, nb, leading dimensions, flags)
+  struct DagPlan* dag_plans[GPP_DAG_PLANS];  // LRU of DAG-executor plans (gpp_dag.hip), keyed by (N, nb, leading dimensions, flags, rank, ranks)
   uint64_t dag_clock;
   struct DagPlan* shard_cur;  // the sharded list between gpp_shard_list_begin and _end
   int32_t* shard_info;

@@ -18,6 +18,8 @@
 
 namespace {
 
+typedef double v2d_t __attribute__((ext_vector_type(2)));
+
 inline int rc(hipError_t e) { return e == hipSuccess ? 0 : 1000 + (int)e; }
 #define SH_HIP(expr)                      \
   do {                                    \
@@ -34,6 +36,69 @@ inline int rc(hipError_t e) { return e == hipSuccess ? 0 : 1000 + (int)e; }
 __global__ void gpp_copy_lower(const double* __restrict__ src, int64_t lds, double* __restrict__ dst, int64_t ldd, int n) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
   if (j < n) dst[(int64_t)i * ldd + j] = j <= i ? src[(int64_t)i * lds + j] : 0.0;
+}
+
+// ---- virtual-rank replay (tools/replay_rank.py; debug entry points, not part of gpp.h) -----------------------------------------------
+// A block row that would arrive from another GPU is PLAYED into this rank's buffers by a copy kernel with a collective kernel's
+// footprint (a few work-groups of 256-512 threads on whatever CUs have room) that (a) does not start before a given time on the
+// device's 100 MHz constant clock — the earliest moment its owner could have sent it — and (b) moves its bytes no faster than a given
+// rate — the wire.  Two time stamps (start of the first piece, end of the last) come back relative to the caller's epoch.
+__global__ __launch_bounds__(512) void gpp_replay_copy(double* __restrict__ dst, int64_t ldd, const double* __restrict__ src, int64_t lds,
+                                                       int rows, int cols, double bytes_per_tick, const unsigned long long* epoch,
+                                                       long long not_before, unsigned long long* stamps) {
+  __shared__ long long s_start;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  constexpr int PIECE = 4096;  // 16-byte vectors per piece (64 KiB)
+  if (tid == 0) {
+    long long now = (long long)wall_clock64();
+    if (epoch && not_before >= 0) {
+      const long long target = (long long)*epoch + not_before;
+      while (now < target) {
+        __builtin_amdgcn_s_sleep(16);
+        now = (long long)wall_clock64();
+      }
+    }
+    s_start = now;
+    if (stamps && blockIdx.x == 0) stamps[0] = (unsigned long long)(now - (epoch ? (long long)*epoch : 0));
+  }
+  __syncthreads();
+  const long long start = s_start;
+  const int vpr = cols >> 1;  // (cols even: the callers' column ranges are multiples of the block height or end at an even N)
+  const long long nvec = (long long)rows * vpr;
+  const long long npieces = (nvec + PIECE - 1) / PIECE;
+  for (long long q = blockIdx.x; q < npieces; q += gridDim.x) {
+    if (bytes_per_tick > 0.0) {  // pacing: piece q does not start before the wire would have delivered the q pieces in front of it
+      if (tid == 0) {
+        const long long target = start + (long long)((double)q * (PIECE * 16.0) / bytes_per_tick);
+        while ((long long)wall_clock64() < target) __builtin_amdgcn_s_sleep(4);
+      }
+      __syncthreads();
+    }
+    const long long v0 = q * PIECE, v1 = v0 + PIECE < nvec ? v0 + PIECE : nvec;
+    for (long long v = v0 + tid; v < v1; v += nth) {
+      const int r = (int)(v / vpr), c = (int)(v - (long long)r * vpr) << 1;
+      const v2d_t x = *reinterpret_cast<const v2d_t*>(src + (int64_t)r * lds + c);
+      *reinterpret_cast<v2d_t*>(dst + (int64_t)r * ldd + c) = x;
+    }
+  }
+  if (stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      long long now = (long long)wall_clock64();
+      if (bytes_per_tick > 0.0) {  // the last byte is not "there" before the wire says so
+        const long long target = start + (long long)((double)nvec * 16.0 / bytes_per_tick);
+        while (now < target) {
+          __builtin_amdgcn_s_sleep(4);
+          now = (long long)wall_clock64();
+        }
+      }
+      atomicMax(stamps + 1, (unsigned long long)(now - (epoch ? (long long)*epoch : 0)));
+    }
+  }
+}
+__global__ __launch_bounds__(64) void gpp_replay_stamp(unsigned long long* slot, const unsigned long long* epoch) {
+  if (threadIdx.x == 0) *slot = wall_clock64() - (epoch ? *epoch : 0ull);
 }
 
 // ---- RCCL, opened at run time ------------------------------------------------------------------------------------------------------
@@ -81,6 +146,26 @@ int64_t owned_blocks(int64_t nblk, int rank, int nranks) { return rank < nblk ? 
 }  // namespace
 
 extern "C" {
+
+/* (debug, tools/replay_rank.py) rows x cols doubles (cols even, both pointers 16-byte aligned, ld even) from src to dst on `stream` by
+ * `wgs` work-groups of `threads` threads, not before *epoch + not_before ticks of the 100 MHz clock (not_before < 0: at once) and no
+ * faster than `gbps` GB/s (<= 0: unthrottled); stamps2 (device, 2 x uint64, zeroed by the caller): start and end relative to *epoch.
+ * With a pacing rate the kernel ends when the LAST byte is due, whatever the copy itself took. */
+int gpp_debug_replay_copy(void* stream, double* dst, int64_t ldd, const double* src, int64_t lds, int64_t rows, int64_t cols, int wgs,
+                          int threads, double gbps, const void* epoch, long long not_before, void* stamps2) {
+  if (rows < 0 || cols < 0 || (cols & 1) || (ldd & 1) || (lds & 1) || rows * (cols / 2) >= ((int64_t)1 << 31)) return -1;
+  if (wgs < 1 || threads < 64 || threads > 512 || threads % 64 != 0) return -2;
+  hipLaunchKernelGGL(gpp_replay_copy, dim3((unsigned)wgs), dim3((unsigned)threads), 0, reinterpret_cast<hipStream_t>(stream), dst, ldd, src,
+                     lds, (int)rows, (int)cols, gbps > 0.0 ? gbps * 10.0 : 0.0, reinterpret_cast<const unsigned long long*>(epoch),
+                     not_before, reinterpret_cast<unsigned long long*>(stamps2));
+  return rc(hipGetLastError());
+}
+/* (debug) *slot = the 100 MHz clock now, minus *epoch when given */
+int gpp_debug_replay_stamp(void* stream, void* slot, const void* epoch) {
+  hipLaunchKernelGGL(gpp_replay_stamp, dim3(1), dim3(64), 0, reinterpret_cast<hipStream_t>(stream), reinterpret_cast<unsigned long long*>(slot),
+                     reinterpret_cast<const unsigned long long*>(epoch));
+  return rc(hipGetLastError());
+}
 
 int gpp_set_comm(gpp_handle_t h, const gpp_comm_t* comm, int rank, int nranks) {
   if (!h) return -1;
@@ -257,6 +342,9 @@ int gpp_shard_eval(gpp_handle_t h, int64_t N, int64_t nb, const double* U, int D
                               b->flat + D + 1, dU > 0 ? b->flat + D + 1 + S : nullptr, 1));
   if (travel) {
     if (int r = h->comm.allreduce(h->comm.user, b->flat, nflat, GPP_COMM_SUM_F64, main)) return 3000 + r;
+    // (a time-out inside ONE rank's back-substitution list must be every rank's status: the caller's reaction — switch the executor
+    //  off, evaluate again — involves collectives, so all ranks have to take it together)
+    if (int r = h->comm.allreduce(h->comm.user, b->info, 1, GPP_COMM_MAX_I32, main)) return 3000 + r;
   }
   SH_HIP(hipMemcpyAsync(info_host, b->info, sizeof(int32_t), hipMemcpyDeviceToHost, main));  // (a time-out inside the back-substitution)
   SH_HIP(hipStreamSynchronize(main));

@@ -602,19 +602,24 @@ def _vectors(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, need_alpha: boo
         comm.allreduce(ws.alpha)
 
 
-def _backward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
+def _backward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> int:
     """The owned column blocks of Ky^-1 = L^-T L^-1 (rows at and below their diagonal block) into ``Lc``, by back-substitution of
     the owned column blocks Y of L^-1 (in ``Kc``) against the replicated factor:  U[c:, c:] Z = Y, block row j from the last
     one up:   Z_j = X_jj^T Y_j   (X_jj = L_jj^-1: the lower part of ``D[j]``), then the right-looking update
     Y_i -= U[i, j] Z_j of every block row c <= i < j — ONE TN GEMM per step over the lower-triangular tiles of the owned
     column blocks, its row-contiguous left operand being the factor's mirror L[j, i] in the strict lower triangle of ``A``.
     One step of look-ahead as in ``_forward``: block row j-1 of the update first, the small products of step j-1 on a second
-    stream beside the rest.  No communication (bullet 4)."""
+    stream beside the rest.  No communication (bullet 4).  Returns 0, or the status of a ticket list that timed out
+    (agreed on by all ranks; Kc is then destroyed and the caller evaluates again)."""
     offs, P, me, nb = ws.offs, comm.world, comm.rank, ws.nb
     nblk = len(offs) - 1
     A, Lc, Kc = ws.A, ws.Lc, ws.Kc
     if _first_owned(ws, comm) is None:
-        return
+        if _USE_LIST and ctx.dag_sched and comm.travel:
+            info = torch.zeros(1, dtype=torch.int32, device=ws.info.device)  # (takes part in the other ranks' status agreement)
+            comm.allreduce(info, dist.ReduceOp.MAX)
+            return int(info.item())
+        return 0
     if _USE_LIST and ctx.dag_sched:
         # the same sweep as ONE ticket list (gpp_shard_back_list in gpp.h).  The diagonal blocks of Ky^-1 are written as lower
         # triangles: clear what the forward sweep's sums left above them first
@@ -624,15 +629,18 @@ def _backward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
         if not used and os.environ.get("GPP_SHARD_DEBUG"):
             print(f"[sharded rank {me}] back-substitution list: not used", flush=True)
         if used:
-            global BACK_LIST_EVALS
-            BACK_LIST_EVALS += 1
-            st = int(ws.info[0].item())  # (a wait inside the list that ran out of its budget must not pass as a result)
+            # (a wait inside the list that ran out of its budget must not pass as a result — and must be EVERY rank's status: the
+            #  gradient's all-reduce follows, so a rank that raised alone would leave the others blocked in it.  MAX over the ranks,
+            #  as for the factor list; the caller then repeats the evaluation on the launch path, all ranks together.)
+            info = ws.info[0:1].clone()
+            comm.allreduce(info, dist.ReduceOp.MAX)
+            st = int(info.item())
             if st and os.environ.get("GPP_SHARD_DEBUG"):
-                print(f"[sharded rank {me}] back-substitution list: status {st:#x}", flush=True)
-            if st:
-                from .backend import check_status
-                check_status(st)
-            return
+                print(f"[sharded rank {me}] back-substitution list: status {st:#x} (mine {int(ws.info[0].item()):#x})", flush=True)
+            if st == 0:
+                global BACK_LIST_EVALS
+                BACK_LIST_EVALS += 1
+            return st
     oc0 = offs[me]
     main = torch.cuda.current_stream(ctx.index)
     aux = ctx.internal_streams()[2] if _SWEEP_LOOKAHEAD else main
@@ -667,6 +675,7 @@ def _backward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> None:
                     row_done = torch.cuda.Event()
                     row_done.record(main)
     main.wait_stream(aux)
+    return 0
 
 
 class ShardedMLLFunction(torch.autograd.Function):
@@ -686,8 +695,43 @@ class ShardedMLLFunction(torch.autograd.Function):
         ws = _workspace(gctx, N, nb, comm.rank, comm.world)
         ws.epoch += 1
         jitters = [0.0] + [settings.cholesky_jitter.value() * (10 ** i) for i in range(settings.cholesky_max_tries.value())]
-        used = None
         from .linalg import _stage
+        need_grad = any(ctx.needs_input_grad[:6])
+        for redo in (False, True):
+            swept, used = ShardedMLLFunction._factor_with_jitter(gctx, comm, ws, Ud, wd, sd, td, grp, kind, d_split, jitters)
+            if not swept:
+                with _stage("shard_inverse"):
+                    _forward(gctx, comm, ws)
+            torch.sub(f64(y), f64(mean), out=ws.r)
+            comm.stage = "vectors"
+            _vectors(gctx, comm, ws, need_alpha=need_grad)
+            st = 0
+            if need_grad:
+                with _stage("shard_backsolve"):
+                    st = _backward(gctx, comm, ws)
+            if st == 0:
+                break
+            # The back-substitution's ticket list timed out on some rank (the status is the MAX over the ranks, so every rank is
+            # here): its input is destroyed.  Every rank switches the executor off and the evaluation is repeated on the
+            # launch-per-product path — once; a second failure is reported on all ranks alike.
+            if redo or not panel_timed_out(gctx, st):
+                from .backend import check_status
+                check_status(st)
+                raise RuntimeError(f"sharded evaluation: back-substitution list status {st:#x}")
+            comm.stage = "factor"
+        ws.comm_calls = comm.calls  # (tests: the collectives really ran)
+        ctx.saved = (gctx, comm, ws, ws.epoch, Ud, wd, sd, grp, td.numel(), kind, d_split, dU)
+        ctx.in_dtypes = (U.dtype, w.dtype, sf2.dtype, tau.dtype, mean.dtype, y.dtype)
+        ctx.shapes = (sf2.shape, tau.shape)
+        return ws.out3[2].clone()
+
+    @staticmethod
+    def _factor_with_jitter(gctx, comm, ws, Ud, wd, sd, td, grp, kind, d_split, jitters):
+        """gpytorch's psd_safe_cholesky policy around the distributed factorisation (optim/mll_torch.py:116 reaches it through
+        ``log_prob``): returns (the list also swept the owned column blocks of L^-1, the jitter that succeeded)."""
+        from .linalg import _stage
+        used = None
+        swept = False
         attempts = list(jitters)
         timeouts = 0
         while attempts:
@@ -720,21 +764,7 @@ class ShardedMLLFunction(torch.autograd.Function):
             raise NotPSDError(f"Matrix not positive definite after repeatedly adding jitter up to {jitters[-1]:.1e}.")
         if used > 0:
             warnings.warn(f"A not p.d., added jitter of {used:.1e} to the diagonal", RuntimeWarning)
-        need_grad = any(ctx.needs_input_grad[:6])
-        if not swept:
-            with _stage("shard_inverse"):
-                _forward(gctx, comm, ws)
-        torch.sub(f64(y), f64(mean), out=ws.r)
-        comm.stage = "vectors"
-        _vectors(gctx, comm, ws, need_alpha=need_grad)
-        if need_grad:
-            with _stage("shard_backsolve"):
-                _backward(gctx, comm, ws)
-        ws.comm_calls = comm.calls  # (tests: the collectives really ran)
-        ctx.saved = (gctx, comm, ws, ws.epoch, Ud, wd, sd, grp, td.numel(), kind, d_split, dU)
-        ctx.in_dtypes = (U.dtype, w.dtype, sf2.dtype, tau.dtype, mean.dtype, y.dtype)
-        ctx.shapes = (sf2.shape, tau.shape)
-        return ws.out3[2].clone()
+        return swept, used
 
     @staticmethod
     def backward(ctx, grad_out):

@@ -110,8 +110,12 @@ def sharded_eval_c(U, w, sf2, tau, mean, y, grp=None, kind: int = 0, d_split: in
     S = td.numel()
     if grp is not None and grp.dtype != torch.int32:
         grp = grp.to(torch.int32)
-    key = (ctx.index, id(group), bool(rccl))
-    if key not in _state:  # the communicator of this handle: once
+    # The handle has ONE communicator slot (gpp_set_comm / gpp_comm_init_rccl overwrite it): the key names the group by its member
+    # ranks (``id(group)`` can be reused by a later group object) and ``_state["installed", device]`` says which key the handle
+    # currently carries — another group or backend re-installs before the call instead of running with the previous one's collectives.
+    members = tuple(range(world)) if group is None else tuple(dist.get_process_group_ranks(group))
+    key = (ctx.index, members, bool(rccl))
+    if _state.get(("installed", ctx.index)) != key:
         if rccl:
             uid = torch.zeros(128, dtype=torch.uint8)
             if rank == 0:
@@ -131,6 +135,7 @@ def sharded_eval_c(U, w, sf2, tau, mean, y, grp=None, kind: int = 0, d_split: in
             comm = _Comm(None, cb[0], cb[1])
             check(lib.gpp_set_comm(ctx.h, ctypes.byref(comm), rank, world), "gpp_set_comm")
             _state[key] = (cb, comm)  # (kept alive: the library calls them)
+        _state[("installed", ctx.index)] = key
     n = lambda which: int(lib.gpp_shard_buffer_doubles(N, nb, rank, world, which))  # noqa: E731
     ld = (N + 15) // 16 * 16
     nblk = -(-N // nb)
@@ -138,7 +143,7 @@ def sharded_eval_c(U, w, sf2, tau, mean, y, grp=None, kind: int = 0, d_split: in
     mk = lambda k: torch.empty(k, dtype=torch.float64, device=dev)  # noqa: E731
     bufs = _state.get(("bufs", key, N, nb))
     if bufs is None:
-        for k in [k for k in _state if k[0] == "bufs"]:
+        for k in [k for k in _state if k and k[0] == "bufs"]:
             del _state[k]
         bufs = dict(A=mk(n(0)), Kc=mk(n(1)), Lc=mk(n(1)), D=mk(n(2)), W0=mk(n(3)), W1=mk(n(3)), W2=mk(n(3)), msg=mk(n(4)),
                     z=mk(N), alpha=mk(N), r=mk(N), out3=mk(3), info=torch.zeros(2, dtype=torch.int32, device=dev))

@@ -24,8 +24,9 @@ def run_ranks(args, world=2, port=29531, **extra_env):
     return res[0]
 
 
-def config_values(name, nb, world, n=None, nograd=False, port=29977, timeout=1500, meta=None, **extra_env):
-    """Loss and gradients of a BASELINE config through GP_Plus: (single-GPU path, sharded over ``world`` ranks)."""
+def config_values(name, nb, world, n=None, nograd=False, port=29977, timeout=1500, meta=None, only=None, **extra_env):
+    """Loss and gradients of a BASELINE config through GP_Plus: (single-GPU path, sharded over ``world`` ranks); ``only="sharded"``
+    skips the single-GPU run (its slot is None) — for comparisons with a committed fixture instead."""
     import re
 
     worker = os.path.join(ROOT, "tests", "workers", "sharded_worker.py")
@@ -49,7 +50,7 @@ def config_values(name, nb, world, n=None, nograd=False, port=29977, timeout=150
             meta["status_lines"] = [l[:300] for l in p.stdout.splitlines() if l.startswith("[sharded rank")]
         return res[0]["values"]
 
-    single = values([sys.executable, worker, "config", name, "single", str(nb)] + extra)
+    single = None if only == "sharded" else values([sys.executable, worker, "config", name, "single", str(nb)] + extra)
     shard = values([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
                     "127.0.0.1", "--master-port", str(port), worker, "config", name, "sharded", str(nb)] + extra)
     return single, shard
