@@ -9,7 +9,8 @@ HIP back end.  Differences, by design:
   * restart points come from ``model.reset_parameters()`` (prior samples pushed through the parameters' own setting
     closures) — the reference concatenates prior samples in ``named_priors`` order and on the constrained scale for the
     outputscale (:130-137), which does not line up with its own packing order;
-  * parameters keep the model's dtype (the reference round-trips theta through fp32, :32-35,97; SURVEY.md B-4);
+  * parameters keep the model's dtype; the reference round-trips theta through fp32 (:32-35,97), which
+    ``settings.reference_fp32_theta(True)`` reproduces;
   * the interval-score term and the NN-weight regularisers (:44-59) belong to out-of-scope model variants.
 """
 from collections import OrderedDict
@@ -55,11 +56,20 @@ class MLLObjective:
     def unpack_parameters(self, x: np.ndarray) -> "OrderedDict[str, torch.Tensor]":
         i, named = 0, OrderedDict()
         params = self._params()
+        x = self._theta(x)
         for n, shape in self.param_shapes.items():
             ln = reduce(lambda a, b: a * b, shape)
             named[n] = torch.from_numpy(np.asarray(x[i:i + ln], dtype=np.float64).reshape(*shape)).to(params[n]).reshape(params[n].shape)
             i += ln
         return named
+
+    @staticmethod
+    def _theta(x: np.ndarray) -> np.ndarray:
+        """theta as the model will see it: float32-rounded under ``settings.reference_fp32_theta`` (optim/mll_scipy.py:32-35,97)."""
+        from .. import settings
+
+        x = np.asarray(x, dtype=np.float64)
+        return x.astype(np.float32).astype(np.float64) if settings.reference_fp32_theta.value() else x
 
     def pack_grads(self) -> np.ndarray:
         return np.concatenate([p.grad.detach().cpu().double().numpy().ravel() for p in self._params().values()]).astype(np.float64)
@@ -98,7 +108,7 @@ class MLLObjective:
     def fun(self, x: np.ndarray, return_grad=True) -> Union[float, Tuple[float, np.ndarray]]:
         g = self._graphed() if return_grad else None
         if g is not None:
-            res = g.evaluate(x)
+            res = g.evaluate(self._theta(x))
             if res is not None:
                 return res
             # the factorisation failed without jitter (or the objective is not finite): this point goes the eager way

@@ -38,6 +38,14 @@ batched_restarts = _Value(True)
 graphed_objective = _Value(True)
 
 
+# The reference's scipy driver casts every slice of theta to float32 before loading it into the model (optim/mll_scipy.py:32-35
+# ``tkwargs``, :97 ``torch.from_numpy(param).to(**tkwargs)``), whatever the model's dtype: an fp64 model's L-BFGS trajectory is
+# evaluated at fp32-rounded points.  Off by default (this build keeps the model's dtype);
+# ``with settings.reference_fp32_theta(True):`` reproduces the reference's round trip in ``MLLObjective`` — objective, gradient
+# and the final ``load_state_dict`` then see float32(theta) — so that a trajectory can be compared with the reference's.
+reference_fp32_theta = _Value(False)
+
+
 # Sharded single evaluation (gp-plus_amd/sharded.py): ``with settings.sharded_evaluation({"group": None, "nb": 1024}):``
 # makes every exact-GP log-likelihood inside the block a cooperative evaluation by all ranks of the process group
 # (None = the default group).  Every rank must run the same model code with the same parameters.

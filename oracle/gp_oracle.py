@@ -654,3 +654,156 @@ def oracle_sobol(oracle: "OracleGP", sequence, levels_per_cat: Sequence[int]):
         ST[i] = ((FA - Fi) ** 2).sum(0) / (2 * N)
     varY = torch.var(torch.cat([FA, FB]), dim=0, unbiased=False)  # np.var
     return (S / varY).T.numpy(), (ST / varY).T.numpy()
+
+
+# ---------------------------------------------------------------------------------------------------
+# scipy multistart driver and noise continuation, restated on the oracle
+# ---------------------------------------------------------------------------------------------------
+def _pack(o: "OracleGP", names: Sequence[str]):
+    """optim/mll_scipy.py:77-82 pack_parameters: the trainable raw parameters as one float64 vector."""
+    import numpy as np
+
+    return np.concatenate([o.params[k].detach().numpy().astype(np.float64).ravel() for k in names])
+
+
+def _unpack(o: "OracleGP", names: Sequence[str], x, fp32_theta: bool = False) -> None:
+    """optim/mll_scipy.py:84-98 unpack_parameters + :103-106 load_state_dict.  ``fp32_theta``: the reference casts every
+    slice of theta to ``tkwargs`` = float32 before loading it (:32-35, :97), whatever the model's own dtype."""
+    import numpy as np
+
+    i = 0
+    for k in names:
+        n = o.params[k].numel()
+        v = torch.from_numpy(np.asarray(x[i:i + n], dtype=np.float64).copy())
+        if fp32_theta:
+            v = v.to(torch.float32)
+        o.params[k] = v.to(DT).reshape(o.params[k].shape)
+        i += n
+
+
+def oracle_fit_scipy(o: "OracleGP", add_prior: bool = True, num_restarts: int = 1, theta0_list=None, options: Optional[dict] = None,
+                     generator: Optional[torch.Generator] = None, fp32_theta: bool = False):
+    """``fit_model_scipy`` (optim/mll_scipy.py:243-307) with method 'L-BFGS-B' on the oracle: objective
+    ``-(log_prob + sum of prior log-densities)``, NOT divided by N (:37-43, :120), over the trainable raw parameters; defaults
+    ftol 1e-6 / gtol 1e-5 / maxfun 5000 / maxiter 2000 (:262); a start that raises NotPSDError / NanError is kept as the exception
+    and scored inf (:232-236, :295); the best start's theta is loaded (:296-301).  Start points when ``theta0_list`` is None
+    (:277-281): ``num_restarts + 1`` prior draws.  The reference concatenates ``prior.sample()`` in named_priors order and on the
+    constrained scale (:130-137), which does not line up with its own packing; the build under test draws them with
+    ``reset_parameters`` (models/gpregression.py:168-174) instead — a documented deviation — and so does this restatement, so that
+    both drivers start from the same points.  Returns (list of OptimizeResult / exceptions, best objective)."""
+    import numpy as np
+    from scipy.optimize import minimize
+
+    defaults = {'ftol': 1e-6, 'gtol': 1e-5, 'maxfun': 5000, 'maxiter': 2000}
+    for key, val in (options or {}).items():
+        if key not in defaults:
+            raise RuntimeError('Unknown option %s!' % key)
+        defaults[key] = val
+    names = list(o.trainable)
+
+    def fun(x):  # MLLObjective.fun, :101-127
+        _unpack(o, names, x, fp32_theta)
+        p = {k: v.clone().requires_grad_(k in names) for k, v in o.params.items()}
+        val = o.mll(p)
+        if add_prior:
+            val = val + o.log_priors(p)
+        obj = -val
+        grads = torch.autograd.grad(obj, [p[k] for k in names])
+        return obj.item(), np.concatenate([g.numpy().ravel() for g in grads]).astype(np.float64)
+
+    if theta0_list is None:
+        theta0_list = [_pack(o, names)]
+        if num_restarts > -1:
+            saved = {k: v.clone() for k, v in o.params.items()}
+            samples = []
+            for _ in range(num_restarts + 1):
+                o.reset_parameters(generator)
+                samples.append(_pack(o, names))
+            o.params = saved
+            theta0_list.extend(samples)
+            theta0_list.pop(0)
+    out = []
+    for theta0 in theta0_list:
+        try:
+            out.append(minimize(fun=fun, x0=theta0, jac=True, method='L-BFGS-B', options=dict(defaults)))
+        except (NotPSDError, NanError) as e:
+            out.append(e)
+    nlls = [np.inf if isinstance(r, Exception) or not np.isfinite(r.fun) else r.fun for r in out]
+    best = int(np.argmin(nlls))
+    if not isinstance(out[best], Exception) and np.isfinite(nlls[best]):
+        _unpack(o, names, out[best].x, fp32_theta)
+    return out, nlls[best]
+
+
+def oracle_continuation(o: "OracleGP", add_prior: bool = True, num_restarts: int = 32, initial_noise_var: float = 1.0,
+                        red_factor: float = math.sqrt(10), options: Optional[dict] = None, accuracy: float = 1e-2,
+                        generator: Optional[torch.Generator] = None):
+    """``fit_model_continuation`` (optim/mll_noise_continuation.py:45-244, criterion 'NLL') on the oracle.  The noise variance is
+    FIXED (raw_noise frozen, :127-128) at each of a sequence of levels — first pass: initial / 10^i, i = 0..9 (:143-144); later
+    passes: ten levels between the neighbours of the best one (:148-155) — and ``oracle_fit_scipy`` runs at each; the distinct
+    optima of a level (Euclidean distance >= 1e-2 * dim, :199-207) start the next; a level at which every start fails ends the pass
+    (:178-180); a pass ends the search when its best level is within ``accuracy`` of the pass's first level (:238-240) or lies at
+    an end of the list (:156-160).  ``likelihood.initialize(noise=v)`` is raw = log(v - lb) ([3P] GreaterThan(lb, exp).inverse_transform,
+    models/gpregression.py:59).  Returns (nll at the selected level, {'noise_history', 'nll_history'}) of the last pass and leaves
+    ``o.params`` at the selected state."""
+    import numpy as np
+    from scipy.spatial import distance_matrix
+
+    nk = "likelihood.noise_covar.raw_noise"
+    o.trainable = [k for k in o.trainable if k != nk]
+    o.fix_noise = True  # (reset_parameters then skips the noise draw without consuming random numbers: gpregression.py:172-173)
+
+    def set_noise(v):
+        o.params[nk] = torch.log(torch.full_like(o.params[nk], float(v)) - o.lb_noise)
+
+    def noise_now():
+        return float(noise_transform(o.params[nk], o.lb_noise).reshape(-1)[0])
+
+    t = 0
+    theta0_list = None
+    index, history, old_state = None, None, {}
+    names = None
+    while True:
+        t += 1
+        first = initial_noise_var
+        if t == 1:
+            noises = [first / (10 ** i) for i in range(int(10 / t))]
+        else:
+            n_hist = len(history['noise_history'])
+            if (index >= 2 and index < n_hist - 2) or (index >= 1 and index < n_hist - 1):
+                noises = np.linspace(history['noise_history'][index - 1], history['noise_history'][index + 1], 10)
+                initial_noise_var = history['noise_history'][index - 1]
+                o.params = {k: v.clone() for k, v in old_state[index - 1].items()}
+            else:
+                o.params = {k: v.clone() for k, v in old_state[index].items()}
+                return history['nll_history'][index], history
+        noise_list, nll_list = [], []
+        t += 1
+        old_state = {}
+        for i in range(len(noises)):
+            set_noise(noises[i])
+            old_state[i] = {k: v.clone() for k, v in o.params.items()}
+            reslist, nll = oracle_fit_scipy(o, add_prior, num_restarts=num_restarts, theta0_list=theta0_list, options=options,
+                                            generator=generator)
+            if all(isinstance(r, (RuntimeError, TypeError)) for r in reslist):
+                break
+            noise_list.append(noise_now())
+            nll_list.append(nll)
+            theta0_list = []
+            for r in reslist:
+                if isinstance(r, Exception):
+                    continue
+                if len(theta0_list) > 0:
+                    d = distance_matrix(r.x.reshape(1, -1), np.vstack(theta0_list)).ravel()
+                    if np.any(d < 1e-2 * r.x.shape[0]):
+                        continue
+                theta0_list.append(r.x)
+            set_noise(noise_list[-1] / red_factor)  # (:209-216; overwritten by the next level's set_noise)
+        if not nll_list:
+            raise RuntimeError('oracle_continuation: every start failed at the first noise level')
+        history = {'noise_history': noise_list, 'nll_history': nll_list}
+        index = int(np.argmin(nll_list))
+        if abs(first - noise_list[index]) < accuracy:
+            o.params = {k: v.clone() for k, v in old_state[index].items()}
+            break
+    return history['nll_history'][index], history

@@ -37,6 +37,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 from gpplus_amd import sharded  # noqa: E402
 from gpplus_amd.backend import UPLO_FULL, UPLO_UPPER, get_context, square_buffer  # noqa: E402
 
@@ -98,6 +99,7 @@ class Replay:
         self.sink = torch.empty_like(self.ws0.pack)
         self.stamps = torch.zeros((self.nblk, 2, 4), dtype=torch.int64, device=dev)  # [block][head / tail][own ready, start, end, -]
         self.epoch = torch.zeros(2, dtype=torch.int64, device=dev)
+        self.after_list = None
 
     # ---- the single-GPU result: what the other ranks would send, and what this rank's results are compared with ----------------------
     def _reference(self, keep_kinv):
@@ -190,6 +192,7 @@ class Replay:
                         self._rcopy(cs, dblk, self.Liref[o:o1, o:o1], rate, -1, slot(k, False, 1))
                         A[o:o1, o:o2].copy_(head)
                         Lkk.copy_(dblk)
+                        self._stamp(cs, slot(k, False, 3))
                         ctx.shard_list_signal(cs, False, k)
                     if N > o2:
                         tail = ws.pack[:nbk * (N - o2)].view(nbk, N - o2)
@@ -201,6 +204,7 @@ class Replay:
                         else:
                             self._rcopy(cs, tail, self.Aref[o:o1, o2:N], rate, ready_t[k] / TICK_US, slot(k, True, 1))
                             A[o:o1, o2:N].copy_(tail)
+                            self._stamp(cs, slot(k, True, 3))
                             ctx.shard_list_signal(cs, True, k)
                     if not own:
                         arrived[k] = torch.cuda.Event()
@@ -216,6 +220,8 @@ class Replay:
                     A[o1:N, o:o1].copy_(A[o:o1, o1:N].t())
         finally:
             ctx.shard_list_end()
+        if self.after_list is not None:  # (--trace-rank: the factor + forward list is the handle's most recent plan exactly here)
+            self.after_list()
         for s in (cs, cpy):
             main.wait_stream(s)
         for c in range(r, nblk, P):
@@ -244,8 +250,41 @@ class Replay:
         out.update(status_back=int(st_back), build_ms=ev[0].elapsed_time(ev[1]), ff_ms=ev[1].elapsed_time(ev[2]),
                    vec_ms=ev[2].elapsed_time(ev[3]), back_ms=ev[3].elapsed_time(ev[4]), grad_ms=ev[4].elapsed_time(ev[5]),
                    ready_h={k: st[k, 0, 0] for k in own}, ready_t={k: st[k, 1, 0] for k in own if st[k, 1, 0] > 0},
-                   msg_start_h=st[:, 0, 1].tolist(), msg_end_h=st[:, 0, 2].tolist(), msg_end_t=st[:, 1, 2].tolist())
+                   msg_start_h=st[:, 0, 1].tolist(), msg_end_h=st[:, 0, 2].tolist(), msg_end_t=st[:, 1, 2].tolist(),
+                   unpacked_h=st[:, 0, 3].tolist(), unpacked_t=st[:, 1, 3].tolist())
+        # the chain as this rank sees it: from the unpacked head of block k - 1 (another rank's) to its own head of block k being
+        # ready to send — diagonal update, gate, panel, head solve, copies, gate (DESIGN.md section 7 assumed ~1.2 ms)
+        out["chain_us"] = {k: st[k, 0, 0] - st[k - 1, 0, 3] for k in own if k > 0 and (k - 1) % P != r and st[k - 1, 0, 3] > 0}
+        out["tail_lag_us"] = {k: st[k, 1, 0] - st[k, 0, 0] for k in own if st[k, 1, 0] > 0}  # own tail ready after own head ready
         return out
+
+    def trace(self, r, rate, rh, rt):
+        """Per-task trace of rank r's factor + forward list (tools/dag_check.py's report) in the converged timeline."""
+        from dag_check import trace_report
+
+        def on():
+            torch.cuda.synchronize()
+            assert self.lib.gpp_debug_dag_trace(self.ctx.h, 1) == 0
+
+        def report():
+            torch.cuda.synchronize()
+            trace_report(self.ctx, self.N)
+            self.lib.gpp_debug_dag_trace(self.ctx.h, 0)
+
+        self.after_list = on
+        self.run(r, rate, rh, rt)
+        self.after_list = report
+        o = self.run(r, rate, rh, rt)
+        self.after_list = None
+        print(f"  rank {r}'s communication stream, ms since its list started (own rows: 'ready' = the gate passed; others: when the replay could start):")
+        print("    block owner | head: ready/start   sent/received   unpacked | tail: ready/start   sent/received   unpacked")
+        for k in range(self.nblk):
+            own = k % self.P == r
+            hs = o["ready_h"].get(k, 0.0) if own else o["msg_start_h"][k]
+            ts = o["ready_t"].get(k, 0.0) if own else max(rt[k], o["msg_end_h"][k])
+            print(f"    {k:5d} {k % self.P:5d}{'*' if own else ' '}|       {hs / 1e3:10.3f}      {o['msg_end_h'][k] / 1e3:10.3f} {o['unpacked_h'][k] / 1e3:10.3f} |"
+                  f"       {ts / 1e3:10.3f}      {o['msg_end_t'][k] / 1e3:10.3f} {o['unpacked_t'][k] / 1e3:10.3f}")
+        return o
 
     # ---- comparisons with the single-GPU result (--check, tests/test_gpu_replay.py) ----------------------------------------------------
     def _rel(self, a, b):
@@ -322,6 +361,14 @@ def summarise(rp, rate, res, hist):
     print(f"  rate {('unthrottled' if rate <= 0 else f'{rate:g} GB/s'):>12s}   rank   build      ff  z/alpha    back    grad    total | last message at   status")
     for r, b, f, v, bk, g, last, s1, s2 in rows:
         print(f"  {'':17s}{r:6d} {b:7.2f} {f:7.2f} {v:8.2f} {bk:7.2f} {g:7.2f} {b + f + v + bk + g:8.2f} | {last:10.2f} ms    {s1:#x} {s2:#x}")
+    chain = [v for o in res.values() for v in o.get("chain_us", {}).values()]
+    lag = [v for o in res.values() for v in o.get("tail_lag_us", {}).values()]
+    unp = [o["unpacked_t"][k] - o["msg_end_t"][k] for o in res.values() for k in range(rp.nblk) if o["unpacked_t"][k] > 0]
+    if chain:
+        print(f"  {'':17s}   chain per step (head k-1 unpacked -> own head k ready to send): mean {np.mean(chain) / 1e3:.3f} ms, "
+              f"p10 {np.percentile(chain, 10) / 1e3:.3f}, p90 {np.percentile(chain, 90) / 1e3:.3f}, max {np.max(chain) / 1e3:.3f}; "
+              f"own tail ready {np.mean(lag) / 1e3:.3f} ms after own head (max {np.max(lag) / 1e3:.3f}); "
+              f"unpacking a tail {np.mean(unp) / 1e3:.3f} ms (max {np.max(unp) / 1e3:.3f})")
     ff, back = max(x[2] for x in rows), max(x[4] for x in rows)
     small = max(x[1] + x[3] + x[5] for x in rows)
     total = ff + back + small  # the ranks meet at the all-reduces of z / alpha and of the gradient
@@ -330,6 +377,8 @@ def summarise(rp, rate, res, hist):
           f"{n3 / total / 1e9 / P:5.1f} TFLOP/s per GPU; sweeps {len(hist)}, last move {hist[-1][0] / 1e3:.3f} ms", flush=True)
     return {"rate_gbs": rate, "ff_ms": ff, "back_ms": back, "small_ms": small, "total_ms": total, "evals_per_s": 1e3 / total,
             "sweeps": len(hist), "last_move_ms": hist[-1][0] / 1e3,
+            "chain_ms": None if not chain else {"mean": float(np.mean(chain)) / 1e3, "p90": float(np.percentile(chain, 90)) / 1e3,
+                                                "max": float(np.max(chain)) / 1e3},
             "ranks": [{"rank": r, "build_ms": b, "ff_ms": f, "vec_ms": v, "back_ms": bk, "grad_ms": g, "last_message_ms": last,
                        "status": [s1, s2]} for r, b, f, v, bk, g, last, s1, s2 in rows]}
 
@@ -348,6 +397,7 @@ def main():
     ap.add_argument("--threads", type=int, default=512)
     ap.add_argument("--check", action="store_true", help="compare the rank's block rows / column blocks with the single-GPU result")
     ap.add_argument("--json", default=None)
+    ap.add_argument("--trace-rank", type=int, default=None, help="per-task trace of this rank's factor + forward list at the last rate")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     n = args.n or {"C2": 20000, "C5": 60000}[args.config]
@@ -358,11 +408,15 @@ def main():
     print(f"  single-GPU factor + inverse (the reference the other ranks' block rows are taken from): {rp.ref_factor_inverse_ms:.1f} ms; "
           f"GPP_SHARD_FILL = {os.environ.get('GPP_SHARD_FILL', 'default (one filler work-group per panel CU)')}", flush=True)
     out = {"N": n, "d": int(U.shape[1]), "P": args.P, "nb": args.nb, "library": rp.ctx.lib.gpp_version().decode(), "rates": []}
+    t0 = time.perf_counter()
+    zero = ({k: 0.0 for k in range(rp.nblk)}, {k: 0.0 for k in range(rp.nblk)})
+    for r_ in ranks:  # (the host plans each rank's two lists on their first use — seconds at N = 60 000 — with the device idle)
+        rp.run(r_, 0.0, *zero)
+    print(f"  warm-up pass over {len(ranks)} rank(s) (plans, allocations): {time.perf_counter() - t0:.1f} s", flush=True)
     ready = None
     for rate in [float(x) for x in args.rates.split(",")]:
         rp.wgs = max(args.wgs, 32) if (rate <= 0 or rate >= 300) else args.wgs
         if rate <= 0:  # the work bound: every block row of another rank is there when the list starts asking for it
-            zero = ({k: 0.0 for k in range(rp.nblk)}, {k: 0.0 for k in range(rp.nblk)})
             res, _, hist = rp.converge(rate, ranks, 1, check=args.check, ready=zero)
         else:
             res, ready, hist = rp.converge(rate, ranks, args.sweeps, check=args.check, ready=ready)
@@ -372,6 +426,9 @@ def main():
             print(f"  {'':17s}   vs the single-GPU result: factor {errs['err_factor']:.2e}, L^-1 {errs['err_linv']:.2e}, Ky^-1 {errs['err_kinv']:.2e}")
             rec["errors"] = errs
         out["rates"].append(rec)
+        if args.trace_rank is not None and rate > 0:
+            print(f"  trace of rank {args.trace_rank}'s factor + forward list at {rate:g} GB/s:")
+            rp.trace(args.trace_rank, rate, *ready)
     if args.json:
         with open(args.json, "w") as fh:
             json.dump(out, fh, indent=1)
