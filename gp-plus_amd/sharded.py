@@ -423,8 +423,20 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
 
 #: GPP_SHARD_LIST=0: the launch-per-product factorisation and forward sweep of rounds 2-4 (also the library's own knob)
 _USE_LIST = os.environ.get("GPP_SHARD_LIST", "1") not in ("", "0")
-#: the factor's mirror beside the list on the copy stream (default) or behind it (GPP_SHARD_MIRROR_BESIDE=0)
-_MIRROR_BESIDE = os.environ.get("GPP_SHARD_MIRROR_BESIDE", "1") not in ("", "0")
+#: the factor's mirror beside the list on the copy stream or behind it (GPP_SHARD_MIRROR_BESIDE=1 / 0; default: see _mirror_beside)
+_MIRROR_ENV = os.environ.get("GPP_SHARD_MIRROR_BESIDE", "")
+
+
+def _mirror_beside(world: int) -> bool:
+    """Where the factor's mirror L = U^T is written.  ONE rank: beside the list on the copy stream (same-box A/B in round 5: -1 ms
+    at C2, -10 ms at C5 — its list keeps every CU busy and the strided copies hide behind it).  SEVERAL ranks: behind the list, as
+    the library's LDS-tiled transposition on every CU.  Measured with tools/replay_rank.py (round 6, profiles/r06_virtual_rank.txt):
+    a rank of a P = 8 run is bound by the chain of panels and messages, which lives on the 32 panel CUs — the executor's
+    work-groups fill the other 224 to the last register whether they compute or wait — and the copy stream's strided
+    transpositions (up to 150 MB each) landed on those same 32 CUs between the packing copies, the gates and the panel."""
+    if _MIRROR_ENV != "":
+        return _MIRROR_ENV != "0"
+    return world <= 1
 #: evaluations whose factorisation + forward sweep ran as a ticket list (tests)
 LIST_EVALS = 0
 BACK_LIST_EVALS = 0
@@ -494,7 +506,7 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
         # back-substitution reads row-contiguously — block row k as soon as it is in place (an owned one: behind the gates the packing
         # uses; another rank's: behind its unpacking).  Nothing in the list reads or writes the strict lower triangle.
         with torch.cuda.stream(cpy):
-            for k in range(nblk - 1 if _MIRROR_BESIDE else 0):
+            for k in range(nblk - 1 if _mirror_beside(P) else 0):
                 o, o1 = offs[k], offs[k + 1]
                 if k % P == me:
                     ctx.shard_list_gate(cpy, False, k)
@@ -506,7 +518,7 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
         ctx.shard_list_end()
     main.wait_stream(cs)
     main.wait_stream(cpy)
-    if not _MIRROR_BESIDE:  # (experiment knob: the mirror behind the list, as the library's transposition launches)
+    if not _mirror_beside(P):  # (several ranks: the mirror behind the list, as the library's transposition launches)
         for k in range(nblk - 1):
             ctx.transpose(A[offs[k]:offs[k + 1], offs[k + 1]:N], A[offs[k + 1]:N, offs[k]:offs[k + 1]])
     # what the list leaves to the launches behind it: the owned diagonal blocks of L^-1 (lower triangles of D) into Kc

@@ -417,6 +417,64 @@ def test_loocv_and_noise_continuation(gpu_ctx):
     assert np.isfinite(f_now)
 
 
+def test_noise_continuation_follows_the_oracle_driver(gpu_ctx):
+    """f3 against a restatement, not structurally: ``fit_model_continuation`` on the HIP back end and
+    ``oracle_continuation`` (optim/mll_noise_continuation.py:45-244 on the oracle's scipy objective) from the same seed — the same
+    start points (a12), the same fixed noise levels, and NLLs that agree level by level."""
+    from oracle.gp_oracle import OracleGP, oracle_continuation
+    from gpplus_amd.models import GP_Plus
+    from gpplus_amd.optim import fit_model_continuation
+
+    rng = np.random.default_rng(21)
+    n = 96
+    X = rng.standard_normal((n, 3))
+    y = np.sin(1.5 * X[:, 0]) + 0.3 * X[:, 1] ** 2 + 0.05 * rng.standard_normal(n)
+    m = GP_Plus(torch.tensor(X), torch.tensor(y), dtype=torch.float64, device="cuda")
+    m.train()
+    torch.manual_seed(6)
+    nll, hist = fit_model_continuation(m, num_restarts=1, initial_noise_var=1.0, verbose=False)
+    o = OracleGP(X, y)
+    torch.manual_seed(6)
+    nll_o, hist_o = oracle_continuation(o, num_restarts=1, initial_noise_var=1.0)
+    lv = [float(v.reshape(-1)[0]) for v in hist["noise_history"]]
+    np.testing.assert_allclose(lv, hist_o["noise_history"], rtol=1e-10)
+    # (two L-BFGS-B runs on objectives that agree to ~1e-11 stop within their own tolerance of each other: ftol = 1e-6 relative)
+    np.testing.assert_allclose(hist["nll_history"], hist_o["nll_history"], rtol=2e-5)
+    assert abs(nll - nll_o) <= 2e-5 * abs(nll_o)
+    # the model is left at the selected level's noise (:239); the other parameters are optimiser outputs, equal to its tolerance only
+    k = "likelihood.noise_covar.raw_noise"
+    np.testing.assert_allclose(m.state_dict()[k].detach().cpu().double().reshape(-1).numpy(), o.params[k].reshape(-1).numpy(), rtol=1e-10)
+
+
+def test_scipy_objective_with_the_references_fp32_theta(gpu_ctx):
+    """``settings.reference_fp32_theta(True)`` (optim/mll_scipy.py:32-35,97): the objective at theta equals the default mode's
+    objective at float32(theta) bit for bit — eager and replayed — and the oracle's fp32 mode agrees."""
+    from oracle.gp_oracle import OracleGP, _pack, _unpack
+    from gpplus_amd import settings
+    from gpplus_amd.optim import MLLObjective
+
+    fx = load("c1_borehole_n500.npz")
+    m = build(fx, "theta1")
+    m.train()
+    x = MLLObjective(m, True, [0, 0]).pack_parameters() + 1e-9
+    x32 = x.astype(np.float32).astype(np.float64)
+    for graphed in (False, True):
+        with settings.graphed_objective(graphed):
+            f_ref, g_ref = MLLObjective(m, True, [0, 0]).fun(x32)
+            with settings.reference_fp32_theta(True):
+                f, g = MLLObjective(m, True, [0, 0]).fun(x)
+            assert f == f_ref and np.array_equal(g, g_ref), (graphed, f, f_ref)
+            f64, _ = MLLObjective(m, True, [0, 0]).fun(x)
+            assert f64 != f_ref  # (1e-9 off a float32 grid point is visible in fp64)
+    o = OracleGP(fx["Xtrain"], fx["ytrain"])
+    names = [n for n in MLLObjective(m, True, [0, 0]).param_shapes]
+    assert sorted(names) == sorted(o.trainable)
+    _unpack(o, names, x, fp32_theta=True)
+    lo = o.loss(normalize=False).item()
+    assert abs(f - lo) <= RTOL_MLL * abs(lo)
+    np.testing.assert_array_equal(_pack(o, names), x32)
+
+
 def test_bayesian_optimisation_consumers(gpu_ctx):
     """acquisition functions and the cost-aware multi-fidelity BO loop (bayesian_optimizations/*) on the
     HIP-backed model: one iteration of the continuous branch and one of the pool branch, plus EI against its closed form."""

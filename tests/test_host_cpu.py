@@ -465,3 +465,21 @@ def test_shard_eval_buffer_sizes_and_argument_checks():
     assert lib.gpp_set_comm(None, None, 0, 1) == -1 and lib.gpp_comm_init_rccl(None, None, 0, 1) == -1
     info = ctypes.c_int(0)
     assert lib.gpp_shard_eval(None, N, nb, None, 8, None, None, None, None, 1, 0, 0, 0.0, 0, 1, None, ctypes.byref(info)) == -1
+
+
+def test_reference_fp32_theta_round_trip_is_a_switch():
+    """optim/mll_scipy.py:32-35,97: the reference loads float32(theta) into the model whatever its dtype.  Default here: theta keeps
+    the model's dtype; ``settings.reference_fp32_theta(True)`` reproduces the round trip — the two modes differ by that rounding only."""
+    from gpplus_amd import settings
+    from gpplus_amd.optim import MLLObjective
+
+    _, m = _mixed_model()
+    obj = MLLObjective(m, True, [0, 0])
+    x = obj.pack_parameters() + 1e-9
+    assert not np.array_equal(x, x.astype(np.float32).astype(np.float64))
+    flat = lambda d: np.concatenate([v.detach().double().numpy().ravel() for v in d.values()])  # noqa: E731
+    np.testing.assert_array_equal(flat(obj.unpack_parameters(x)), x)
+    with settings.reference_fp32_theta(True):
+        np.testing.assert_array_equal(flat(obj.unpack_parameters(x)), x.astype(np.float32).astype(np.float64))
+        assert all(v.dtype == torch.float64 for v in obj.unpack_parameters(x).values())  # (cast back to the model's dtype on load)
+    np.testing.assert_array_equal(flat(obj.unpack_parameters(x)), x)

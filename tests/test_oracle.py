@@ -274,3 +274,56 @@ def test_oracle_bo_consumers_against_closed_forms():
     gen.fast_forward(1)
     S, ST = G.oracle_sobol(o, gen.random(1024), [2])
     assert S.shape == (1, 2) and ST.shape == (1, 2) and (ST > 0).all() and (ST[0] >= S[0] - 0.05).all()
+
+
+def _small_oracle(n=48, seed=7):
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((n, 3))
+    y = np.sin(1.5 * X[:, 0]) + 0.3 * X[:, 1] ** 2 + 0.05 * rng.standard_normal(n)
+    return G.OracleGP(X, y)
+
+
+def test_oracle_scipy_driver_and_fp32_round_trip():
+    """``oracle_fit_scipy`` (optim/mll_scipy.py:243-307): the L-BFGS-B multistart lowers the un-normalised objective from every
+    start, loads the best start, and — ``fp32_theta`` (optim/mll_scipy.py:32-35,97) — evaluates at float32-rounded points: the two
+    modes differ by that rounding and by nothing else."""
+    o = _small_oracle()
+    f0 = o.loss(normalize=False).item()
+    torch.manual_seed(4)
+    res, best = G.oracle_fit_scipy(o, num_restarts=1, options={"maxiter": 40})
+    assert len(res) == 2 and best == min(r.fun for r in res) and best < f0
+    assert abs(o.loss(normalize=False).item() - best) <= 1e-10 * abs(best)  # the best start's theta is loaded
+    # a start is an L-BFGS-B run from a prior draw: the same seed gives the same starts
+    o2 = _small_oracle()
+    torch.manual_seed(4)
+    res2, best2 = G.oracle_fit_scipy(o2, num_restarts=1, options={"maxiter": 40})
+    assert best2 == best and all(np.array_equal(a.x, b.x) for a, b in zip(res, res2))
+    # fp32 mode: theta is loaded as float32(theta)
+    names = list(o.trainable)
+    x = G._pack(o, names) + 1e-9  # not representable in float32
+    G._unpack(o, names, x, fp32_theta=True)
+    np.testing.assert_array_equal(G._pack(o, names), x.astype(np.float32).astype(np.float64))
+    f32 = o.loss(normalize=False).item()
+    G._unpack(o, names, x.astype(np.float32).astype(np.float64), fp32_theta=False)
+    assert o.loss(normalize=False).item() == f32
+    G._unpack(o, names, x, fp32_theta=False)
+    np.testing.assert_array_equal(G._pack(o, names), x)
+
+
+def test_oracle_noise_continuation_follows_the_reference_schedule():
+    """``oracle_continuation`` (optim/mll_noise_continuation.py:45-244): first pass over initial / 10^i with the noise FIXED at each
+    level (raw_noise = log(v - lb), never trained), the level below the bound ends the pass (every start fails on a NaN covariance,
+    :178-180), refinement passes between the neighbours of the best level, the selected level's NLL returned."""
+    o = _small_oracle(n=40)
+    torch.manual_seed(2)
+    nll, hist = G.oracle_continuation(o, num_restarts=0, options={"maxiter": 30}, initial_noise_var=1.0)
+    lv = hist["noise_history"]
+    assert "likelihood.noise_covar.raw_noise" not in o.trainable and o.fix_noise
+    assert len(lv) == len(hist["nll_history"]) >= 2 and nll == min(hist["nll_history"])
+    assert all(np.isfinite(v) for v in hist["nll_history"])
+    # the levels of a pass are monotone (decreasing powers of ten, or an increasing linspace between two of them) and above the bound
+    d = np.diff(lv)
+    assert (np.all(d < 0) or np.all(d > 0)) and min(lv) >= o.lb_noise
+    # the model is left at a state whose noise is the selected level's
+    sel = lv[int(np.argmin(hist["nll_history"]))]
+    assert abs(float(G.noise_transform(o.params["likelihood.noise_covar.raw_noise"], o.lb_noise)[0]) - sel) <= 1e-12 * sel

@@ -210,7 +210,7 @@ class Replay:
                         arrived[k] = torch.cuda.Event()
                         arrived[k].record(cs)
             with torch.cuda.stream(cpy):  # the factor's mirror beside the list, as sharded.py writes it
-                for k in range(nblk - 1):
+                for k in range(nblk - 1 if sharded._mirror_beside(P) else 0):
                     o, o1 = offs[k], offs[k + 1]
                     if k % P == r:
                         ctx.shard_list_gate(cpy, False, k)
@@ -224,6 +224,9 @@ class Replay:
             self.after_list()
         for s in (cs, cpy):
             main.wait_stream(s)
+        if not sharded._mirror_beside(P):  # (the mirror behind the list, as the library's transposition launches on every CU)
+            for k in range(nblk - 1):
+                ctx.transpose(A[offs[k]:offs[k + 1], offs[k + 1]:N], A[offs[k + 1]:N, offs[k]:offs[k + 1]])
         for c in range(r, nblk, P):
             blk = ws.Kc[offs[c]:offs[c + 1], ws.col(c)]
             blk.copy_(ws.dblk(c))
@@ -406,7 +409,8 @@ def main():
     ranks = [int(x) for x in args.ranks.split(",")] if args.ranks else list(range(args.P))
     print(f"virtual-rank replay: N = {n}, d = {U.shape[1]}, P = {args.P}, nb = {args.nb}, {rp.nblk} block rows; library {rp.ctx.lib.gpp_version().decode()}")
     print(f"  single-GPU factor + inverse (the reference the other ranks' block rows are taken from): {rp.ref_factor_inverse_ms:.1f} ms; "
-          f"GPP_SHARD_FILL = {os.environ.get('GPP_SHARD_FILL', 'default (one filler work-group per panel CU)')}", flush=True)
+          f"GPP_SHARD_FILL = {os.environ.get('GPP_SHARD_FILL', 'default (one filler work-group per panel CU)')}; the factor's mirror "
+          f"{'beside' if sharded._mirror_beside(args.P) else 'behind'} the list", flush=True)
     out = {"N": n, "d": int(U.shape[1]), "P": args.P, "nb": args.nb, "library": rp.ctx.lib.gpp_version().decode(), "rates": []}
     t0 = time.perf_counter()
     zero = ({k: 0.0 for k in range(rp.nblk)}, {k: 0.0 for k in range(rp.nblk)})
@@ -414,7 +418,8 @@ def main():
         rp.run(r_, 0.0, *zero)
     print(f"  warm-up pass over {len(ranks)} rank(s) (plans, allocations): {time.perf_counter() - t0:.1f} s", flush=True)
     ready = None
-    for rate in [float(x) for x in args.rates.split(",")]:
+    rates = [float(x) for x in args.rates.split(",")]
+    for rate in rates:
         rp.wgs = max(args.wgs, 32) if (rate <= 0 or rate >= 300) else args.wgs
         if rate <= 0:  # the work bound: every block row of another rank is there when the list starts asking for it
             res, _, hist = rp.converge(rate, ranks, 1, check=args.check, ready=zero)
@@ -426,7 +431,7 @@ def main():
             print(f"  {'':17s}   vs the single-GPU result: factor {errs['err_factor']:.2e}, L^-1 {errs['err_linv']:.2e}, Ky^-1 {errs['err_kinv']:.2e}")
             rec["errors"] = errs
         out["rates"].append(rec)
-        if args.trace_rank is not None and rate > 0:
+        if args.trace_rank is not None and rate > 0 and rate == rates[-1]:
             print(f"  trace of rank {args.trace_rank}'s factor + forward list at {rate:g} GB/s:")
             rp.trace(args.trace_rank, rate, *ready)
     if args.json:
