@@ -43,6 +43,7 @@ _SIGNATURES = {
                                     c_double, c_int64, c_int64, c_int, c_int, c_int64, c_int64, c_int]),
     "gpp_shard_list_begin": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                      c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int, POINTER(c_int)]),
+    "gpp_shard_piece_cols": (c_int64, []),
     "gpp_shard_list_gate": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "gpp_shard_list_signal": (c_int, [c_void_p, c_void_p, c_int, c_int]),
     "gpp_shard_list_end": (c_int, [c_void_p]),

@@ -261,12 +261,20 @@ class GppContext:
                                             info.data_ptr(), int(workers), ctypes.byref(used)), "gpp_shard_list_begin")
         return bool(used.value)
 
+    def shard_messages(self, N: int, nb: int, k: int):
+        """Column ranges [(c0, c1), ...] of block row k's messages in the order they travel (gpp.h): the head — diagonal block and
+        the next block's columns —, then the tail in pieces of ``gpp_shard_piece_cols()`` columns.  The index in the list is the
+        ``tail`` argument of ``shard_list_gate`` / ``shard_list_signal``."""
+        o, o2 = k * nb, min((k + 2) * nb, N)
+        W = int(self.lib.gpp_shard_piece_cols()) or N
+        return [(o, o2)] + [(c, min(c + W, N)) for c in range(o2, N, W)]
+
     @_on_own_device
-    def shard_list_gate(self, stream, tail: bool, k: int) -> None:
+    def shard_list_gate(self, stream, tail: int, k: int) -> None:
         check(self.lib.gpp_shard_list_gate(self.h, ctypes.c_void_p(stream.cuda_stream), int(tail), k), "gpp_shard_list_gate")
 
     @_on_own_device
-    def shard_list_signal(self, stream, tail: bool, k: int) -> None:
+    def shard_list_signal(self, stream, tail: int, k: int) -> None:
         check(self.lib.gpp_shard_list_signal(self.h, ctypes.c_void_p(stream.cuda_stream), int(tail), k), "gpp_shard_list_signal")
 
     @_on_own_device

@@ -876,10 +876,10 @@ int gpp_debug_dag_counters(gpp_handle_t h, int* out, int nmax) {
   put(c[0]); put(c[1]); put(P->B);
   for (int b = 0; b < P->B; ++b) put(c[P->c_pd + b]);
   for (int b = 0; b < P->B; ++b) put(c[P->c_g1d + b]);
-  if (P->flags & DAG_SHARD) {
+  if (P->flags & DAG_SHARD) {  // (of the tails' pieces: the first one's counters)
     for (int b = 0; b < P->B; ++b) put(c[P->c_cph + b]);
-    for (int b = 0; b < P->B; ++b) put(c[P->c_cpt + b]);
-    for (int b = 0; b < P->B; ++b) put(c[P->c_art + b]);
+    for (int b = 0; b < P->B; ++b) put(c[P->c_cpt + b * P->GP]);
+    for (int b = 0; b < P->B; ++b) put(c[P->c_art + b * P->GP]);
   }
   return n;
 }
@@ -1163,27 +1163,35 @@ int gpp_shard_list_begin(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nr
 }
 
 /* tail == 0: `stream` waits until this rank's panel of block row k is done and its copies of the head's strips (the columns of block
- * k + 1) are in A — the head message (diagonal block, D[k], head) can be packed; tail != 0: the same for the columns behind. */
+ * k + 1) are in A — the head message (diagonal block, D[k], head) can be packed; tail = 1 + g: the same for piece g of the columns
+ * behind (gpp_shard_piece_cols() columns each). */
+static int shard_pieces(const DagPlan* P, int k) {  // pieces of block row k's tail (gpp_dag.hip: Planner::npieces)
+  const int hi = P->tb[std::min(k + 2, P->B)];
+  return hi >= P->nt ? 0 : (P->nt - hi + P->piece_tiles - 1) / P->piece_tiles;
+}
 int gpp_shard_list_gate(gpp_handle_t h, void* stream, int tail, int k) {
   if (!h || !h->shard_cur) return -1;
   const DagPlan* P = h->shard_cur;
   if (k < 0 || k >= P->B || k % P->nranks != P->rank) return -4;
+  if (tail < 0 || tail > shard_pieces(P, k)) return -3;
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   const long long budget = shard_budget(h);
   GPP_TRY(hipStreamWaitEvent(s, h->shard_ready, 0));  // the counters are cleared
   GPP_TRY(gpp_launch_exec_gate(s, P->d_counters, P->c_pd + k, 1, h->shard_info, budget));
-  const int target = tail ? P->cpt_target[k] : P->cph_target[k];
-  if (target > 0) GPP_TRY(gpp_launch_exec_gate(s, P->d_counters, (tail ? P->c_cpt : P->c_cph) + k, target, h->shard_info, budget));
+  const int piece = k * P->GP + tail - 1;
+  const int target = tail ? P->cpt_target[piece] : P->cph_target[k];
+  if (target > 0) GPP_TRY(gpp_launch_exec_gate(s, P->d_counters, tail ? P->c_cpt + piece : P->c_cph + k, target, h->shard_info, budget));
   return 0;
 }
 
-/* Behind the unpacked head (tail == 0) / tail message of another rank's block row k on `stream`: its tasks may run. */
+/* Behind the unpacked head (tail == 0) / piece tail - 1 of the tail of another rank's block row k on `stream`: its tasks may run. */
 int gpp_shard_list_signal(gpp_handle_t h, void* stream, int tail, int k) {
   if (!h || !h->shard_cur) return -1;
   const DagPlan* P = h->shard_cur;
   if (k < 0 || k >= P->B || k % P->nranks == P->rank) return -4;
+  if (tail < 0 || tail > shard_pieces(P, k)) return -3;
   GPP_TRY(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(stream), h->shard_ready, 0));
-  return rc(gpp_launch_exec_signal(reinterpret_cast<hipStream_t>(stream), P->d_counters, (tail ? P->c_art : P->c_pd) + k));
+  return rc(gpp_launch_exec_signal(reinterpret_cast<hipStream_t>(stream), P->d_counters, tail ? P->c_art + k * P->GP + tail - 1 : P->c_pd + k));
 }
 
 /* The handle's stream waits for the list (its executor and its panels). */

@@ -62,8 +62,12 @@ struct Planner {
   int cur_lvl = 0;
   // DAG_SHARD: this rank's list of the sharded evaluation
   int rank = 0, nranks = 1;
-  int c_cpd = 0, c_cph = 0, c_cpt = 0, c_art = 0;
-  std::vector<int> cph_n, cpt_n;  // copies that raise CPH(k) / CPT(k)
+  int c_cpd = 0, c_cph = 0, c_cpt = 0, c_art = 0, c_own = 0;
+  std::vector<int> cph_n, cpt_n;  // copies that raise CPH(k) / CPT(k, g)
+  int piece_tiles = 0, GP = 1;    // the tail of a block row's message in pieces of piece_tiles column tiles (DagPlan::piece_tiles)
+  int hi_of(int k) const { return tb[std::min(k + 2, B)]; }  // first column tile of block row k's tail
+  int npieces(int k) const { return hi_of(k) >= nt ? 0 : (nt - hi_of(k) + piece_tiles - 1) / piece_tiles; }
+  int piece_of(int k, int c) const { return (c - hi_of(k)) / piece_tiles; }  // c >= hi_of(k)
   bool own(int b) const { return b % nranks == rank; }
   int c_zs = 0, c_yr = 0, c_vy = 0;  // DAG_BACK
   int ZS(int b, int c) const { return c_zs + b * nt + c; }
@@ -71,8 +75,10 @@ struct Planner {
   int VY(int i, int j) const { return c_vy + (int)((int64_t)i * (i + 1) / 2 + j); }  // i >= j
   int CPD(int b, int c) const { return c_cpd + b * nt + c; }
   int CPH(int b) const { return c_cph + b; }
-  int CPT(int b) const { return c_cpt + b; }
-  int ART(int b) const { return c_art + b; }
+  int CPT(int b, int g) const { return c_cpt + b * GP + g; }
+  int ART(int b, int g) const { return c_art + b * GP + g; }
+  int OWNM(int b, int m) const { return c_own + b * (GP + 1) + m; }  // this rank's own message m (0 head, 1 + g piece g) is on the wire:
+                                                                     // raised by the simulation's communication stream only
 
   int blk_of(int tile) const { return (int)(std::upper_bound(tb.begin(), tb.end(), tile) - tb.begin()) - 1; }
   int64_t rows_of(int b) const { return std::min<int64_t>((int64_t)tb[b + 1] * 128, N) - (int64_t)tb[b] * 128; }
@@ -182,12 +188,15 @@ struct Planner {
     if (flags & DAG_SHARD) {
       // (uniform blocks: the sharded buffers address block k at k * nb; a last block too short for the panel is the caller's to avoid)
       if (B != (nt + bt - 1) / bt || rank < 0 || rank >= nranks || rank >= B) return false;
+      piece_tiles = tune.piece_cols >= GPP_TILE ? (int)(tune.piece_cols / GPP_TILE) : nt;
+      GP = std::max(1, npieces(0));
       c_cpd = ncounters; ncounters += B * nt;
       c_cph = ncounters; ncounters += B;
-      c_cpt = ncounters; ncounters += B;
-      c_art = ncounters; ncounters += B;
+      c_cpt = ncounters; ncounters += B * GP;
+      c_art = ncounters; ncounters += B * GP;
+      c_own = ncounters; ncounters += B * (GP + 1);
       cph_n.assign(B, 0);
-      cpt_n.assign(B, 0);
+      cpt_n.assign((size_t)B * GP, 0);
     }
     chain.assign(ncounters, 0);
     for (int c = c_va; c < n_ver; ++c) chain[c] = 1;  // VA, VT
@@ -480,15 +489,15 @@ struct Planner {
     const int64_t ldc = ldi, ldw = ldt;
     auto avail = [&](int node, int k, int c) {  // block row k of the factor, column tile c, is in A
       if (own(k)) wait(node, CPD(k, c), 1);
-      else wait(node, c < tb[std::min(k + 2, B)] ? PD(k) : ART(k), 1);
+      else wait(node, c < hi_of(k) ? PD(k) : ART(k, piece_of(k, c)), 1);
     };
-    auto avail2 = [&](int node, int k, int i, int j) {
+    auto avail2 = [&](int node, int k, int i, int j) {  // column tiles i <= j
       if (own(k)) {
         wait(node, CPD(k, i), 1);
         if (j != i) wait(node, CPD(k, j), 1);
       } else {
-        const int hi2 = tb[std::min(k + 2, B)];
-        wait(node, (i < hi2 && j < hi2) ? PD(k) : ART(k), 1);  // (the tail arrives behind the head)
+        // (the head, then the tail's pieces in column order, arrive on ONE stream: the later tile's message implies the earlier's)
+        wait(node, j < hi_of(k) ? PD(k) : ART(k, piece_of(k, j)), 1);
       }
     };
     auto fuse_of = [&](int bi, int kk) {
@@ -499,10 +508,35 @@ struct Planner {
       return 1;
     };
     int last_comm = -1;  // the communication stream's previous event
+    // Every message of the communication stream is a node of the simulation, in the stream's order: per block row its head, then
+    // the pieces of its tail.  Another rank's message raises PD(k) / ART(k, g) when it has arrived; this rank's own occupies the
+    // stream behind its gate (the copies of those strips: CPH(k) / CPT(k, g)) for its bytes at ~50 GB/s and raises OWNM, which
+    // nothing on the device waits for.
+    auto piece_mb = [&](int k, int g) {
+      const int t0 = hi_of(k) + g * piece_tiles, t1 = std::min(t0 + piece_tiles, nt);
+      return 1e-6 * 8.0 * (double)rows_of(k) * (double)(std::min<int64_t>((int64_t)t1 * 128, N) - (int64_t)t0 * 128);
+    };
+    auto own_messages = [&](int k) {  // (behind the generation of block row k's copies: their counts are the gates' targets)
+      const int64_t o_ = (int64_t)tb[k] * 128, nbk_ = rows_of(k);
+      const double mb_head = 1e-6 * 8.0 * (double)(nbk_ * (std::min<int64_t>((int64_t)hi_of(k) * 128, N) - o_ + nbk_));
+      const int h = add_node(-1, k, 0, -2, 50.0 + mb_head / 0.05);
+      if (last_comm >= 0) wait(h, nodes[last_comm].inc[0], 1);
+      if (cph_n[k] > 0) wait(h, CPH(k), ALL);
+      else wait(h, PD(k), 1);
+      inc(h, OWNM(k, 0));
+      last_comm = h;
+      for (int g = 0; g < npieces(k); ++g) {
+        const int t = add_node(-1, k, g, -3, 50.0 + piece_mb(k, g) / 0.05);
+        wait(t, nodes[last_comm].inc[0], 1);
+        if (cpt_n[(size_t)k * GP + g] > 0) wait(t, CPT(k, g), ALL);
+        inc(t, OWNM(k, 1 + g));
+        last_comm = t;
+      }
+    };
     for (int k = 0; k < B; ++k) {
       const int lo = tb[k + 1], btk = tb[k + 1] - tb[k];
       const int64_t o = (int64_t)tb[k] * 128, nbk = rows_of(k), c0 = (int64_t)lo * 128, rem = N - c0;
-      const int hi = tb[std::min(k + 2, B)];
+      const int hi = hi_of(k);
       const int64_t dk = (int64_t)k * nb * nb;  // D[k]
       const int nl = nleft(k);                  // owned column blocks left of block k: compact tiles [0, nl * bt)
       cur_lvl = k;
@@ -510,21 +544,18 @@ struct Planner {
         const int p = add_node(-1, k, 0, -1, tune.t_gate + tune.t_panel0 + tune.t_panel_leaf * (double)((nbk + 127) / 128));
         if (k > 0) wait(p, G1D(k), ALL);
         inc(p, PD(k));
-      } else {
+      } else if (nranks > 1) {
         // the head of a remote slab: its owner needed the previous slab's head first
         const double mb_head = 1e-6 * 8.0 * (double)(nbk * (std::min<int64_t>(c0 + nb, N) - o + nbk));
         const int h = add_node(-1, k, 0, -2, 1300.0 + mb_head / 0.05);  // update + panel + head solve + copy, the message at ~50 GB/s
-        // (the stream's order: behind the previous message — a remote one's arrival, or the gates of this rank's own)
-        if (last_comm >= 0) wait(h, nodes[last_comm].inc[0], 1);
-        if (k > 0 && own(k - 1) && cph_n[k - 1] > 0) wait(h, CPH(k - 1), ALL);
-        if (k > 0 && own(k - 1) && cpt_n[k - 1] > 0) wait(h, CPT(k - 1), ALL);
+        if (last_comm >= 0) wait(h, nodes[last_comm].inc[0], 1);  // (the stream's order: behind the previous message)
         inc(h, PD(k));
         last_comm = h;
-        if ((int64_t)hi * 128 < N) {
-          const double mb_tail = 1e-6 * 8.0 * (double)(nbk * (N - (int64_t)hi * 128));
-          const int t = add_node(-1, k, 0, -3, 200.0 + mb_tail / 0.05);
-          wait(t, PD(k), 1);
-          inc(t, ART(k));
+        for (int g = 0; g < npieces(k); ++g) {
+          // (its first piece: one piece's update + solve + copies behind the previous block row's first piece; then the wire)
+          const int t = add_node(-1, k, g, -3, (g == 0 ? 200.0 : 20.0) + piece_mb(k, g) / 0.05);
+          wait(t, nodes[last_comm].inc[0], 1);
+          inc(t, ART(k, g));
           last_comm = t;
         }
       }
@@ -549,7 +580,10 @@ struct Planner {
             inc(n, XS(k, j));
           }
       }
-      if (rem <= 0) continue;
+      if (rem <= 0) {
+        if (own(k) && nranks > 1) own_messages(k);
+        continue;
+      }
       const int nbk1 = (int)rows_of(k + 1);
       const bool chain_here = own(k) && own(k + 1);  // this rank's next panel reads this solve's output directly
       const int slot = 4 + ((k - me) / P) % 3;
@@ -607,9 +641,15 @@ struct Planner {
           // the same of the rows above it (fused tasks wait for their last step only); with P > 1 the messages' order does that
           if (k > 0 && own(k - 1)) wait(n, CPD(k - 1, c), 1);
           inc(n, CPD(k, c));
-          inc(n, c < hi ? CPH(k) : CPT(k));
-          ++(c < hi ? cph_n : cpt_n)[k];
+          if (c < hi) {
+            inc(n, CPH(k));
+            ++cph_n[k];
+          } else {
+            inc(n, CPT(k, piece_of(k, c)));
+            ++cpt_n[(size_t)k * GP + piece_of(k, c)];
+          }
         }
+        if (nranks > 1) own_messages(k);
       }
       // ---- U(k): the trailing update of the block rows this rank owns -----------------------------------------------------------
       GemmArgs u{};
@@ -1107,6 +1147,7 @@ DagPlan* emit(Planner& pl) {
   P->rank = pl.rank; P->nranks = pl.nranks;
   P->c_cph = pl.c_cph; P->c_cpt = pl.c_cpt; P->c_art = pl.c_art;
   P->cph_target = pl.cph_n; P->cpt_target = pl.cpt_n;
+  P->piece_tiles = pl.piece_tiles; P->GP = pl.GP;
   P->sim_ms = pl.makespan * 1e-3;
   P->sim_busy = pl.busy;
   // first ticket of each level: a filler launch behind panel b stops in front of the first task that needs panel b + 1
@@ -1160,6 +1201,16 @@ DagPlan* emit(Planner& pl) {
 
 }  // namespace
 
+// Columns per piece of a block row's tail message (gpp.h).  Measured with tools/replay_rank.py at C5 on 8 virtual ranks: see
+// profiles/r06_virtual_rank.txt.  GPP_SHARD_PIECE_COLS=0: one piece, as in round 5.
+extern "C" int64_t gpp_shard_piece_cols(void) {
+  static const int64_t cols = [] {
+    const int64_t v = getenv("GPP_SHARD_PIECE_COLS") ? atol(getenv("GPP_SHARD_PIECE_COLS")) : 8192;
+    return v <= 0 ? (int64_t)0 : std::max<int64_t>(GPP_TILE, v / GPP_TILE * GPP_TILE);
+  }();
+  return cols;
+}
+
 DagTuning gpp_dag_default_tuning() {
   DagTuning t;
   // two work-groups per CU, measured per task with TRACE=1 tools/dag_check.py (profiles/r05_dag_traces.txt): the big tile 264 us at
@@ -1177,6 +1228,7 @@ DagTuning gpp_dag_default_tuning() {
   t.chain_tile = getenv("GPP_DAG_CHAIN_TILE") ? atoi(getenv("GPP_DAG_CHAIN_TILE")) : 64;
   t.workers = 448;
   t.inv_rows = 0;
+  t.piece_cols = gpp_shard_piece_cols();
   t.fuse = getenv("GPP_DAG_FUSE") ? atoi(getenv("GPP_DAG_FUSE")) : 1;  // (potrf_dag chooses by size)
   t.fill = getenv("GPP_DAG_FILL") ? atoi(getenv("GPP_DAG_FILL")) : 64;
   return t;
@@ -1644,7 +1696,14 @@ extern "C" int gpp_debug_shard_check(int64_t N, int64_t nb, int nranks, int chai
   auto blk_of = [&](int tile) { return (int)(std::upper_bound(tb.begin(), tb.end(), tile) - tb.begin()) - 1; };
   auto tixU = [&](int i, int j) { return (size_t)((int64_t)i * nt - (int64_t)i * (i - 1) / 2 + (j - i)); };
   auto hi_of = [&](int k) { return tb[std::min(k + 2, B)]; };
-  auto has_tail = [&](int k) { return (int64_t)hi_of(k) * 128 < N; };
+  // the tail's pieces, recomputed from the documented rule (gpp.h), not read from the plans
+  const int pt = gpp_shard_piece_cols() > 0 ? (int)(gpp_shard_piece_cols() / GPP_TILE) : nt;
+  auto npieces = [&](int k) { return hi_of(k) >= nt ? 0 : (nt - hi_of(k) + pt - 1) / pt; };
+  const int GP = std::max(1, npieces(0));
+  if (R[0].plan->GP != GP || R[0].plan->piece_tiles != pt) {
+    cleanup();
+    return 3;
+  }
   auto elems = [](const void* p) { return (int64_t)(reinterpret_cast<uintptr_t>(p) / 8); };
   for (int r = 0; r < P; ++r) {
     Rank& q = R[r];
@@ -1659,7 +1718,7 @@ extern "C" int gpp_debug_shard_check(int64_t N, int64_t nb, int nranks, int chai
     q.x_done.assign((size_t)nt * nt, 0);
     q.copied.assign((size_t)B * nt, 0);
     q.panel_done.assign(B, 0);
-    q.arr_head.assign(B, 0); q.arr_tail.assign(B, 0); q.sent_head.assign(B, 0); q.sent_tail.assign(B, 0);
+    q.arr_head.assign(B, 0); q.arr_tail.assign((size_t)B * GP, 0); q.sent_head.assign(B, 0); q.sent_tail.assign((size_t)B * GP, 0);
     q.cur.assign(std::max(W, 1), -1);
     q.lazy.assign(q.plan->tasks.size(), 0);
   }
@@ -1748,7 +1807,7 @@ extern "C" int gpp_debug_shard_check(int64_t N, int64_t nb, int nranks, int chai
   };
   auto in_a = [&](int r, const Rank& q, int k, int c) {  // block row k of the factor, column tile c, is in this rank's A
     if (own(r, k)) return (bool)q.copied[(size_t)k * nt + c];
-    return (bool)(c < hi_of(k) ? q.arr_head[k] : q.arr_tail[k]);
+    return (bool)(c < hi_of(k) ? q.arr_head[k] : q.arr_tail[(size_t)k * GP + (c - hi_of(k)) / pt]);
   };
   auto d_here = [&](int r, const Rank& q, int k) { return (bool)(own(r, k) ? q.panel_done[k] : q.arr_head[k]); };
   auto try_task = [&](int r, const DagTask& t) -> bool {
@@ -1920,40 +1979,45 @@ extern "C" int gpp_debug_shard_check(int64_t N, int64_t nb, int nranks, int chai
     ++q.op;
     return true;
   };
-  // the communication stream of rank r: operation 2k = head of block row k, 2k + 1 = its tail
+  // the communication stream of rank r: operation k (GP + 1) + m = message m of block row k — 0 its head, 1 + g piece g of its tail
+  const size_t nops = (size_t)B * (GP + 1);
+  auto skip_absent = [&](size_t c) {
+    while (c < nops && (int)(c % (GP + 1)) > npieces((int)(c / (GP + 1)))) ++c;
+    return c;
+  };
   auto comm_step = [&](int r) -> bool {
     Rank& q = R[r];
     const DagPlan* pl = q.plan;
     if (P == 1) return false;
-    while (q.cop < (size_t)2 * B && (q.cop & 1) && !has_tail((int)(q.cop / 2))) ++q.cop;
-    if (q.cop >= (size_t)2 * B) return false;
-    const int k = (int)(q.cop / 2);
-    const bool tail = q.cop & 1;
+    q.cop = skip_absent(q.cop);
+    if (q.cop >= nops) return false;
+    const int k = (int)(q.cop / (GP + 1)), m = (int)(q.cop % (GP + 1));
+    const bool tail = m > 0;
+    const size_t pc = (size_t)k * GP + (tail ? m - 1 : 0);  // the piece's slot
     if (own(r, k)) {
       // gates: the panel's signal, then the copies counted
       if (q.counters[pl->c_pd + k] < 1) return false;
       if (!tail && q.counters[pl->c_cph + k] < pl->cph_target[k]) return false;
-      if (tail && q.counters[pl->c_cpt + k] < pl->cpt_target[k]) return false;
+      if (tail && q.counters[pl->c_cpt + (int)pc] < pl->cpt_target[pc]) return false;
       if (!q.panel_done[k]) fail(r, 90);
-      for (int c = tail ? hi_of(k) : tb[k + 1]; c < (tail ? nt : hi_of(k)); ++c)
+      const int cb = tail ? hi_of(k) + (m - 1) * pt : tb[k + 1], ce = tail ? std::min(cb + pt, nt) : hi_of(k);
+      for (int c = cb; c < ce; ++c)
         if (!q.copied[(size_t)k * nt + c]) fail(r, 91);
-      (tail ? q.sent_tail : q.sent_head)[k] = 1;
+      if (tail) q.sent_tail[pc] = 1;
+      else q.sent_head[k] = 1;
     } else {
       const Rank& ow = R[k % P];
-      if (!(tail ? ow.sent_tail : ow.sent_head)[k]) return false;
-      if (r == lazy_rank && (tail ? pl->c_art : pl->c_pd) + k == lazy_counter && !allow_lazy_g) return false;
-      (tail ? q.arr_tail : q.arr_head)[k] = 1;
-      ++q.counters[(tail ? pl->c_art : pl->c_pd) + k];
+      if (!(tail ? ow.sent_tail[pc] : ow.sent_head[k])) return false;
+      const int cid = tail ? pl->c_art + (int)pc : pl->c_pd + k;
+      if (r == lazy_rank && cid == lazy_counter && !allow_lazy_g) return false;
+      if (tail) q.arr_tail[pc] = 1;
+      else q.arr_head[k] = 1;
+      ++q.counters[cid];
     }
     ++q.cop;
     return true;
   };
-  auto comm_done = [&](int r) {
-    if (P == 1) return true;
-    size_t c = R[r].cop;
-    while (c < (size_t)2 * B && (c & 1) && !has_tail((int)(c / 2))) ++c;
-    return c >= (size_t)2 * B;
-  };
+  auto comm_done = [&](int r) { return P == 1 || skip_absent(R[r].cop) >= nops; };
   const int mode = (lazy_counter >= 0 && (seed & 3u) == 0) ? 1 : (int)(seed & 3u);
   allow_lazy_g = lazy_counter < 0;
   const int Wn = std::max(W, 1);
@@ -2009,7 +2073,11 @@ extern "C" int gpp_debug_shard_check(int64_t N, int64_t nb, int nranks, int chai
           if (!q.panel_done[b]) fail(r, 80);
           for (int c = tb[b + 1]; c < nt && !rc; ++c)
             if (!q.copied[(size_t)b * nt + c]) fail(r, 81);
-        } else if (P > 1 && (!q.arr_head[b] || (has_tail(b) && !q.arr_tail[b]))) fail(r, 83);
+        } else if (P > 1) {
+          if (!q.arr_head[b]) fail(r, 83);
+          for (int g = 0; g < npieces(b); ++g)
+            if (!q.arr_tail[(size_t)b * GP + g]) fail(r, 83);
+        }
         for (int i = tb[b]; i < tb[b + 1] && !rc; ++i)
           for (int j = 0; j < tb[b]; ++j)
             if (own(r, blk_of(j)) && !q.x_done[(size_t)i * nt + j]) { fail(r, 82); break; }

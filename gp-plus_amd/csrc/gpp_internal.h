@@ -220,14 +220,22 @@ struct DagTuning {
                               // (one prologue, one read-modify-write of the tile and one ticket instead of `fuse`)
   int64_t inv_rows;           // DAG_INV: rows of the inverse built inside the list — >= N: all of it; a multiple of nb below N: only
                               // the leading inv_rows x inv_rows block (gpp_trtri then merges the rest around it)
+  int64_t piece_cols;         // DAG_SHARD: the tail of a block row's message travels in pieces of this many columns (a multiple of 128;
+                              // 0: one piece) — see DagPlan::piece_tiles
 };
 struct DagPlan {
   int64_t N = 0, nb = 0, ld = 0, ldi = 0, ldt = 0, ldk = 0, inv_rows = 0;
   int rank = 0, nranks = 1, workers = 0, fill = 0;            // DAG_SHARD: block-cyclic owner of block k is k % nranks; ldi = the compact buffers' leading
                                        // dimension, ldt = the scratch rows'
-  int c_cph = 0, c_cpt = 0, c_art = 0; // DAG_SHARD: first ids of "head copied" / "tail copied" (gates of the owner's broadcasts) and
-                                       // "tail arrived" (signalled behind a received broadcast; the head's arrival raises c_pd + k)
-  std::vector<int> cph_target, cpt_target;
+  int c_cph = 0, c_cpt = 0, c_art = 0; // DAG_SHARD: first ids of "head copied" / "tail piece copied" (gates of the owner's broadcasts) and
+                                       // "tail piece arrived" (signalled behind a received broadcast; the head's arrival raises c_pd + k)
+  // Round 6: the tail of block row k (the columns behind block k + 1) travels in PIECES of piece_tiles column tiles, piece g = the
+  // column tiles [tb[k + 2] + g piece_tiles, ...): counters c_cpt + k GP + g and c_art + k GP + g, GP = the pieces of block row 0.  A
+  // task that reads block row k of another rank waits for the piece of its LATER column tile only (messages arrive in order), so the
+  // owner of block row k + 1 updates, solves and sends ITS first piece while the rest of block row k is still on the wire: the
+  // chain per step is the transfer plus ONE piece's update + solve instead of the whole row's (measured with tools/replay_rank.py).
+  int piece_tiles = 0, GP = 1;
+  std::vector<int> cph_target, cpt_target;  // cpt_target[k GP + g]
   int flags = 0;                       // DAG_INV: also the inverse (right-looking; all of it or its leading inv_rows block)
   int B = 0, nt = 0;
   std::vector<int> tb;                 // first tile of block b (tb[B] = nt)

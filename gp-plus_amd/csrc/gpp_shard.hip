@@ -277,9 +277,12 @@ int gpp_shard_eval(gpp_handle_t h, int64_t N, int64_t nb, const double* U, int D
       const int64_t o = off(k), o1 = off(k + 1), o2 = off(k + 2), nbk = o1 - o;
       const bool own = k % P == me;
       double* Dk = b->D + k * nb * nb;
-      for (int tail = 0; tail < 2 && !comm_rc && !err; ++tail) {
-        // head: block row k's columns [o, o2) (diagonal block + the next block's columns), then D[k]; tail: columns [o2, N)
-        const int64_t c0 = tail ? o2 : o, wcols = (tail ? N : o2) - c0;
+      // messages of block row k (gpp.h): 0 = the head — columns [o, o2) (diagonal block + the next block's columns), then D[k] —,
+      // 1 + g = piece g of the tail: W columns from o2 + g W on
+      const int64_t W = gpp_shard_piece_cols() > 0 ? gpp_shard_piece_cols() : N;
+      const int nmsg = 1 + (N > o2 ? (int)((N - o2 + W - 1) / W) : 0);
+      for (int tail = 0; tail < nmsg && !comm_rc && !err; ++tail) {
+        const int64_t c0 = tail ? o2 + (tail - 1) * W : o, wcols = (tail ? std::min(c0 + W, N) : o2) - c0;
         if (wcols <= 0) continue;
         const size_t count = (size_t)(nbk * wcols + (tail ? 0 : nbk * nbk));
         if (own) {

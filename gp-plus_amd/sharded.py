@@ -482,23 +482,25 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
                     head = ws.hbuf[:nbk * wh].view(nbk, wh)
                     dblk = ws.hbuf[nbk * wh:nbk * (wh + nbk)].view(nbk, nbk)
                     if own:
-                        ctx.shard_list_gate(cs, False, k)
+                        ctx.shard_list_gate(cs, 0, k)
                         head.copy_(A[o:o1, o:o2])
                         dblk.copy_(Lkk)
                     comm.bcast(ws.hbuf[:nbk * (wh + nbk)], k % P)
                     if not own:
                         A[o:o1, o:o2].copy_(head)
                         Lkk.copy_(dblk)
-                        ctx.shard_list_signal(cs, False, k)
-                    if N > o2:
-                        tail = ws.pack[:nbk * (N - o2)].view(nbk, N - o2)
+                        ctx.shard_list_signal(cs, 0, k)
+                    # the tail in pieces (round 6; gpp_shard_piece_cols in gpp.h): the list's tasks wait for the piece of the column
+                    # tile they read, so the next owner's first piece is updated, solved and sent while the rest of this row travels
+                    for g, (c0, c1) in enumerate(ctx.shard_messages(N, nb, k)[1:]):
+                        tail = ws.pack[:nbk * (c1 - c0)].view(nbk, c1 - c0)
                         if own:
-                            ctx.shard_list_gate(cs, True, k)
-                            tail.copy_(A[o:o1, o2:N])
-                        comm.bcast(ws.pack[:nbk * (N - o2)], k % P)
+                            ctx.shard_list_gate(cs, 1 + g, k)
+                            tail.copy_(A[o:o1, c0:c1])
+                        comm.bcast(ws.pack[:nbk * (c1 - c0)], k % P)
                         if not own:
-                            A[o:o1, o2:N].copy_(tail)
-                            ctx.shard_list_signal(cs, True, k)
+                            A[o:o1, c0:c1].copy_(tail)
+                            ctx.shard_list_signal(cs, 1 + g, k)
                     if not own:
                         arrived[k] = torch.cuda.Event()
                         arrived[k].record(cs)
@@ -509,8 +511,8 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
             for k in range(nblk - 1 if _mirror_beside(P) else 0):
                 o, o1 = offs[k], offs[k + 1]
                 if k % P == me:
-                    ctx.shard_list_gate(cpy, False, k)
-                    ctx.shard_list_gate(cpy, True, k)
+                    for m in range(len(ctx.shard_messages(N, nb, k))):
+                        ctx.shard_list_gate(cpy, m, k)
                 else:
                     cpy.wait_event(arrived[k])
                 A[o1:N, o:o1].copy_(A[o:o1, o1:N].t())

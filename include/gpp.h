@@ -164,8 +164,8 @@ int gpp_gemm_lower_cols(gpp_handle_t h, const double* A, int64_t lda, const doub
  * its share of the trailing updates, and — right-looking beside them — the rows below the diagonal of ITS column blocks of
  * X = L^-1 into Kc (compact, as in gpp_gemm_lower_cols; Lc: the running sums).  Block rows of other ranks arrive as messages the
  * CALLER moves on a stream of its own (RCCL broadcasts in gp-plus_amd/sharded.py): per block row k a head (diagonal block, D[k], the
- * columns of block k + 1) and a tail (the columns behind).  The owner enqueues gpp_shard_list_gate in front of packing each from A;
- * a receiver enqueues gpp_shard_list_signal behind unpacking each into A / D.  Replaces the per-step launches of
+ * columns of block k + 1) and a tail (the columns behind, in pieces: gpp_shard_piece_cols).  The owner enqueues gpp_shard_list_gate in
+ * front of packing each from A; a receiver enqueues gpp_shard_list_signal behind unpacking each into A / D.  Replaces the per-step launches of
  * gp-plus_amd/sharded.py::_factor and ::_forward (reference counterpart: torch.linalg.cholesky + the solves of optim/mll_torch.py:114-117;
  * the reference has no multi-GPU evaluation).  *used = 0: not applicable here (size, block height, options) — nothing was
  * enqueued and the caller runs its launch-per-product path.  workers: work-groups of the executor (0 = two per throughput CU; tests
@@ -175,6 +175,12 @@ int gpp_gemm_lower_cols(gpp_handle_t h, const double* A, int64_t lda, const doub
 int gpp_shard_list_begin(gpp_handle_t h, int64_t N, int64_t nb, int rank, int nranks, double* A, int64_t ld, double* Kc, double* Lc,
                          int64_t ldc, double* D, double* W0, double* W1, double* W2, int64_t ldw, int32_t* info, int workers,
                          int* used);
+/* Messages of block row k, in the order every rank moves them on its communication stream: the HEAD (message 0), then the TAIL in
+ * pieces of gpp_shard_piece_cols() columns (messages 1 + g: the columns [(k + 2) nb + g W, min((k + 2) nb + (g + 1) W, N)), while that
+ * range is not empty; W = 8192, or GPP_SHARD_PIECE_COLS, a multiple of 128; 0 = the whole tail as ONE piece [(k + 2) nb, N)).  Round 6:
+ * a task waits for the piece of the column tile it reads, so the owner of block row k + 1 updates, solves and sends its first piece
+ * while the rest of block row k is still on the wire.  `tail` in gpp_shard_list_gate / _signal is the message number. */
+int64_t gpp_shard_piece_cols(void);
 int gpp_shard_list_gate(gpp_handle_t h, void* stream, int tail, int k);
 int gpp_shard_list_signal(gpp_handle_t h, void* stream, int tail, int k);
 int gpp_shard_list_end(gpp_handle_t h);

@@ -382,6 +382,41 @@ def test_sharded_lists_are_valid_schedules_under_any_interleaving(N, nb, P, chai
     assert (by_fillers > 0) == (fill > 0)
 
 
+@pytest.mark.parametrize("piece_cols", [0, 1024, 2048])
+def test_sharded_lists_with_other_tail_piece_sizes(piece_cols):
+    """The tail of a block row travels in pieces of gpp_shard_piece_cols() columns (gpp.h; round 6): the joint check with ONE piece
+    (round 5's messages), pieces of one block's width and of two — in a child process, the size is read once per process.  Also
+    a mutation run: a task that loses its wait for a PIECE reads columns that have not arrived."""
+    import subprocess
+
+    code = (
+        "import ctypes, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from gpplus_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "assert lib.gpp_shard_piece_cols() == %d\n"
+        "f = lib.gpp_debug_shard_check\n"
+        "f.restype = ctypes.c_int\n"
+        "f.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_uint, ctypes.POINTER(ctypes.c_int64), ctypes.c_int]\n"
+        "st = (ctypes.c_int64 * 4)()\n"
+        "for N, nb, P, ct, W, fill in ((9000, 512, 3, 4064, 448, 0), (13000, 1024, 4, 2064, 448, 64), (6100, 384, 2, 64, 3, 2)):\n"
+        "    for seed in range(3):\n"
+        "        rc = f(N, nb, P, ct, W, fill, seed, st, 0)\n"
+        "        assert rc == 0, (N, nb, P, seed, rc)\n"
+        "f(9000, 512, 3, 4064, 448, 0, 0, st, 0)\n"
+        "nw = int(st[1]); caught = total = piece = 0\n"
+        "for mut in range(1, nw + 1, max(1, nw // 150)):\n"
+        "    rc = f(9000, 512, 3, 4064, 448, 0, mut, st, mut)\n"
+        "    total += 1; caught += rc != 0\n"
+        "    piece += (int(st[3]) %% 10 == 9)\n"
+        "print('CAUGHT', caught, total, piece)\n" % (ROOT, piece_cols))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, GPP_SHARD_PIECE_COLS=str(piece_cols)))
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    caught, total, piece = (int(v) for v in p.stdout.split("CAUGHT", 1)[1].split()[:3])
+    assert caught >= 0.75 * total and piece > 0, (caught, total, piece)  # (some waits are implied by others: 79-90 %)
+
+
 def test_sharded_list_check_notices_a_missing_wait():
     """With ONE wait removed from one rank's list — and what raises that counter made slow: its tasks, the panel, or the arrival of
     the message — the joint execution must find a violation in most cases (some waits are implied by the others: the scratch row's

@@ -97,7 +97,9 @@ class Replay:
         self.offs = self.ws0.offs
         self.nblk = len(self.offs) - 1
         self.sink = torch.empty_like(self.ws0.pack)
-        self.stamps = torch.zeros((self.nblk, 2, 4), dtype=torch.int64, device=dev)  # [block][head / tail][own ready, start, end, -]
+        self.msgs = [self.ctx.shard_messages(self.N, nb, k) for k in range(self.nblk)]  # per block row: column ranges of its messages
+        self.M = max(len(m) for m in self.msgs)
+        self.stamps = torch.zeros((self.nblk, self.M, 4), dtype=torch.int64, device=dev)  # [block][message][own ready, start, end, unpacked]
         self.epoch = torch.zeros(2, dtype=torch.int64, device=dev)
         self.after_list = None
 
@@ -145,9 +147,10 @@ class Replay:
         assert rc == 0, rc
 
     # ---- one rank ------------------------------------------------------------------------------------------------------------------
-    def run(self, r, rate, ready_h, ready_t, check=False):
-        """Rank r's evaluation with the other ranks' block rows replayed at `rate` GB/s (<= 0: as fast as the copy goes), each no
-        earlier than ready_h[k] / ready_t[k] microseconds after the start.  Returns times, the rank's own ready times and status."""
+    def run(self, r, rate, ready, check=False):
+        """Rank r's evaluation with the other ranks' block rows replayed at `rate` GB/s (<= 0: as fast as the copy goes), message m of
+        block row k (0 the head, 1 + g piece g of the tail) no earlier than ready[(k, m)] microseconds after the start.  Returns
+        times, the rank's own ready times and status."""
         ctx, ws, N, nb, P, offs, nblk = self.ctx, self._ws(r), self.N, self.nb, self.P, self.offs, self.nblk
         dev, A = self.dev, self.ws0.A
         main = torch.cuda.current_stream(ctx.index)
@@ -157,7 +160,7 @@ class Replay:
         ws.info.zero_()
         comm = _NoComm(r, P)
         sp = self.stamps.data_ptr()
-        slot = lambda k, tail, q: sp + 8 * ((k * 2 + (1 if tail else 0)) * 4 + q)  # noqa: E731
+        slot = lambda k, m, q: sp + 8 * ((k * self.M + int(m)) * 4 + q)  # noqa: E731
         ev[0].record(main)
         for k in range(r, nblk, P):
             ctx.kernel_build(self.U, self.w, self.sf2, self.tau, None, A, uplo=UPLO_FULL, row0=offs[k], nrows=offs[k + 1] - offs[k])
@@ -181,31 +184,31 @@ class Replay:
                     head = ws.hbuf[:nbk * wh].view(nbk, wh)
                     dblk = ws.hbuf[nbk * wh:nbk * (wh + nbk)].view(nbk, nbk)
                     if own:
-                        ctx.shard_list_gate(cs, False, k)
-                        self._stamp(cs, slot(k, False, 0))
+                        ctx.shard_list_gate(cs, 0, k)
+                        self._stamp(cs, slot(k, 0, 0))
                         head.copy_(A[o:o1, o:o2])
                         dblk.copy_(Lkk)
                         msg = ws.hbuf[:nbk * (wh + nbk)].view(nbk, wh + nbk)  # the broadcast: the stream is busy for bytes / rate
-                        self._rcopy(cs, self.sink[:msg.numel()].view_as(msg), msg, rate, -1, slot(k, False, 1))
+                        self._rcopy(cs, self.sink[:msg.numel()].view_as(msg), msg, rate, -1, slot(k, 0, 1))
                     else:
-                        self._rcopy(cs, head, self.Aref[o:o1, o:o2], rate, ready_h[k] / TICK_US, slot(k, False, 1))
-                        self._rcopy(cs, dblk, self.Liref[o:o1, o:o1], rate, -1, slot(k, False, 1))
+                        self._rcopy(cs, head, self.Aref[o:o1, o:o2], rate, ready[(k, 0)] / TICK_US, slot(k, 0, 1))
+                        self._rcopy(cs, dblk, self.Liref[o:o1, o:o1], rate, -1, slot(k, 0, 1))
                         A[o:o1, o:o2].copy_(head)
                         Lkk.copy_(dblk)
-                        self._stamp(cs, slot(k, False, 3))
-                        ctx.shard_list_signal(cs, False, k)
-                    if N > o2:
-                        tail = ws.pack[:nbk * (N - o2)].view(nbk, N - o2)
+                        self._stamp(cs, slot(k, 0, 3))
+                        ctx.shard_list_signal(cs, 0, k)
+                    for g, (c0, c1) in enumerate(ctx.shard_messages(N, nb, k)[1:]):  # the tail's pieces
+                        tail = ws.pack[:nbk * (c1 - c0)].view(nbk, c1 - c0)
                         if own:
-                            ctx.shard_list_gate(cs, True, k)
-                            self._stamp(cs, slot(k, True, 0))
-                            tail.copy_(A[o:o1, o2:N])
-                            self._rcopy(cs, self.sink[:tail.numel()].view_as(tail), tail, rate, -1, slot(k, True, 1))
+                            ctx.shard_list_gate(cs, 1 + g, k)
+                            self._stamp(cs, slot(k, 1 + g, 0))
+                            tail.copy_(A[o:o1, c0:c1])
+                            self._rcopy(cs, self.sink[:tail.numel()].view_as(tail), tail, rate, -1, slot(k, 1 + g, 1))
                         else:
-                            self._rcopy(cs, tail, self.Aref[o:o1, o2:N], rate, ready_t[k] / TICK_US, slot(k, True, 1))
-                            A[o:o1, o2:N].copy_(tail)
-                            self._stamp(cs, slot(k, True, 3))
-                            ctx.shard_list_signal(cs, True, k)
+                            self._rcopy(cs, tail, self.Aref[o:o1, c0:c1], rate, ready[(k, 1 + g)] / TICK_US, slot(k, 1 + g, 1))
+                            A[o:o1, c0:c1].copy_(tail)
+                            self._stamp(cs, slot(k, 1 + g, 3))
+                            ctx.shard_list_signal(cs, 1 + g, k)
                     if not own:
                         arrived[k] = torch.cuda.Event()
                         arrived[k].record(cs)
@@ -213,8 +216,8 @@ class Replay:
                 for k in range(nblk - 1 if sharded._mirror_beside(P) else 0):
                     o, o1 = offs[k], offs[k + 1]
                     if k % P == r:
-                        ctx.shard_list_gate(cpy, False, k)
-                        ctx.shard_list_gate(cpy, True, k)
+                        for m in range(len(ctx.shard_messages(N, nb, k))):
+                            ctx.shard_list_gate(cpy, m, k)
                     else:
                         cpy.wait_event(arrived[k])
                     A[o1:N, o:o1].copy_(A[o:o1, o1:N].t())
@@ -250,18 +253,19 @@ class Replay:
             out.update(self._check_back(ws, r))
         st = self.stamps.cpu().numpy().astype(np.float64) * TICK_US  # microseconds since the epoch
         own = list(range(r, nblk, P))
+        nm = [len(m) for m in self.msgs]
         out.update(status_back=int(st_back), build_ms=ev[0].elapsed_time(ev[1]), ff_ms=ev[1].elapsed_time(ev[2]),
                    vec_ms=ev[2].elapsed_time(ev[3]), back_ms=ev[3].elapsed_time(ev[4]), grad_ms=ev[4].elapsed_time(ev[5]),
-                   ready_h={k: st[k, 0, 0] for k in own}, ready_t={k: st[k, 1, 0] for k in own if st[k, 1, 0] > 0},
-                   msg_start_h=st[:, 0, 1].tolist(), msg_end_h=st[:, 0, 2].tolist(), msg_end_t=st[:, 1, 2].tolist(),
-                   unpacked_h=st[:, 0, 3].tolist(), unpacked_t=st[:, 1, 3].tolist())
+                   ready={(k, m): st[k, m, 0] for k in own for m in range(nm[k])},   # own messages: the gate passed
+                   start=st[:, :, 1], end=st[:, :, 2], unpacked=st[:, :, 3])         # every message: on this rank's stream
         # the chain as this rank sees it: from the unpacked head of block k - 1 (another rank's) to its own head of block k being
         # ready to send — diagonal update, gate, panel, head solve, copies, gate (DESIGN.md section 7 assumed ~1.2 ms)
         out["chain_us"] = {k: st[k, 0, 0] - st[k - 1, 0, 3] for k in own if k > 0 and (k - 1) % P != r and st[k - 1, 0, 3] > 0}
-        out["tail_lag_us"] = {k: st[k, 1, 0] - st[k, 0, 0] for k in own if st[k, 1, 0] > 0}  # own tail ready after own head ready
+        # ... and the tail's chain: from the unpacked FIRST piece of block row k - 1's tail to the own first piece being ready
+        out["tail_chain_us"] = {k: st[k, 1, 0] - st[k - 1, 1, 3] for k in own if k > 0 and (k - 1) % P != r and nm[k] > 1 and st[k - 1, 1, 3] > 0}
         return out
 
-    def trace(self, r, rate, rh, rt):
+    def trace(self, r, rate, ready):
         """Per-task trace of rank r's factor + forward list (tools/dag_check.py's report) in the converged timeline."""
         from dag_check import trace_report
 
@@ -275,18 +279,21 @@ class Replay:
             self.lib.gpp_debug_dag_trace(self.ctx.h, 0)
 
         self.after_list = on
-        self.run(r, rate, rh, rt)
+        self.run(r, rate, ready)
         self.after_list = report
-        o = self.run(r, rate, rh, rt)
+        o = self.run(r, rate, ready)
         self.after_list = None
-        print(f"  rank {r}'s communication stream, ms since its list started (own rows: 'ready' = the gate passed; others: when the replay could start):")
-        print("    block owner | head: ready/start   sent/received   unpacked | tail: ready/start   sent/received   unpacked")
+        print(f"  rank {r}'s communication stream, ms since its list started (own rows *: 'ready' = the gate passed; others: the earliest start):")
+        print("    block owner | head: ready   sent/received   unpacked | tail, first piece: ready  sent/recvd  unpacked | last piece: ready  sent/recvd  unpacked (pieces)")
+        ms = lambda v: f"{v / 1e3:10.3f}"  # noqa: E731
         for k in range(self.nblk):
-            own = k % self.P == r
-            hs = o["ready_h"].get(k, 0.0) if own else o["msg_start_h"][k]
-            ts = o["ready_t"].get(k, 0.0) if own else max(rt[k], o["msg_end_h"][k])
-            print(f"    {k:5d} {k % self.P:5d}{'*' if own else ' '}|       {hs / 1e3:10.3f}      {o['msg_end_h'][k] / 1e3:10.3f} {o['unpacked_h'][k] / 1e3:10.3f} |"
-                  f"       {ts / 1e3:10.3f}      {o['msg_end_t'][k] / 1e3:10.3f} {o['unpacked_t'][k] / 1e3:10.3f}")
+            own, nm = k % self.P == r, len(self.msgs[k])
+            rdy = lambda m: o["ready"][(k, m)] if own else ready[(k, m)]  # noqa: E731
+            line = f"    {k:5d} {k % self.P:5d}{'*' if own else ' '}|   {ms(rdy(0))}      {ms(o['end'][k, 0])} {ms(o['unpacked'][k, 0])} |"
+            if nm > 1:
+                line += f"        {ms(rdy(1))} {ms(o['end'][k, 1])} {ms(o['unpacked'][k, 1])} |"
+                line += f"  {ms(rdy(nm - 1))} {ms(o['end'][k, nm - 1])} {ms(o['unpacked'][k, nm - 1])} ({nm - 1})"
+            print(line)
         return o
 
     # ---- comparisons with the single-GPU result (--check, tests/test_gpu_replay.py) ----------------------------------------------------
@@ -317,41 +324,42 @@ class Replay:
         + gate per step, then the message)."""
         N, nb, offs, nblk = self.N, self.nb, self.offs, self.nblk
         per_us = (lambda b: 0.0) if rate <= 0 else (lambda b: b / (rate * 1e3))
-        rh, rt, t_head, t_tail = {}, {}, 0.0, 0.0
+        ready, t_head, t_tail = {}, 0.0, 0.0
         for k in range(nblk):
-            o, o1 = offs[k], offs[k + 1]
-            o2 = offs[k + 2] if k + 2 <= nblk else N
-            rh[k] = t_head + chain_us
-            t_head = rh[k] + per_us(8.0 * (o1 - o) * (o2 - o + o1 - o))
-            rt[k] = max(t_head, t_tail) + tail_us
-            t_tail = rt[k] + per_us(8.0 * (o1 - o) * (N - o2))
-        return rh, rt
+            nbk = offs[k + 1] - offs[k]
+            ready[(k, 0)] = t_head + chain_us
+            c0, c1 = self.msgs[k][0]
+            t_head = ready[(k, 0)] + per_us(8.0 * nbk * (c1 - c0 + nbk))
+            for m, (c0, c1) in enumerate(self.msgs[k][1:], 1):
+                ready[(k, m)] = max(t_head, t_tail) + (tail_us if m == 1 else 0.0)
+                t_tail = t_head = ready[(k, m)] + per_us(8.0 * nbk * (c1 - c0))
+        return ready
+
+    def zero_ready(self):
+        return {(k, m): 0.0 for k in range(self.nblk) for m in range(len(self.msgs[k]))}
 
     def converge(self, rate, ranks, sweeps, check=False, ready=None, verbose=True, tol_us=300.0):
-        rh, rt = ready if ready is not None else self.model_ready(rate)
+        ready = dict(ready) if ready is not None else self.model_ready(rate)
         res, hist = {}, []
         for sweep in range(sweeps):
             delta = 0.0
             for r in ranks:
-                o = self.run(r, rate, rh, rt, check=check and sweep == sweeps - 1)
-                for k, v in o["ready_h"].items():
-                    delta = max(delta, abs(v - rh[k]))
-                    rh[k] = v
-                for k, v in o["ready_t"].items():
-                    delta = max(delta, abs(v - rt[k]))
-                    rt[k] = v
+                o = self.run(r, rate, ready, check=check and sweep == sweeps - 1)
+                for key, v in o["ready"].items():
+                    delta = max(delta, abs(v - ready[key]))
+                    ready[key] = v
                 res[r] = o
             tot = {r: sum(res[r][q] for q in ("build_ms", "ff_ms", "vec_ms", "back_ms", "grad_ms")) for r in res}
             hist.append((delta, max(tot.values())))
             if verbose:
                 print(f"    sweep {sweep}: ready times moved by up to {delta / 1e3:8.3f} ms; slowest rank {max(tot.values()):9.2f} ms "
                       f"(ff {max(res[r]['ff_ms'] for r in res):8.2f}, back {max(res[r]['back_ms'] for r in res):8.2f})", flush=True)
-            if len(ranks) < self.P or delta < max(tol_us, 0.004 * max(rt.values())):
+            if len(ranks) < self.P or delta < max(tol_us, 0.004 * max(ready.values())):
                 break
         if check and "err_factor" not in res[ranks[-1]]:  # converged before the last sweep: one more pass for the comparison
             for r in ranks:
-                res[r] = self.run(r, rate, rh, rt, check=True)
-        return res, (rh, rt), hist
+                res[r] = self.run(r, rate, ready, check=True)
+        return res, ready, hist
 
 
 def summarise(rp, rate, res, hist):
@@ -359,19 +367,19 @@ def summarise(rp, rate, res, hist):
     rows = []
     for r in sorted(res):
         o = res[r]
-        last = max([v for v in o["msg_end_h"] + o["msg_end_t"]] + [0.0]) / 1e3
+        last = float(o["end"].max()) / 1e3
         rows.append((r, o["build_ms"], o["ff_ms"], o["vec_ms"], o["back_ms"], o["grad_ms"], last, o["status_ff"], o["status_back"]))
     print(f"  rate {('unthrottled' if rate <= 0 else f'{rate:g} GB/s'):>12s}   rank   build      ff  z/alpha    back    grad    total | last message at   status")
     for r, b, f, v, bk, g, last, s1, s2 in rows:
         print(f"  {'':17s}{r:6d} {b:7.2f} {f:7.2f} {v:8.2f} {bk:7.2f} {g:7.2f} {b + f + v + bk + g:8.2f} | {last:10.2f} ms    {s1:#x} {s2:#x}")
     chain = [v for o in res.values() for v in o.get("chain_us", {}).values()]
-    lag = [v for o in res.values() for v in o.get("tail_lag_us", {}).values()]
-    unp = [o["unpacked_t"][k] - o["msg_end_t"][k] for o in res.values() for k in range(rp.nblk) if o["unpacked_t"][k] > 0]
-    if chain:
+    lag = [v for o in res.values() for v in o.get("tail_chain_us", {}).values()]
+    unp = [o["unpacked"][k, m] - o["end"][k, m] for o in res.values() for k in range(rp.nblk) for m in range(1, rp.M) if o["unpacked"][k, m] > 0]
+    if chain and lag and unp:
         print(f"  {'':17s}   chain per step (head k-1 unpacked -> own head k ready to send): mean {np.mean(chain) / 1e3:.3f} ms, "
               f"p10 {np.percentile(chain, 10) / 1e3:.3f}, p90 {np.percentile(chain, 90) / 1e3:.3f}, max {np.max(chain) / 1e3:.3f}; "
-              f"own tail ready {np.mean(lag) / 1e3:.3f} ms after own head (max {np.max(lag) / 1e3:.3f}); "
-              f"unpacking a tail {np.mean(unp) / 1e3:.3f} ms (max {np.max(unp) / 1e3:.3f})")
+              f"tail chain (first piece of row k-1 unpacked -> own first piece ready): mean {np.mean(lag) / 1e3:.3f} ms (max {np.max(lag) / 1e3:.3f}); "
+              f"unpacking a piece {np.mean(unp) / 1e3:.3f} ms (max {np.max(unp) / 1e3:.3f})")
     ff, back = max(x[2] for x in rows), max(x[4] for x in rows)
     small = max(x[1] + x[3] + x[5] for x in rows)
     total = ff + back + small  # the ranks meet at the all-reduces of z / alpha and of the gradient
@@ -409,13 +417,14 @@ def main():
     ranks = [int(x) for x in args.ranks.split(",")] if args.ranks else list(range(args.P))
     print(f"virtual-rank replay: N = {n}, d = {U.shape[1]}, P = {args.P}, nb = {args.nb}, {rp.nblk} block rows; library {rp.ctx.lib.gpp_version().decode()}")
     print(f"  single-GPU factor + inverse (the reference the other ranks' block rows are taken from): {rp.ref_factor_inverse_ms:.1f} ms; "
+          f"tail pieces of {int(rp.ctx.lib.gpp_shard_piece_cols()) or n} columns (up to {rp.M - 1} per block row); "
           f"GPP_SHARD_FILL = {os.environ.get('GPP_SHARD_FILL', 'default (one filler work-group per panel CU)')}; the factor's mirror "
           f"{'beside' if sharded._mirror_beside(args.P) else 'behind'} the list", flush=True)
     out = {"N": n, "d": int(U.shape[1]), "P": args.P, "nb": args.nb, "library": rp.ctx.lib.gpp_version().decode(), "rates": []}
     t0 = time.perf_counter()
-    zero = ({k: 0.0 for k in range(rp.nblk)}, {k: 0.0 for k in range(rp.nblk)})
+    zero = rp.zero_ready()
     for r_ in ranks:  # (the host plans each rank's two lists on their first use — seconds at N = 60 000 — with the device idle)
-        rp.run(r_, 0.0, *zero)
+        rp.run(r_, 0.0, zero)
     print(f"  warm-up pass over {len(ranks)} rank(s) (plans, allocations): {time.perf_counter() - t0:.1f} s", flush=True)
     ready = None
     rates = [float(x) for x in args.rates.split(",")]
@@ -433,7 +442,7 @@ def main():
         out["rates"].append(rec)
         if args.trace_rank is not None and rate > 0 and rate == rates[-1]:
             print(f"  trace of rank {args.trace_rank}'s factor + forward list at {rate:g} GB/s:")
-            rp.trace(args.trace_rank, rate, *ready)
+            rp.trace(args.trace_rank, rate, ready)
     if args.json:
         with open(args.json, "w") as fh:
             json.dump(out, fh, indent=1)
