@@ -294,6 +294,8 @@ class Replay:
                 line += f"        {ms(rdy(1))} {ms(o['end'][k, 1])} {ms(o['unpacked'][k, 1])} |"
                 line += f"  {ms(rdy(nm - 1))} {ms(o['end'][k, nm - 1])} {ms(o['unpacked'][k, nm - 1])} ({nm - 1})"
             print(line)
+            if nm > 2 and os.environ.get("REPLAY_PIECES"):
+                print("                  pieces ready>end: " + "  ".join(f"{rdy(m) / 1e3:.2f}>{o['end'][k, m] / 1e3:.2f}" for m in range(1, nm)))
         return o
 
     # ---- comparisons with the single-GPU result (--check, tests/test_gpu_replay.py) ----------------------------------------------------
