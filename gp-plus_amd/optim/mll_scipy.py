@@ -154,7 +154,12 @@ def _fit_model_from_state(likobj, theta0, jac, options, method='L-BFGS-B', const
         return minimize(fun=likobj.fun, x0=theta0, args=(True) if jac else (False), method=method, jac=jac, bounds=bnds,
                         options=options)
     except (NotPSDError, NanError) as e:  # unstable start: scored inf by the caller (optim/mll_scipy.py:232-236,295)
-        return e
+        # The exception is RETURNED and lives on in the caller's result list (as in the reference) — without its traceback: the
+        # frames of the failed evaluation (the autograd Function's forward, its tensors, its context) would stay alive with it, and
+        # with them alive the NEXT HIP-graph capture on this stack dies in hipStreamEndCapture (round 6: found by the continuation
+        # driver, whose level below the noise bound fails by design and is followed by more fits; minimal reproducer
+        # tools/dev/capture_bisect.py — `fun_keep_exc` crashes, `keep_no_tb` does not).
+        return e.with_traceback(None)
 
 
 def fit_model_scipy(model, add_prior: bool = True, num_restarts: int = 1, theta0_list: Optional[List[np.ndarray]] = None,

@@ -754,7 +754,11 @@ def oracle_continuation(o: "OracleGP", add_prior: bool = True, num_restarts: int
     o.fix_noise = True  # (reset_parameters then skips the noise draw without consuming random numbers: gpregression.py:172-173)
 
     def set_noise(v):
-        o.params[nk] = torch.log(torch.full_like(o.params[nk], float(v)) - o.lb_noise)
+        # [3P] gpytorch's noise setter: torch.as_tensor(python float) is float32 (the default dtype) before it is cast to the
+        # parameter's dtype — the levels are float32-rounded.  The level 1e-8 of the first pass is therefore BELOW
+        # the fp64 bound 1e-8: log of a negative number, a NaN covariance, every start fails and the pass ends there (:178-180).
+        v32 = torch.as_tensor(float(v), dtype=torch.float32).to(DT)
+        o.params[nk] = torch.log(torch.full_like(o.params[nk], float(v32)) - o.lb_noise)
 
     def noise_now():
         return float(noise_transform(o.params[nk], o.lb_noise).reshape(-1)[0])
