@@ -65,6 +65,49 @@ class ExactGP(GP):
                 self.prediction_strategy = factorize(cov.U1, cov.spec, noisy.tau, noisy.grp, train_out.mean, self.train_targets)
         return self.prediction_strategy
 
+    def _graphed_prior_call(self, inputs, kwargs):
+        """The training-mode call — the model's own ``forward``: manifold map, mean, parameter transforms, kernel weights
+        (models/gp_plus.py:386-484) — as a replayed pair of HIP graphs (gp-plus_amd/graphed.py::GraphedSegment) where that applies
+        (N >= 3840, autograd on, a lazy kernel covariance); None otherwise: the caller runs ``forward`` op by op.  Same kernels on
+        the same data: the same numbers."""
+        from ..graphed import GraphedSegment, segment_key, segments_apply
+        from ..linalg import KernelSpec
+
+        if kwargs or len(inputs) != 1 or not torch.is_tensor(inputs[0]) or not segments_apply(inputs[0].shape[0], inputs[0].device):
+            return None
+        params = [p for p in self.parameters()]
+        if not any(p.requires_grad for p in params) or any(p.device != inputs[0].device for p in params):
+            return None
+        key = segment_key(params, inputs[0])
+        st = getattr(self, "_prior_segment", None)
+        if st is None or st["key"] != key:
+            meta = {}
+
+            def fn():
+                out = Module.__call__(self, *inputs)
+                cov = out.lazy_covariance_matrix
+                if not isinstance(cov, LazyKernelMatrix) or not cov.is_square or cov.tau is not None:
+                    raise TypeError("not a lazy kernel covariance")
+                meta.update(kind=cov.spec.kind, d_split=cov.spec.d_split, n_grad_dims=cov.n_grad_dims,
+                            U=None if cov.U1.requires_grad else cov.U1)
+                tens = [out.mean, cov.spec.w, cov.spec.sf2.reshape(1)]
+                if cov.U1.requires_grad:
+                    tens.append(cov.U1)
+                return tuple(tens)
+
+            st = {"key": key, "seg": None, "meta": meta}
+            try:
+                st["seg"] = GraphedSegment(fn, params, inputs[0].device)
+            except (TypeError, RuntimeError) as exc:  # a forward the stack cannot capture: op by op, and say so once
+                warnings.warn(f"the model's forward could not be captured as a HIP graph ({exc}); evaluating it op by op", RuntimeWarning)
+            self._prior_segment = st
+        if st["seg"] is None:
+            return None
+        outs, meta = st["seg"](), st["meta"]
+        U = outs[3] if meta["U"] is None else meta["U"]
+        cov = LazyKernelMatrix(U, None, KernelSpec(outs[1], outs[2].reshape(()), meta["kind"], meta["d_split"]), n_grad_dims=meta["n_grad_dims"])
+        return MultivariateNormal(outs[0], cov)
+
     def __call__(self, *args, **kwargs):
         inputs = [a.unsqueeze(-1) if torch.is_tensor(a) and a.ndimension() == 1 else a for a in args]
         if self.training:
@@ -72,7 +115,8 @@ class ExactGP(GP):
                 raise RuntimeError("train_inputs, train_targets cannot be None in training mode.")
             if not all(ti is x or torch.equal(ti, x) for ti, x in zip(self.train_inputs, inputs)):  # (equal() waits for the GPU)
                 raise RuntimeError("You must train on the training inputs!")
-            return Module.__call__(self, *inputs, **kwargs)
+            out = self._graphed_prior_call(inputs, kwargs)
+            return out if out is not None else Module.__call__(self, *inputs, **kwargs)
         # ---- posterior mode -----------------------------------------------------------------------
         from ..linalg import factorize, predict_from_cache, cross_kernel
 

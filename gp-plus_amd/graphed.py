@@ -40,7 +40,7 @@ def capture_without_gc():
         if was:
             gc.enable()
 
-__all__ = ["GraphedObjective", "GraphedLossAndGrad"]
+__all__ = ["GraphedObjective", "GraphedLossAndGrad", "GraphedSegment"]
 
 
 class GraphedObjective:
@@ -176,3 +176,93 @@ class GraphedLossAndGrad:
         for p, g in zip(self.params, self.grads):
             p.grad = g
         return value
+
+
+# ---------------------------------------------------------------------------------------------------
+# The HOST segments of an evaluation as graphs (round 6; N >= 3840, where the whole evaluation cannot be one graph)
+# ---------------------------------------------------------------------------------------------------
+class GraphedSegment:
+    """A piece of the model's OWN code — ``fn()`` -> tuple of tensors, a function of ``params`` through ordinary PyTorch ops — as two
+    replayed HIP graphs: its forward, and its backward (``torch.autograd.grad`` of the outputs w.r.t. the parameters for given output
+    gradients), tied into autograd by one ``torch.autograd.Function`` node.
+
+    Why: above N = 3840 the factorisation runs on the library's internal streams and does not belong in a graph, so an evaluation
+    through the plain API (``model(*x)``, ``-mll(...)``, ``backward()``: optim/mll_torch.py:114-117) issued ~170 element-wise kernels of
+    3-4 us for the parameter transforms (models/gp_plus.py:243-295), the priors (priors/horseshoe.py:63-66, gpregression.py:84-115), the
+    manifold map and their backward, one Python call each: 0.4 ms of device time and a 0.4 ms gap in front of the next covariance build
+    at C3 (profiles/r05_hbm_probe.txt), the whole cost of an evaluation at small N.  The kernels are the same ones, on the same data,
+    in the same order — the numbers are bitwise those of the eager evaluation — but the host issues four graph launches instead.
+    The outputs live in the graph's static buffers: they are valid until the next replay (the next evaluation of the same model)."""
+
+    def __init__(self, fn: Callable[[], tuple], params: List[torch.nn.Parameter], device):
+        device = torch.device(device)
+        self.params = [p for p in params if p.requires_grad]
+        self.device = device
+
+        def grads_of(outs, gouts):
+            diff = [(o, g) for o, g in zip(outs, gouts) if g is not None]
+            if not diff or not self.params:
+                return [None] * len(self.params)
+            return list(torch.autograd.grad([o for o, _ in diff], self.params, [g for _, g in diff], allow_unused=True))
+
+        side = torch.cuda.Stream(device=device)
+        side.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                outs = fn()
+                grads_of(outs, [torch.zeros_like(o) if o.requires_grad else None for o in outs])
+        torch.cuda.current_stream(device).wait_stream(side)
+        torch.cuda.synchronize(device)
+        self.fwd = torch.cuda.CUDAGraph()
+        with capture_without_gc(), torch.cuda.graph(self.fwd):
+            self.outs = tuple(fn())
+        self.gouts = [torch.zeros_like(o) if o.requires_grad else None for o in self.outs]
+        self.bwd = torch.cuda.CUDAGraph()
+        with capture_without_gc(), torch.cuda.graph(self.bwd, pool=self.fwd.pool()):
+            self.grads = grads_of(self.outs, self.gouts)
+        self.replays = 0
+
+    def __call__(self) -> tuple:
+        """The outputs of this evaluation (autograd-connected to the parameters through ONE node)."""
+        return _SegmentFunction.apply(self, *self.params)
+
+
+class _SegmentFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg: GraphedSegment, *params):
+        seg.fwd.replay()
+        seg.replays += 1
+        ctx.seg = seg
+        outs = tuple(o.detach() for o in seg.outs)
+        ctx.mark_non_differentiable(*[o for o, g in zip(outs, seg.gouts) if g is None])
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gs):
+        seg = ctx.seg
+        for static, g in zip(seg.gouts, gs):
+            if static is None:
+                continue
+            if g is None:
+                static.zero_()
+            else:
+                static.copy_(g)
+        seg.bwd.replay()
+        return (None,) + tuple(None if g is None else g.detach() for g in seg.grads)
+
+
+def segment_key(params, *tensors) -> tuple:
+    """What a captured segment depends on besides the parameters' VALUES: their storage, shape, dtype and requires_grad flags, and
+    the identity of the data tensors it reads."""
+    return (tuple((p.data_ptr(), tuple(p.shape), p.dtype, p.requires_grad) for p in params),
+            tuple((t.data_ptr(), tuple(t.shape), t.dtype) for t in tensors))
+
+
+def segments_apply(n_points: int, device) -> bool:
+    """Graphed host segments are used for evaluations the whole-evaluation graphs do not cover (N >= 3840), on a GPU, with autograd
+    on, outside any capture, and unless ``settings.graphed_segments(False)``."""
+    from . import settings
+
+    device = torch.device(device)
+    return (settings.graphed_segments.value() and device.type == "cuda" and n_points >= LOOKAHEAD_MIN_N and torch.is_grad_enabled()
+            and not torch.cuda.is_current_stream_capturing())

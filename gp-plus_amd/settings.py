@@ -38,6 +38,13 @@ batched_restarts = _Value(True)
 graphed_objective = _Value(True)
 
 
+# Above N = 3840 (where the whole evaluation cannot be one graph) the model's own host code — parameter transforms, manifold map, mean,
+# priors and their backward: ~170 element-wise launches per evaluation — is replayed as HIP graphs around the library's call
+# (gp-plus_amd/graphed.py::GraphedSegment; gpcore/models.py, gpcore/mlls.py).  Same kernels, same numbers.
+# ``with settings.graphed_segments(False):`` issues them one by one, as the reference does.
+graphed_segments = _Value(True)
+
+
 # The reference's scipy driver casts every slice of theta to float32 before loading it into the model (optim/mll_scipy.py:32-35
 # ``tkwargs``, :97 ``torch.from_numpy(param).to(**tkwargs)``), whatever the model's dtype: an fp64 model's L-BFGS trajectory is
 # evaluated at fp32-rounded points.  Off by default (this build keeps the model's dtype);

@@ -258,3 +258,75 @@ def test_two_captured_graphs_on_one_handle_alternate():
         grads = [p.grad for p in m.parameters() if p.grad is not None]
         for g, r in zip(grads, ref[k][1]):
             assert torch.equal(g, r), k
+
+
+# ---------------------------------------------------------------------------------------------------
+# round 6: the host segments of an evaluation above N = 3840 as replayed graphs (graphed.GraphedSegment)
+# ---------------------------------------------------------------------------------------------------
+def _big_model(cfg, n):
+    from gpplus_amd.models import GP_Plus
+    from gpplus_amd.test_functions.baseline_configs import apply_theta, make_config
+
+    X, y, kw, theta = make_config(cfg, n)
+    torch.manual_seed(0)
+    m = GP_Plus(X, y, dtype=torch.float64, device="cuda", **kw)
+    apply_theta(m, theta)
+    m.train()
+    return m
+
+
+def _eval(m):
+    from gpplus_amd.gpcore import ExactMarginalLogLikelihood
+
+    mll = getattr(m, "_test_mll", None)
+    if mll is None:
+        mll = m._test_mll = ExactMarginalLogLikelihood(m.likelihood, m)
+    for p in m.parameters():
+        p.grad = None
+    loss = -mll(m(*m.train_inputs), m.train_targets)
+    loss.backward()
+    return loss.item(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("cfg,n", [("C2", 4096), ("C3", 4200), ("C4", 4500)])
+def test_graphed_host_segments_give_the_eager_numbers(cfg, n):
+    """The plain API above N = 3840 — ``model(*x)``, ``-mll(...)``, ``backward()`` (optim/mll_torch.py:114-117) — with the model's
+    forward and the likelihood / prior terms replayed as graphs against the same calls issued op by op: bitwise the same loss and
+    gradients (same kernels, same data, same order), over parameter updates, and the graphs really replay.  C3: the manifold map
+    (gradients w.r.t. the latent matrix through dMLL/dU); C4: per-source noise and means."""
+    from gpplus_amd import settings
+
+    m = _big_model(cfg, n)
+    with settings.graphed_segments(False):
+        l0, g0 = _eval(m)
+        assert getattr(m, "_prior_segment", None) is None
+    l1, g1 = _eval(m)
+    seg, tail = m._prior_segment["seg"], m._test_mll._tail_segment["seg"]
+    assert seg is not None and tail is not None
+    assert l1 == l0 and set(g0) == set(g1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    # an optimizer moves the parameters in place: the replays read the new values
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=0.05)
+    for _ in range(3):
+        _eval(m)
+        opt.step()
+    r0 = seg.replays
+    l2, g2 = _eval(m)
+    assert seg.replays == r0 + 1 and tail.replays >= 4
+    with settings.graphed_segments(False):
+        l3, g3 = _eval(m)
+    assert l2 == l3 and l2 != l1
+    for k in g2:
+        assert torch.equal(g2[k], g3[k]), k
+    # a parameter that stops being trained is a different segment (the continuation driver freezes the noise)
+    m.likelihood.raw_noise.requires_grad_(False)
+    l4, g4 = _eval(m)
+    assert m._prior_segment["seg"] is not seg and "likelihood.noise_covar.raw_noise" not in g4
+    with settings.graphed_segments(False):
+        l5, g5 = _eval(m)
+    assert l4 == l5 and all(torch.equal(g4[k], g5[k]) for k in g4)
+    # prediction (eval mode) and gradient-free evaluations do not go through the segments
+    m.eval()
+    mean, std = m.predict(m.train_inputs[0][:16], return_std=True)
+    assert torch.isfinite(mean).all() and torch.isfinite(std).all()
