@@ -42,6 +42,11 @@ def capture_without_gc():
 
 __all__ = ["GraphedObjective", "GraphedLossAndGrad", "GraphedSegment"]
 
+import os as _os
+
+#: capture_error_mode of every capture here (experiment knob GPP_CAPTURE_MODE: global / thread_local / relaxed)
+_CAPTURE_MODE = _os.environ.get("GPP_CAPTURE_MODE", "global")
+
 
 class GraphedObjective:
     """``closure()`` -> scalar objective of ``params``; ``evaluate(theta)`` -> (value, gradient) as numpy, or None."""
@@ -88,7 +93,7 @@ class GraphedObjective:
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
-        with capture_without_gc(), torch.cuda.graph(self.graph):
+        with capture_without_gc(), torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
             self.out = body()
         self._lib_scratch = self.gctx._ws  # (same reason: the library's scratch buffer is replaced when a larger one is needed)
         self.last_status = 0
@@ -154,7 +159,7 @@ class GraphedLossAndGrad:
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.graph = torch.cuda.CUDAGraph()
-        with capture_without_gc(), torch.cuda.graph(self.graph):
+        with capture_without_gc(), torch.cuda.graph(self.graph, capture_error_mode=_CAPTURE_MODE):
             self.head, self.grads = body()
         self._lib_scratch = self.gctx._ws
         self.replays = self.declined = 0
@@ -210,15 +215,20 @@ class GraphedSegment:
         with torch.cuda.stream(side):
             for _ in range(3):
                 outs = fn()
-                grads_of(outs, [torch.zeros_like(o) if o.requires_grad else None for o in outs])
+                used = grads_of(outs, [torch.zeros_like(o) if o.requires_grad else None for o in outs])
+                # Only the parameters the segment really depends on are inputs of its autograd node.  (Not a nicety: with a
+                # parameter among the node's inputs that the segment does not use, the NEXT graph capture in the process — while
+                # such a node is alive — dies in hipStreamEndCapture on this stack (ROCm 7.2 / PyTorch 2.10); minimal reproducer
+                # tools/dev/segment_probe.py with DISJOINT=1.)
+                self.params = [p for p, g in zip(self.params, used) if g is not None]
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.fwd = torch.cuda.CUDAGraph()
-        with capture_without_gc(), torch.cuda.graph(self.fwd):
+        with capture_without_gc(), torch.cuda.graph(self.fwd, capture_error_mode=_CAPTURE_MODE):
             self.outs = tuple(fn())
         self.gouts = [torch.zeros_like(o) if o.requires_grad else None for o in self.outs]
         self.bwd = torch.cuda.CUDAGraph()
-        with capture_without_gc(), torch.cuda.graph(self.bwd, pool=self.fwd.pool()):
+        with capture_without_gc(), torch.cuda.graph(self.bwd, pool=self.fwd.pool(), capture_error_mode=_CAPTURE_MODE):
             self.grads = grads_of(self.outs, self.gouts)
         self.replays = 0
 
