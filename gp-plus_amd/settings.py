@@ -42,7 +42,7 @@ graphed_objective = _Value(True)
 # priors and their backward: ~170 element-wise launches per evaluation — is replayed as HIP graphs around the library's call
 # (gp-plus_amd/graphed.py::GraphedSegment; gpcore/models.py, gpcore/mlls.py).  Same kernels, same numbers.
 # ``with settings.graphed_segments(False):`` issues them one by one, as the reference does.
-graphed_segments = _Value(True)
+graphed_segments = _Value(__import__("os").environ.get("GPP_GRAPHED_SEGMENTS", "1") not in ("", "0"))  # (the variable: A/B runs of tools/)
 
 
 # The reference's scipy driver casts every slice of theta to float32 before loading it into the model (optim/mll_scipy.py:32-35
