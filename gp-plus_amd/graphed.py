@@ -230,12 +230,8 @@ class GraphedSegment:
         self.bwd = torch.cuda.CUDAGraph()
         with capture_without_gc(), torch.cuda.graph(self.bwd, pool=self.fwd.pool(), capture_error_mode=_CAPTURE_MODE):
             self.grads = grads_of(self.outs, self.gouts)
-        # Both graphs exist: the autograd graph recorded during the capture is no longer needed — and must go.  It keeps the
-        # parameters' AccumulateGrad nodes alive, which were created on the capture stream; every later backward through this
-        # segment would then accumulate p.grad ON THAT STREAM (PyTorch warns: "The AccumulateGrad node's stream does not match ..."),
-        # and a second active stream is what perturbs the factorisation's hardware-queue mapping (measured: +2 ms at C2, see
-        # linalg._forward's note on side streams).  The activations the backward graph reads stay in the graphs' private pool.
-        self.outs = tuple(o.detach() for o in self.outs)
+        # (The captured autograd graph stays alive: the backward graph replays into the activations it holds.  Its AccumulateGrad
+        #  nodes live on the capture stream — the cost of that is in settings.graphed_segments' note.)
         self.replays = 0
 
     def __call__(self) -> tuple:
@@ -275,8 +271,8 @@ def segment_key(params, *tensors) -> tuple:
 
 
 def segments_apply(n_points: int, device) -> bool:
-    """Graphed host segments are used for evaluations the whole-evaluation graphs do not cover (N >= 3840), on a GPU, with autograd
-    on, outside any capture, and unless ``settings.graphed_segments(False)``."""
+    """Graphed host segments apply to evaluations the whole-evaluation graphs do not cover (N >= 3840), on a GPU, with autograd on,
+    outside any capture — when ``settings.graphed_segments`` is on (default off: measured slower, see there)."""
     from . import settings
 
     device = torch.device(device)

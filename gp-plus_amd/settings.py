@@ -39,10 +39,16 @@ graphed_objective = _Value(True)
 
 
 # Above N = 3840 (where the whole evaluation cannot be one graph) the model's own host code — parameter transforms, manifold map, mean,
-# priors and their backward: ~170 element-wise launches per evaluation — is replayed as HIP graphs around the library's call
-# (gp-plus_amd/graphed.py::GraphedSegment; gpcore/models.py, gpcore/mlls.py).  Same kernels, same numbers.
-# ``with settings.graphed_segments(False):`` issues them one by one, as the reference does.
-graphed_segments = _Value(__import__("os").environ.get("GPP_GRAPHED_SEGMENTS", "1") not in ("", "0"))  # (the variable: A/B runs of tools/)
+# priors and their backward: 130 (C1) to 172 (C3) element-wise launches per evaluation, gpurun census of round 6 — CAN be replayed as
+# HIP graphs around the library's call (gp-plus_amd/graphed.py::GraphedSegment; gpcore/models.py, gpcore/mlls.py): same kernels, the
+# same numbers bit for bit (tests/test_gpu_graphed.py).  OFF by default: measured on one box, twice each, it LOSES — C3 20.42-20.50
+# -> 20.67 ms, C4 57.97-58.02 -> 59.48, C2 127.95-127.98 -> 129.89 — because the parameters' AccumulateGrad nodes of a captured
+# autograd graph live on the capture stream, so every later backward accumulates p.grad on a SECOND stream, and a second active
+# stream is what perturbs the hardware-queue mapping of the factorisation's streams (the effect linalg._forward documents for side
+# streams; PyTorch's own warning: "The AccumulateGrad node's stream does not match ...").  Creating those nodes on the caller's
+# stream first breaks the capture; dropping the captured autograd graph frees memory its backward graph replays into (both crash).
+# ``with settings.graphed_segments(True):`` (or GPP_GRAPHED_SEGMENTS=1) switches it on.
+graphed_segments = _Value(__import__("os").environ.get("GPP_GRAPHED_SEGMENTS", "0") not in ("", "0"))
 
 
 # The reference's scipy driver casts every slice of theta to float32 before loading it into the model (optim/mll_scipy.py:32-35

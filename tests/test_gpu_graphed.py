@@ -300,9 +300,11 @@ def test_graphed_host_segments_give_the_eager_numbers(cfg, n):
     from gpplus_amd import settings
 
     m = _big_model(cfg, n)
-    with settings.graphed_segments(False):
-        l0, g0 = _eval(m)
-        assert getattr(m, "_prior_segment", None) is None
+    l0, g0 = _eval(m)  # (the default: off — measured slower on this stack, see settings.graphed_segments)
+    assert getattr(m, "_prior_segment", None) is None
+    ctx_on = settings.graphed_segments(True)
+    ctx_on.__enter__()
+    request_off = lambda: settings.graphed_segments(False)  # noqa: E731
     l1, g1 = _eval(m)
     seg, tail = m._prior_segment["seg"], _MLLS[id(m)]._tail_segment["seg"]
     assert seg is not None and tail is not None
@@ -317,7 +319,7 @@ def test_graphed_host_segments_give_the_eager_numbers(cfg, n):
     r0 = seg.replays
     l2, g2 = _eval(m)
     assert seg.replays == r0 + 1 and tail.replays >= 4
-    with settings.graphed_segments(False):
+    with request_off():
         l3, g3 = _eval(m)
     assert l2 == l3 and l2 != l1
     for k in g2:
@@ -326,10 +328,11 @@ def test_graphed_host_segments_give_the_eager_numbers(cfg, n):
     m.likelihood.raw_noise.requires_grad_(False)
     l4, g4 = _eval(m)
     assert m._prior_segment["seg"] is not seg and "likelihood.noise_covar.raw_noise" not in g4
-    with settings.graphed_segments(False):
+    with request_off():
         l5, g5 = _eval(m)
     assert l4 == l5 and all(torch.equal(g4[k], g5[k]) for k in g4)
     # prediction (eval mode) and gradient-free evaluations do not go through the segments
     m.eval()
     mean, std = m.predict(m.train_inputs[0][:16], return_std=True)
     assert torch.isfinite(mean).all() and torch.isfinite(std).all()
+    ctx_on.__exit__(None, None, None)
