@@ -294,45 +294,43 @@ def _eval(m):
 @pytest.mark.parametrize("cfg,n", [("C2", 4096), ("C3", 4200), ("C4", 4500)])
 def test_graphed_host_segments_give_the_eager_numbers(cfg, n):
     """The plain API above N = 3840 — ``model(*x)``, ``-mll(...)``, ``backward()`` (optim/mll_torch.py:114-117) — with the model's
-    forward and the likelihood / prior terms replayed as graphs against the same calls issued op by op: bitwise the same loss and
-    gradients (same kernels, same data, same order), over parameter updates, and the graphs really replay.  C3: the manifold map
-    (gradients w.r.t. the latent matrix through dMLL/dU); C4: per-source noise and means."""
+    forward and the likelihood / prior terms replayed as graphs (``settings.graphed_segments(True)``; off by default: measured
+    slower on this stack) against the same calls issued op by op: bitwise the same loss and gradients (same kernels, same data,
+    same order), over parameter updates, and the graphs really replay.  C3: the manifold map (gradients w.r.t. the latent matrix
+    through dMLL/dU); C4: per-source noise and means."""
     from gpplus_amd import settings
 
     m = _big_model(cfg, n)
-    l0, g0 = _eval(m)  # (the default: off — measured slower on this stack, see settings.graphed_segments)
-    assert getattr(m, "_prior_segment", None) is None
-    ctx_on = settings.graphed_segments(True)
-    ctx_on.__enter__()
-    request_off = lambda: settings.graphed_segments(False)  # noqa: E731
-    l1, g1 = _eval(m)
-    seg, tail = m._prior_segment["seg"], _MLLS[id(m)]._tail_segment["seg"]
-    assert seg is not None and tail is not None
-    assert l1 == l0 and set(g0) == set(g1)
-    for k in g0:
-        assert torch.equal(g0[k], g1[k]), k
-    # an optimizer moves the parameters in place: the replays read the new values
-    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=0.05)
-    for _ in range(3):
-        _eval(m)
-        opt.step()
-    r0 = seg.replays
-    l2, g2 = _eval(m)
-    assert seg.replays == r0 + 1 and tail.replays >= 4
-    with request_off():
-        l3, g3 = _eval(m)
-    assert l2 == l3 and l2 != l1
-    for k in g2:
-        assert torch.equal(g2[k], g3[k]), k
-    # a parameter that stops being trained is a different segment (the continuation driver freezes the noise)
-    m.likelihood.raw_noise.requires_grad_(False)
-    l4, g4 = _eval(m)
-    assert m._prior_segment["seg"] is not seg and "likelihood.noise_covar.raw_noise" not in g4
-    with request_off():
-        l5, g5 = _eval(m)
-    assert l4 == l5 and all(torch.equal(g4[k], g5[k]) for k in g4)
-    # prediction (eval mode) and gradient-free evaluations do not go through the segments
-    m.eval()
-    mean, std = m.predict(m.train_inputs[0][:16], return_std=True)
-    assert torch.isfinite(mean).all() and torch.isfinite(std).all()
-    ctx_on.__exit__(None, None, None)
+    l0, g0 = _eval(m)
+    assert getattr(m, "_prior_segment", None) is None  # (the default is off)
+    with settings.graphed_segments(True):
+        l1, g1 = _eval(m)
+        seg, tail = m._prior_segment["seg"], _MLLS[id(m)]._tail_segment["seg"]
+        assert seg is not None and tail is not None
+        assert l1 == l0 and set(g0) == set(g1)
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
+        # an optimizer moves the parameters in place: the replays read the new values
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=0.05)
+        for _ in range(3):
+            _eval(m)
+            opt.step()
+        r0 = seg.replays
+        l2, g2 = _eval(m)
+        assert seg.replays == r0 + 1 and tail.replays >= 4
+        with settings.graphed_segments(False):
+            l3, g3 = _eval(m)
+        assert l2 == l3 and l2 != l1
+        for k in g2:
+            assert torch.equal(g2[k], g3[k]), k
+        # a parameter that stops being trained is a different segment (the continuation driver freezes the noise)
+        m.likelihood.raw_noise.requires_grad_(False)
+        l4, g4 = _eval(m)
+        assert m._prior_segment["seg"] is not seg and "likelihood.noise_covar.raw_noise" not in g4
+        with settings.graphed_segments(False):
+            l5, g5 = _eval(m)
+        assert l4 == l5 and all(torch.equal(g4[k], g5[k]) for k in g4)
+        # prediction (eval mode) and gradient-free evaluations do not go through the segments
+        m.eval()
+        mean, std = m.predict(m.train_inputs[0][:16], return_std=True)
+        assert torch.isfinite(mean).all() and torch.isfinite(std).all()
