@@ -166,10 +166,6 @@ class ShardedWorkspace:
         self.Tk = torch.empty((nb, nb), dtype=torch.float64, device=dev)       # scratch of a diagonal block's factorisation
         self.ld = self.A.stride(0)
         self.pack = torch.empty(N * nb, dtype=torch.float64, device=dev)       # the packed tail of a row slab of the factor
-        # two buffers of one PIECE of a tail each (gpp_shard_piece_cols in gpp.h): a piece is packed / unpacked while its neighbour
-        # is on the wire (_factor_list); None when the tail travels as one piece
-        wpiece = int(ctx.lib.gpp_shard_piece_cols())
-        self.pack2 = None if wpiece <= 0 or world <= 1 else [torch.empty(min(wpiece, N) * nb, dtype=torch.float64, device=dev) for _ in range(2)]
         self.hbuf = torch.empty(3 * nb * nb, dtype=torch.float64, device=dev)  # its packed head: diagonal block, block k+1, inverse
         self.comm_stream = torch.cuda.Stream(device=dev)
         self.copy_stream = torch.cuda.Stream(device=dev)
@@ -441,8 +437,6 @@ def _mirror_beside(world: int) -> bool:
     if _MIRROR_ENV != "":
         return _MIRROR_ENV != "0"
     return world <= 1
-#: pack / unpack the tail's pieces on the copy stream through two buffers (default; GPP_SHARD_PIPELINE=0: on the communication stream)
-_PIPELINE_PIECES = os.environ.get("GPP_SHARD_PIPELINE", "1") not in ("", "0")
 #: evaluations whose factorisation + forward sweep ran as a ticket list (tests)
 LIST_EVALS = 0
 BACK_LIST_EVALS = 0
@@ -476,10 +470,6 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
     if not ctx.shard_list_begin(N, nb, me, P, A, ws.Kc, ws.Lc, ws.D, ws.W2, ws.info[0:1], _LIST_WORKERS):
         return None
     arrived = {}  # per block row of another rank: the event behind its unpacked tail
-    # the tail's pieces through two buffers with packing / unpacking on the copy stream — when that stream is free (the mirror is
-    # written behind the list, i.e. several ranks) and the pieces are small enough for two of them
-    pipelined = comm.travel and not _mirror_beside(P) and _PIPELINE_PIECES and ws.pack2 is not None
-    buf_free, npiece = [None, None], 0
     try:
         if comm.travel:
             with torch.cuda.stream(cs):
@@ -503,40 +493,6 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
                     # the tail in pieces (round 6; gpp_shard_piece_cols in gpp.h): the list's tasks wait for the piece of the column
                     # tile they read, so the next owner's first piece is updated, solved and sent while the rest of this row travels
                     for g, (c0, c1) in enumerate(ctx.shard_messages(N, nb, k)[1:]):
-                        if pipelined:
-                            # Two message buffers; packing (behind the piece's gate) and unpacking (in front of its signal) run on
-                            # the copy stream, so the communication stream carries broadcasts back to back: at C5 on 8 virtual ranks a
-                            # 67 MB piece cost its stream 0.35 ms of packing or 0.2 ms of unpacking on top of 0.96 ms on the wire
-                            # at 70 GB/s (tools/replay_rank.py, profiles/r06_virtual_rank.txt).
-                            b = npiece % 2
-                            npiece += 1
-                            flat = ws.pack2[b][:nbk * (c1 - c0)]
-                            tail = flat.view(nbk, c1 - c0)
-                            if own:
-                                with torch.cuda.stream(cpy):
-                                    if buf_free[b] is not None:
-                                        cpy.wait_event(buf_free[b])
-                                    ctx.shard_list_gate(cpy, 1 + g, k)
-                                    tail.copy_(A[o:o1, c0:c1])
-                                    packed = torch.cuda.Event()
-                                    packed.record(cpy)
-                                cs.wait_event(packed)
-                                comm.bcast(flat, k % P)
-                                buf_free[b] = torch.cuda.Event()
-                                buf_free[b].record(cs)
-                            else:
-                                if buf_free[b] is not None:
-                                    cs.wait_event(buf_free[b])
-                                comm.bcast(flat, k % P)
-                                received = torch.cuda.Event()
-                                received.record(cs)
-                                with torch.cuda.stream(cpy):
-                                    cpy.wait_event(received)
-                                    A[o:o1, c0:c1].copy_(tail)
-                                    ctx.shard_list_signal(cpy, 1 + g, k)
-                                    buf_free[b] = torch.cuda.Event()
-                                    buf_free[b].record(cpy)
-                            continue
                         tail = ws.pack[:nbk * (c1 - c0)].view(nbk, c1 - c0)
                         if own:
                             ctx.shard_list_gate(cs, 1 + g, k)
@@ -545,7 +501,7 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
                         if not own:
                             A[o:o1, c0:c1].copy_(tail)
                             ctx.shard_list_signal(cs, 1 + g, k)
-                    if not own and not pipelined:
+                    if not own:
                         arrived[k] = torch.cuda.Event()
                         arrived[k].record(cs)
         # Beside the list, on a stream of its own: the factor's mirror L = U^T into A's strict lower triangle, which the

@@ -173,8 +173,6 @@ class Replay:
         if not ctx.shard_list_begin(N, nb, r, P, A, ws.Kc, ws.Lc, ws.D, ws.W2, ws.info[0:1], 0):
             raise RuntimeError("the ticket list does not apply to this size / block height")
         arrived = {}
-        pipelined = not sharded._mirror_beside(P) and sharded._PIPELINE_PIECES and ws.pack2 is not None
-        buf_free, npiece = [None, None], 0
         try:
             with torch.cuda.stream(cs):
                 for k in range(nblk):
@@ -200,37 +198,6 @@ class Replay:
                         self._stamp(cs, slot(k, 0, 3))
                         ctx.shard_list_signal(cs, 0, k)
                     for g, (c0, c1) in enumerate(ctx.shard_messages(N, nb, k)[1:]):  # the tail's pieces
-                        if pipelined:  # (as sharded._factor_list: two buffers, packing / unpacking on the copy stream)
-                            b = npiece % 2
-                            npiece += 1
-                            tail = ws.pack2[b][:nbk * (c1 - c0)].view(nbk, c1 - c0)
-                            if own:
-                                with torch.cuda.stream(cpy):
-                                    if buf_free[b] is not None:
-                                        cpy.wait_event(buf_free[b])
-                                    ctx.shard_list_gate(cpy, 1 + g, k)
-                                    tail.copy_(A[o:o1, c0:c1])
-                                    packed = torch.cuda.Event()
-                                    packed.record(cpy)
-                                cs.wait_event(packed)
-                                self._stamp(cs, slot(k, 1 + g, 0))  # (ready = packed and the stream free)
-                                self._rcopy(cs, self.sink[:tail.numel()].view_as(tail), tail, rate, -1, slot(k, 1 + g, 1))
-                                buf_free[b] = torch.cuda.Event()
-                                buf_free[b].record(cs)
-                            else:
-                                if buf_free[b] is not None:
-                                    cs.wait_event(buf_free[b])
-                                self._rcopy(cs, tail, self.Aref[o:o1, c0:c1], rate, ready[(k, 1 + g)] / TICK_US, slot(k, 1 + g, 1))
-                                received = torch.cuda.Event()
-                                received.record(cs)
-                                with torch.cuda.stream(cpy):
-                                    cpy.wait_event(received)
-                                    A[o:o1, c0:c1].copy_(tail)
-                                    self._stamp(cpy, slot(k, 1 + g, 3))
-                                    ctx.shard_list_signal(cpy, 1 + g, k)
-                                    buf_free[b] = torch.cuda.Event()
-                                    buf_free[b].record(cpy)
-                            continue
                         tail = ws.pack[:nbk * (c1 - c0)].view(nbk, c1 - c0)
                         if own:
                             ctx.shard_list_gate(cs, 1 + g, k)
@@ -242,7 +209,7 @@ class Replay:
                             A[o:o1, c0:c1].copy_(tail)
                             self._stamp(cs, slot(k, 1 + g, 3))
                             ctx.shard_list_signal(cs, 1 + g, k)
-                    if not own and not pipelined:
+                    if not own:
                         arrived[k] = torch.cuda.Event()
                         arrived[k].record(cs)
             with torch.cuda.stream(cpy):  # the factor's mirror beside the list, as sharded.py writes it
@@ -454,8 +421,7 @@ def main():
     print(f"  single-GPU factor + inverse (the reference the other ranks' block rows are taken from): {rp.ref_factor_inverse_ms:.1f} ms; "
           f"tail pieces of {int(rp.ctx.lib.gpp_shard_piece_cols()) or n} columns (up to {rp.M - 1} per block row); "
           f"GPP_SHARD_FILL = {os.environ.get('GPP_SHARD_FILL', 'default (one filler work-group per panel CU)')}; the factor's mirror "
-          f"{'beside' if sharded._mirror_beside(args.P) else 'behind'} the list; pieces packed / unpacked "
-          f"{'on the copy stream (two buffers)' if (sharded._PIPELINE_PIECES and not sharded._mirror_beside(args.P)) else 'on the communication stream'}", flush=True)
+          f"{'beside' if sharded._mirror_beside(args.P) else 'behind'} the list", flush=True)
     out = {"N": n, "d": int(U.shape[1]), "P": args.P, "nb": args.nb, "library": rp.ctx.lib.gpp_version().decode(), "rates": []}
     t0 = time.perf_counter()
     zero = rp.zero_ready()
