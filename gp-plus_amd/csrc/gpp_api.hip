@@ -267,7 +267,7 @@ hipError_t ensure_streams(gpp_handle_s* h) {
     if (ncu >= 4 * PANEL_CUS && ncu <= 1024 && PANEL_CUS > 0 && !getenv("GPP_NO_CU_SPLIT")) {
       uint32_t mp[32] = {0}, mu[32] = {0};
       const int words = (ncu + 31) / 32;
-      // The FIRST mask bits.  Measured (tools/gemm_update_probe.py with GPP_GEMM_ON_UPD=1): a K = 1024 trailing update runs
+      // The FIRST mask bits.  Measured (tools/attic/gemm_update_probe.py with GPP_GEMM_ON_UPD=1): a K = 1024 trailing update runs
       // at 62.3 TFLOP/s on all 256 CUs and at 54.3 / 54.8 / 54.7 with 2 / 16 / 32 CUs masked out — the loss is a step of
       // 12.5 %, not proportional.  Consecutive mask bits fall in different XCDs and then in different shader engines of an
       // XCD; work-groups are dealt round-robin to XCDs and to their 4 shader engines regardless of the CUs each has left, so
@@ -657,7 +657,7 @@ hipError_t dag_abort(gpp_handle_s* h, const DagPlan* P) {
 hipError_t potrf_dag(gpp_handle_s* h, const Ctx& cm, int64_t N, double* T, int64_t ldt, bool* used) {
   *used = false;
   static const bool dag_env = !(getenv("GPP_DAG_SCHED") && atoi(getenv("GPP_DAG_SCHED")) == 0);
-  // Measured on one box, potrf + inverse (tools/sweep_dag.sh, profiles/r05_dag_sweep.txt): launches win below ~6900 rows, where the
+  // Measured on one box, potrf + inverse (tools/attic/sweep_dag.sh, profiles/r05_dag_sweep.txt): launches win below ~6900 rows, where the
   // chain of diagonal blocks is all there is (4.99 vs 5.39 ms at 6144), the ticket list from there (6.35 vs 6.82 at 7168, 8.05 vs
   // 9.16 at 8192, 13.45 vs 15.68 at 10 000, 18.14 vs 20.46 at 11 264).  With the inverse inside the list up to ~19 000 rows (22.64 vs
   // 24.73 at 12 288, 40.19 vs 41.97 at 15 000); above, the inverse's K = 1024 tiles on 503 slots lose to gpp_trtri's long-K launches on
@@ -1717,8 +1717,8 @@ int gpp_gemm(gpp_handle_t h, int transA, int transB, int64_t M, int64_t N, int64
   GemmArgs g = mk(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta);
   g.a_mask = a_mask; g.b_mask = b_mask; g.klo_mode = klo_mode; g.khi_mode = khi_mode; g.c_lower = c_tri;
   int ftm = 0, ftn = 0;
-  if (const char* e = getenv("GPP_GEMM_TILE")) sscanf(e, "%d,%d", &ftm, &ftn);  // dev knob (tools/gemm_small_probe.py)
-  if (getenv("GPP_GEMM_ON_UPD")) {  // dev knob (tools/gemm_update_probe.py): run on the CU-masked update stream
+  if (const char* e = getenv("GPP_GEMM_TILE")) sscanf(e, "%d,%d", &ftm, &ftn);  // dev knob (tools/attic/gemm_small_probe.py)
+  if (getenv("GPP_GEMM_ON_UPD")) {  // dev knob (tools/attic/gemm_update_probe.py): run on the CU-masked update stream
     GPP_TRY(ensure_streams(h));
     hipEvent_t a = next_event(h), b = next_event(h);
     GPP_TRY(hipEventRecord(a, h->stream));

@@ -7,7 +7,7 @@
 //   - V = K_*N Linv^T of the prediction path (models/gpregression.py:122-149).
 //
 // Design (CDNA4, measured on MI355X): v_mfma_f64_16x16x4_f64 — lane l supplies A[row l%16][k l/16] and B[k l/16][col l%16] and
-// holds D[row (l/16) + 4v][col l%16] in element v of its 4-double accumulator (tools/mfma16_layout.hip).  A bare loop of the
+// holds D[row (l/16) + 4v][col l%16] in element v of its 4-double accumulator (tools/attic/mfma16_layout.hip).  A bare loop of the
 // instruction sustains 69.6 TFLOP/s chip-wide, the rate rocBLAS's MI16x16x4 DGEMM kernels reach too (72.9); the round-1 kernel
 // used the 4x4x4_4b form on the strength of a probe that had measured hipcc's AGPR copies (profiles/r02_mfma_f64_16x16x4.txt).
 // A (2*WT)^2 output tile per 256-thread work-group, 2x2 waves; each wave owns WT x WT = (WT/16)^2 blocks of 16 x 16
@@ -237,7 +237,7 @@ __device__ __forceinline__ void gemm_tile(const P& p, const int tm, const int tn
   const int nch = khi > klo ? (khi - klo + BK - 1) / BK : 0;
 
   // accumulators: acc4[a4][b] element v is C[row0 + wm + 16 a4 + 4 v + (l>>4)][col0 + wn + 16 b + (l&15)] — the 16 x 16 result
-  // block of v_mfma_f64_16x16x4_f64 (lane l, element v: row (l>>4) + 4 v, column l&15; tools/mfma16_layout.hip)
+  // block of v_mfma_f64_16x16x4_f64 (lane l, element v: row (l>>4) + 4 v, column l&15; tools/attic/mfma16_layout.hip)
   static_assert(RB % 4 == 0, "wave tile rows must be a multiple of 16");
   v4d acc4[RB / 4][CB];
 #pragma unroll

@@ -67,7 +67,7 @@ constexpr int GPP_PANEL_CAP_RING = 16;
 // k ln2_hi exact), e^r by a degree-12 Horner polynomial on |r| <= ln2 / 2 (truncation 1.7e-16), scaled by 2^k with v_ldexp_f64
 // (exact down to the denormals).  ~19 fp64 instructions and no branches against ~55 instructions (range checks, special cases for
 // positive / huge arguments, constants re-materialised per call) of the general-purpose library exp, which made the N^2
-// kernels VALU-bound instead of HBM-bound.  Max error 2 ulp on [-745, 0] (tools/exp_check.py); NaN propagates; x < -800 -> 0.
+// kernels VALU-bound instead of HBM-bound.  Max error 2 ulp on [-745, 0] (tools/attic/exp_check.py); NaN propagates; x < -800 -> 0.
 #ifdef __HIPCC__
 // The constants live in SGPRs for the whole kernel (wave-uniform; one constant-bus operand per v_fma_f64): left to itself the
 // compiler re-materialises each coefficient in a VGPR pair per use (two v_mov_b32 in front of every v_fmac_f64, ~26 per call —

@@ -2,7 +2,7 @@
 // factor inside ONE work-group, with the block held in MFMA accumulator registers and LDS.  Replaces the unblocked
 // LAPACK potf2/trti2 steps inside torch.linalg.cholesky_ex (reference call site: gpytorch psd_safe_cholesky reached
 // from optim/mll_torch.py:116).  It runs N/128 times per factorisation on a latency-bound chain, so it is latency-tuned
-// (tools/leaf_probe.hip prints its per-phase cycle counts).
+// (tools/attic/leaf_probe.hip prints its per-phase cycle counts).
 //
 //   in : A[n x n], UPPER triangle read (A = U^T U with U stored row-major = L stored column-major; the strict lower
 //        triangle is never touched).  Internally the kernel works on L = U^T: every access to A swaps its indices.
@@ -29,7 +29,7 @@
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef double v2d __attribute__((ext_vector_type(2)));
 
-// Phase stamps for tools/leaf_probe.hip only (the product build defines nothing and the macro vanishes).
+// Phase stamps for tools/attic/leaf_probe.hip only (the product build defines nothing and the macro vanishes).
 #ifdef GPP_LEAF_STAMP
 __device__ unsigned long long g_leaf_stamps[64];
 #define STAMP(i)                                                                   \
@@ -425,7 +425,7 @@ __global__ __launch_bounds__(256) void gpp_leaf_potrf_inv(double* __restrict__ A
 // The leaf-step factorisation of a diagonal block (potrf_blk in gpp_api.hip) is a chain of 3 launches per 128 rows — leaf, panel
 // solve, rank-128 update — followed by the pair merges of the block's inverse: at 1024 rows 8 x (45 + ~32) us + ~200 us, of which
 // only the leaves are inherently serial.  Here ONE work-group runs the leaves back to back and the others do everything else in
-// 128 x 32 strips, handing results over through flags in device memory (release / acquire at agent scope: tools/flag_probe.hip
+// 128 x 32 strips, handing results over through flags in device memory (release / acquire at agent scope: tools/attic/flag_probe.hip
 // measures 0.8 us per hand-off on an idle chip, ~4 us beside a kernel that saturates the memory system — a launch gap is 3-12):
 //   chain work-group : for j = 0 .. C-1:  wait until tile (j,j) has its update from row j-1;  leaf(j) -> U_jj, inv(L_jj);  publish
 //   factor strip (c,q), c = 1 .. C-1, q = 0 .. 3 (columns 32 q .. 32 q + 31 of tile column c), for j = 0 .. c-1:
@@ -451,7 +451,7 @@ constexpr int PBK = 16;                           // k rows per staged chunk
 constexpr int PLDA = 128 + 16, PLDB = 32 + 16;    // LDS row strides (doubles): two consecutive k rows fall in different bank halves
 constexpr int P_BUF = PBK * (PLDA + PLDB);        // one staged chunk of both operands; two of them: 48 KiB, less than the leaf's image
 
-// Phase stamps of the chain and of the strip that feeds the next leaf (tools/panel_stamps.py; a probe build only).
+// Phase stamps of the chain and of the strip that feeds the next leaf (tools/attic/panel_stamps.py; a probe build only).
 #ifdef GPP_PANEL_STAMP
 __device__ unsigned long long g_panel_stamps[512];
 #define PSTAMP(i)                                                                   \

@@ -219,7 +219,7 @@ class GraphedSegment:
                 # Only the parameters the segment really depends on are inputs of its autograd node.  (Not a nicety: with a
                 # parameter among the node's inputs that the segment does not use, the NEXT graph capture in the process — while
                 # such a node is alive — dies in hipStreamEndCapture on this stack (ROCm 7.2 / PyTorch 2.10); minimal reproducer
-                # tools/dev/segment_probe.py with DISJOINT=1.)
+                # tools/attic/dev/segment_probe.py with DISJOINT=1.)
                 self.params = [p for p, g in zip(self.params, used) if g is not None]
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)

@@ -239,7 +239,7 @@ class ExactMLLFunction(torch.autograd.Function):
                 return
             # (Measured and NOT adopted: z, the MLL scalars and alpha on a side stream beside the LAUUM launch — the extra
             #  stream perturbs the hardware-queue mapping of the NEXT evaluation's factorisation DAG: potrf 53.3 -> 58-60 ms,
-            #  137 -> 142-144 ms per evaluation at N = 20000, tools/side_ab.py.)
+            #  137 -> 142-144 ms per evaluation at N = 20000, tools/attic/side_ab.py.)
             with _stage("alpha"):
                 gctx.alpha(ws.Li, ws.z, ws.alpha)
             with _stage("lauum"):

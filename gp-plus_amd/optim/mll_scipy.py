@@ -158,7 +158,7 @@ def _fit_model_from_state(likobj, theta0, jac, options, method='L-BFGS-B', const
         # frames of the failed evaluation (the autograd Function's forward, its tensors, its context) would stay alive with it, and
         # with them alive the NEXT HIP-graph capture on this stack dies in hipStreamEndCapture (round 6: found by the continuation
         # driver, whose level below the noise bound fails by design and is followed by more fits; minimal reproducer
-        # tools/dev/capture_bisect.py — `fun_keep_exc` crashes, `keep_no_tb` does not).
+        # tools/attic/dev/capture_bisect.py — `fun_keep_exc` crashes, `keep_no_tb` does not).
         return e.with_traceback(None)
 
 

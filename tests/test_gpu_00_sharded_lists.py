@@ -2,7 +2,7 @@
 DAG_SHARD / DAG_BACK) with 1-4 ranks.  On the 1-GPU test box the ranks share the GPU, and their persistent executors wait for each
 other's messages: that needs every rank's queues mapped on the hardware AT THE SAME TIME.  One more process with a GPU context —
 the pytest process itself once an in-process GPU test has run — oversubscribes the hardware queues, the scheduler then time-slices
-PROCESSES, and every message costs a time slice (measured: a 4 s test stalls past a 60 s budget; tools/dev/w3_parent.sh).  So this
+PROCESSES, and every message costs a time slice (measured: a 4 s test stalls past a 60 s budget; tools/attic/dev/w3_parent.sh).  So this
 file sorts in front of the in-process GPU tests and initialises nothing on the GPU itself.  (One process per GPU, the deployment, has
 no such neighbour.)  The lists' logic is verified for any interleaving on the host (tests/test_host_cpu.py)."""
 import pytest

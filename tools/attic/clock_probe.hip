@@ -1,6 +1,6 @@
 // What core clock does the chip hold while the dominant GEMM launch (LAUUM at N = 20000) runs?  A one-wave sampler kernel
 // reads s_memtime (core clock) and s_memrealtime (100 MHz) every ~50 us on its own stream while gpp_lauum runs on another;
-// prints the clock per millisecond.  Dev tool: hipcc --offload-arch=gfx950 -O2 tools/clock_probe.hip -Iinclude
+// prints the clock per millisecond.  Dev tool: hipcc --offload-arch=gfx950 -O2 tools/attic/clock_probe.hip -Iinclude
 //   -Lgp-plus_amd -lgpp_hip -Wl,-rpath,$PWD/gp-plus_amd -o /tmp/clock_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>

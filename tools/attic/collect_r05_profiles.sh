@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-5 profile collection on the GPU box (run through gpurun from the repo root).  Writes gpurun_out/r5prof/; the summaries are
-# then copied into profiles/r05_* (tools/publish_r05_profiles.sh).  Counter passes are separate runs with --kernel-trace only.
+# then copied into profiles/r05_* (tools/attic/publish_r05_profiles.sh).  Counter passes are separate runs with --kernel-trace only.
 set -u
 OUT=gpurun_out/r5prof
 mkdir -p $OUT

@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev: how often does the pure-C program hang?  usage: tools/dev/c_prog_loop.sh REPS [N]
+# dev: how often does the pure-C program hang?  usage: tools/attic/dev/c_prog_loop.sh REPS [N]
 cd examples/shard_eval_c && make >/dev/null 2>&1
 export GPP_SHARD_TIMEOUT_MS=8000 AMD_LOG_LEVEL=${AMD_LOG_LEVEL:-0}
 ok=0; hung=0; other=0

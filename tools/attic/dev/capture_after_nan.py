@@ -1,4 +1,4 @@
-"""A graph capture after an evaluation that failed with NanError: does it crash?  usage: python tools/dev/capture_after_nan.py MODE
+"""A graph capture after an evaluation that failed with NanError: does it crash?  usage: python tools/attic/dev/capture_after_nan.py MODE
 MODE: nan_graph (NaN point through the graphed objective's warm-up), nan_eager (NaN point with graphs off), none"""
 import faulthandler, os, sys
 faulthandler.enable()

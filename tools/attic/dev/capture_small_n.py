@@ -1,4 +1,4 @@
-"""Does the graphed scipy objective capture at small N?  usage: python tools/dev/capture_small_n.py N [d]"""
+"""Does the graphed scipy objective capture at small N?  usage: python tools/attic/dev/capture_small_n.py N [d]"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -1,6 +1,6 @@
 """Do kernels of two PROCESSES run concurrently on one GPU here?  Each of two processes spins one wave for ~T seconds (torch.cuda._sleep)
 behind a file barrier; concurrent: both finish after ~T, serialised: the second after ~2T.  Then the same with a spin of many
-work-groups (a large elementwise kernel repeated) to see time-slicing.  usage: python tools/dev/co_run_probe.py"""
+work-groups (a large elementwise kernel repeated) to see time-slicing.  usage: python tools/attic/dev/co_run_probe.py"""
 import os, subprocess, sys, time
 
 CHILD = r'''

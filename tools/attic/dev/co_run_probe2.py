@@ -1,5 +1,5 @@
 """While one process's sharded ticket list (rank 1 of 2: its executor spins, waiting for a message that never comes, until
-GPP_SHARD_TIMEOUT_MS) holds the GPU, what can ANOTHER process run?  usage: python tools/dev/co_run_probe2.py"""
+GPP_SHARD_TIMEOUT_MS) holds the GPU, what can ANOTHER process run?  usage: python tools/attic/dev/co_run_probe2.py"""
 import os, subprocess, sys, time, tempfile
 
 SPINNER = r'''

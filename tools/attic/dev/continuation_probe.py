@@ -1,4 +1,4 @@
-"""usage: python tools/dev/continuation_probe.py N num_restarts [maxiter]"""
+"""usage: python tools/attic/dev/continuation_probe.py N num_restarts [maxiter]"""
 import faulthandler, os, sys
 faulthandler.enable()
 import numpy as np, torch

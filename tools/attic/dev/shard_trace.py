@@ -1,4 +1,4 @@
-"""Per-task trace of the sharded ticket lists at one rank (dev): python tools/dev/shard_trace.py N [which]   which = back (default) | fwd"""
+"""Per-task trace of the sharded ticket lists at one rank (dev): python tools/attic/dev/shard_trace.py N [which]   which = back (default) | fwd"""
 import os, sys
 import torch, torch.distributed as dist
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -1,6 +1,6 @@
 """Accuracy of the covariance kernels' exp for non-positive arguments (gpp_exp_nonpos, csrc/gpp_internal.h) through the C ABI:
 one row of gpp_cross_kernel with D = 1, w = 1, sf2 = 1 is exp(-(u_j)^2); compared with numpy on the identical fp64 argument.
-usage: python tools/exp_check.py [n]"""
+usage: python tools/attic/exp_check.py [n]"""
 import os, sys
 import numpy as np
 import torch

@@ -4,7 +4,7 @@
 // the work-groups may sit on different XCDs: buffer_wbl2 / buffer_inv), (1) the payload moved with agent-scope relaxed atomics
 // (sc1 loads / stores that bypass the per-XCD L2) and only a waitcnt before the flag.  Each alone and beside a kernel that keeps
 // dirtying the L2s from another stream.  Dev tool for the cooperative panel kernel:
-//   hipcc --offload-arch=gfx950 -O2 tools/flag_probe.hip -o tools/flag_probe.bin
+//   hipcc --offload-arch=gfx950 -O2 tools/attic/flag_probe.hip -o tools/flag_probe.bin
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <vector>

@@ -1,5 +1,5 @@
 """Sweep the drivers' environment knobs (gpp_api.hip) with tools/bench_stages.py: kernel-only ms per evaluation.  Dev tool.
-usage: python tools/knob_sweep.py  [N ...]"""
+usage: python tools/attic/knob_sweep.py  [N ...]"""
 import os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sizes = [int(a) for a in sys.argv[1:]] or [4096, 8192, 10000, 15000, 20000]

@@ -1,5 +1,5 @@
 """Correctness + timing of gpp_potrf_ws against torch.linalg.cholesky at sizes above the bordering range (dev tool).
-usage: python tools/potrf_check.py N [N ...]   (env knobs of gpp_api.hip apply: GPP_LOOKAHEAD_NB, GPP_SPLIT_UPD, ...)"""
+usage: python tools/attic/potrf_check.py N [N ...]   (env knobs of gpp_api.hip apply: GPP_LOOKAHEAD_NB, GPP_SPLIT_UPD, ...)"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

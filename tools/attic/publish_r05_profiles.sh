@@ -1,5 +1,5 @@
 #!/bin/bash
-# Copy the summaries of tools/collect_r05_profiles.sh (gpurun_out/r5prof/, scratch) into profiles/r05_* (tracked).
+# Copy the summaries of tools/attic/collect_r05_profiles.sh (gpurun_out/r5prof/, scratch) into profiles/r05_* (tracked).
 set -u
 cd "$(dirname "$0")/.."
 R=gpurun_out/r5prof; P=profiles

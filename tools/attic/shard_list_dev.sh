@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev: the sharded ticket list against the single-GPU path, ranks sharing the one GPU (usage: tools/shard_list_dev.sh "world N nb" ...)
+# dev: the sharded ticket list against the single-GPU path, ranks sharing the one GPU (usage: tools/attic/shard_list_dev.sh "world N nb" ...)
 export GPP_SHARD_DEBUG=1 HSA_ENABLE_IPC_MODE_LEGACY=0 GPP_SHARD_TIMEOUT_MS=${GPP_SHARD_TIMEOUT_MS:-20000}
 port=29700
 for c in "$@"; do

@@ -1,6 +1,6 @@
 """Soak of the replayed objectives (graphed.py, optim/mll_batched.py): many thousands of replays of the L-BFGS objective at several
 sizes with eager evaluations, device synchronisations and allocations in between, each compared with the value the eager path gave
-for the same point; then repeated batched fits that must reproduce the first one bit for bit.  Dev tool: python tools/soak_replay.py [s]"""
+for the same point; then repeated batched fits that must reproduce the first one bit for bit.  Dev tool: python tools/attic/soak_replay.py [s]"""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

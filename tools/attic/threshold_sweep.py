@@ -1,5 +1,5 @@
 """Factor + inverse + Ky^-1 at sizes around every dispatch threshold of the drivers (leaf steps / look-ahead / bordering /
-block heights / split update), checked by residuals against the input matrix.  Dev tool: python tools/threshold_sweep.py"""
+block heights / split update), checked by residuals against the input matrix.  Dev tool: python tools/attic/threshold_sweep.py"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gpplus_amd.backend import get_context, square_buffer

@@ -1,6 +1,6 @@
 """Dump the kernel timeline of the last potrf in a rocprofv3 kernel trace of tools/bench_stages.py between two times (ms
 from the start of that potrf): start, end, duration (us), queue, work-groups, short kernel name.  Dev tool.
-usage: python tools/trace_dump.py <rocprof dir> t_from t_to"""
+usage: python tools/attic/trace_dump.py <rocprof dir> t_from t_to"""
 import sys, glob, re
 import pandas as pd
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]

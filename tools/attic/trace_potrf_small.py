@@ -1,6 +1,6 @@
 """Timeline of the LAST potrf in a rocprofv3 kernel trace of tools/bench_stages.py: every kernel with its start, duration
 and the idle gap before it (one stream, so gaps are dispatch latency).  Dev tool.
-usage: python tools/trace_potrf_small.py <rocprof output dir> [max rows]"""
+usage: python tools/attic/trace_potrf_small.py <rocprof output dir> [max rows]"""
 import sys, glob, re
 import pandas as pd
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]

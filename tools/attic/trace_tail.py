@@ -1,6 +1,6 @@
 """Per-queue activity of the last potrf in a rocprofv3 kernel trace of tools/bench_stages.py, in 2 ms windows:
 busy fraction of each HW queue (union of kernel intervals) and the kernel count.  Dev tool.
-usage: python tools/trace_tail.py <rocprof dir>"""
+usage: python tools/attic/trace_tail.py <rocprof dir>"""
 import sys, glob
 import pandas as pd, numpy as np
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]

@@ -1,4 +1,4 @@
-"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/collect_r05_profiles.sh) into the per-stage traffic records that
+"""Turn rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (tools/attic/collect_r05_profiles.sh) into the per-stage traffic records that
 bench.py reads: profiles/<ROUND>_{potrf,trtri,lauum}_pmc.json (ROUND from the environment, default r05).  Each record carries the signature of the kernel build it was collected
 with (gpp_version()), and bench.py refuses a record whose signature differs from the library it runs.
 Bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB — FETCH_SIZE counts 128-byte requests at 64 B on gfx950 (MI355X_MICROARCH.md, HBM) — per
