@@ -346,7 +346,7 @@ class Replay:
         for sweep in range(sweeps):
             delta = 0.0
             for r in ranks:
-                o = self.run(r, rate, ready, check=check and sweep == sweeps - 1)
+                o = self.run(r, rate, ready)
                 for key, v in o["ready"].items():
                     delta = max(delta, abs(v - ready[key]))
                     ready[key] = v
@@ -358,9 +358,13 @@ class Replay:
                       f"(ff {max(res[r]['ff_ms'] for r in res):8.2f}, back {max(res[r]['back_ms'] for r in res):8.2f})", flush=True)
             if len(ranks) < self.P or delta < max(tol_us, 0.004 * max(ready.values())):
                 break
-        if check and "err_factor" not in res[ranks[-1]]:  # converged before the last sweep: one more pass for the comparison
-            for r in ranks:
-                res[r] = self.run(r, rate, ready, check=True)
+        if check:  # one more pass for the comparisons with the single-GPU result: its TIMES are discarded (the checks wait for the device
+            for r in ranks:  # between the stages), only the errors and the statuses are kept
+                o = self.run(r, rate, ready, check=True)
+                for key in ("err_factor", "err_linv", "err_kinv"):
+                    res[r][key] = o.get(key, float("nan"))
+                res[r]["status_ff"] = max(res[r]["status_ff"], o["status_ff"])
+                res[r]["status_back"] = max(res[r]["status_back"], o["status_back"])
         return res, ready, hist
 
 
