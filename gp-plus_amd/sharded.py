@@ -369,14 +369,17 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
                     Lkk.copy_(dblk)
                 head_arrived = torch.cuda.Event()
                 head_arrived.record(cs)
-                if N > o2:
-                    tail = ws.pack[:nbk * (N - o2)].view(nbk, N - o2)
+                # (the tail in the SAME pieces as the ticket lists' messages — gpp_shard_piece_cols in gpp.h — so that a rank on this
+                #  launch path and a rank on the list path can take part in one evaluation: which of the two a rank runs depends on
+                #  its own handle's options, e.g. a panel switched off after a time-out)
+                for c0, c1 in ctx.shard_messages(N, nb, k)[1:]:
+                    tail = ws.pack[:nbk * (c1 - c0)].view(nbk, c1 - c0)
                     if own:
                         cs.wait_event(tail_solved)
-                        tail.copy_(W[:, o2:N])
-                    comm.bcast(ws.pack[:nbk * (N - o2)], k % P)
+                        tail.copy_(W[:, c0:c1])
+                    comm.bcast(ws.pack[:nbk * (c1 - c0)], k % P)
                     if not own:
-                        A[o:o1, o2:N].copy_(tail)
+                        A[o:o1, c0:c1].copy_(tail)
                 arrived = torch.cuda.Event()
                 arrived.record(cs)
         else:
@@ -628,12 +631,20 @@ def _backward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> int:
     offs, P, me, nb = ws.offs, comm.world, comm.rank, ws.nb
     nblk = len(offs) - 1
     A, Lc, Kc = ws.A, ws.Lc, ws.Kc
+    # The status of the back-substitution's list is agreed on by ALL ranks, whether a rank's own list applied or not (a rank without
+    # blocks, a size the list does not take): exactly one MAX all-reduce per evaluation when the lists are enabled at all — the
+    # decision depends on the environment and on options every rank switches together, never on what a rank owns.
+    agree = _USE_LIST and comm.travel
+
+    def agreed(local: int) -> int:
+        if not agree:
+            return local
+        info = torch.full((1,), int(local), dtype=torch.int32, device=ws.info.device)
+        comm.allreduce(info, dist.ReduceOp.MAX)
+        return int(info.item())
+
     if _first_owned(ws, comm) is None:
-        if _USE_LIST and ctx.dag_sched and comm.travel:
-            info = torch.zeros(1, dtype=torch.int32, device=ws.info.device)  # (takes part in the other ranks' status agreement)
-            comm.allreduce(info, dist.ReduceOp.MAX)
-            return int(info.item())
-        return 0
+        return agreed(0)
     if _USE_LIST and ctx.dag_sched:
         # the same sweep as ONE ticket list (gpp_shard_back_list in gpp.h).  The diagonal blocks of Ky^-1 are written as lower
         # triangles: clear what the forward sweep's sums left above them first
@@ -646,11 +657,10 @@ def _backward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> int:
             # (a wait inside the list that ran out of its budget must not pass as a result — and must be EVERY rank's status: the
             #  gradient's all-reduce follows, so a rank that raised alone would leave the others blocked in it.  MAX over the ranks,
             #  as for the factor list; the caller then repeats the evaluation on the launch path, all ranks together.)
-            info = ws.info[0:1].clone()
-            comm.allreduce(info, dist.ReduceOp.MAX)
-            st = int(info.item())
+            mine = int(ws.info[0].item())
+            st = agreed(mine)
             if st and os.environ.get("GPP_SHARD_DEBUG"):
-                print(f"[sharded rank {me}] back-substitution list: status {st:#x} (mine {int(ws.info[0].item()):#x})", flush=True)
+                print(f"[sharded rank {me}] back-substitution list: status {st:#x} (mine {mine:#x})", flush=True)
             if st == 0:
                 global BACK_LIST_EVALS
                 BACK_LIST_EVALS += 1
@@ -689,7 +699,7 @@ def _backward(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace) -> int:
                     row_done = torch.cuda.Event()
                     row_done.record(main)
     main.wait_stream(aux)
-    return 0
+    return agreed(0)
 
 
 class ShardedMLLFunction(torch.autograd.Function):
