@@ -19,6 +19,8 @@ from sharded_launch import assert_close_values, config_values, run_ranks as _run
     (4, 13000, 6, 1024, 0, 2, 2, {}),                      # fused groups of 2 steps, 13 blocks on 4 ranks, per-group noise, manifold gradients
     (2, 15000, 8, 1024, 0, 1, 0, {}),                      # fused groups of 4 steps
     (2, 20000, 8, 1024, 0, 1, 0, {}),                      # the C2 size on two ranks: 20 blocks, 116 000 tasks over the ranks
+    (4, 4400, 5, 2048, 0, 1, 0, {}),                       # three blocks on four ranks: rank 3 owns nothing and runs the launch path beside the
+                                                           # others' lists — same messages (head + pieces), same collectives, one evaluation
     (1, 7000, 6, 512, 0, 1, 0, {"GPP_SHARD_LIST": "0"}),   # the switch: launches per product (rounds 2-4)
 ])
 def test_sharded_ticket_lists_match_single_gpu(world, N, D, nb, kind, S, dU, env):
