@@ -493,3 +493,45 @@ def test_panel_timeout_is_recovered_by_the_host(gpu_ctx):
         gpu_ctx.set_option(OPT_PANEL_FAULT, 0)
         gpu_ctx.set_option(OPT_COOP_PANEL, 1)
     assert gpu_ctx.coop_panel
+
+
+def test_replay_copy_kernel_obeys_its_rate_and_its_start_time(gpu_ctx):
+    """``gpp_debug_replay_copy`` (gpp_shard.hip; tools/replay_rank.py plays other ranks' block rows with it): a strided 2-D copy by a
+    few work-groups that (a) moves the right data, (b) takes at least bytes / rate, (c) does not start before epoch + not_before on
+    the device's 100 MHz clock, and reports both stamps relative to the epoch."""
+    import ctypes
+
+    lib = gpu_ctx.lib
+    lib.gpp_debug_replay_copy.restype = ctypes.c_int
+    lib.gpp_debug_replay_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                          ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_longlong,
+                                          ctypes.c_void_p]
+    lib.gpp_debug_replay_stamp.restype = ctypes.c_int
+    lib.gpp_debug_replay_stamp.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    dev = "cuda"
+    rows, cols, ld = 512, 4096, 5000  # 16 MiB out of a wider matrix
+    src = torch.randn(rows, ld, dtype=torch.float64, device=dev)
+    dst = torch.zeros(rows, cols, dtype=torch.float64, device=dev)
+    epoch = torch.zeros(1, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(2, dtype=torch.int64, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    assert lib.gpp_debug_replay_stamp(s, epoch.data_ptr(), None) == 0
+    rate, delay_ticks = 20.0, 300_000  # 20 GB/s; not before 3 ms after the epoch
+    assert lib.gpp_debug_replay_copy(s, dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), rows, cols, 16, 512, rate,
+                                     epoch.data_ptr(), delay_ticks, stamps.data_ptr()) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(dst, src[:, :cols])
+    start, end = (int(v) for v in stamps.tolist())
+    assert start >= delay_ticks and start < delay_ticks + 50_000, (start, delay_ticks)
+    need = rows * cols * 8 / (rate * 10.0)  # ticks: rate GB/s = 10 rate bytes per tick of 10 ns
+    assert end - start >= 0.98 * need and end - start < 1.5 * need, (end - start, need)
+    # unthrottled, at once: faster than the paced copy by a wide margin
+    stamps.zero_()
+    assert lib.gpp_debug_replay_copy(s, dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), rows, cols, 32, 512, 0.0,
+                                     epoch.data_ptr(), -1, stamps.data_ptr()) == 0
+    torch.cuda.synchronize()
+    start, end = (int(v) for v in stamps.tolist())
+    assert 0 < end - start < 0.25 * need
+    # odd column counts / leading dimensions are refused (16-byte vectors)
+    assert lib.gpp_debug_replay_copy(s, dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), rows, cols - 1, 16, 512, 0.0,
+                                     epoch.data_ptr(), -1, stamps.data_ptr()) != 0
