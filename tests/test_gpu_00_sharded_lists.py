@@ -53,16 +53,20 @@ def test_sharded_lists_at_c5_size_two_ranks():
 
 
 @pytest.mark.gpu
-def test_sharded_c2_on_two_ranks_matches_the_oracle_fixture():
-    """The sharded path pinned to the ORACLE directly, not through the single-GPU path: BASELINE config C2 at
-    full size (N = 20 000) through GP_Plus on two ranks (ticket lists, messages over gloo) against the committed oracle values
-    tests/golden/fullsize_c2.npz — loss and every gradient at BASELINE's bar of 1e-5 relative (optim/mll_torch.py:114-117)."""
+@pytest.mark.parametrize("cfg,world", [("C2", 2), ("C3", 3), ("C4", 2)])
+def test_sharded_configs_match_the_oracle_fixtures(cfg, world):
+    """The sharded path pinned to the ORACLE directly, not through the single-GPU path: the BASELINE configs at
+    FULL size — C2 (N = 20 000), C3 (N = 10 000, manifold-encoded categoricals: gradients w.r.t. the latent map through dMLL/dU,
+    three ranks), C4 (N = 15 000, three noise groups, per-source means) — through GP_Plus on several ranks (ticket lists, messages
+    over gloo) against the committed oracle values tests/golden/fullsize_*.npz: loss and every gradient at BASELINE's bar of 1e-5
+    relative (optim/mll_torch.py:114-117)."""
     import os
     import numpy as np
 
-    fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fullsize_c2.npz")))
+    fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"fullsize_{cfg.lower()}.npz")))
     meta = {}
-    _, shard = config_values("C2", 1024, 2, port=29981, meta=meta, only="sharded", GPP_SHARD_TIMEOUT_MS="60000")
+    _, shard = config_values(cfg, 1024, world, port=29981 + world + len(cfg) * 3 + ord(cfg[1]), meta=meta, only="sharded",
+                             GPP_SHARD_TIMEOUT_MS="60000")
     assert (meta["list_evals"], meta["back_list_evals"]) == (1, 1), meta
     ref = float(fx["loss"])
     assert abs(shard["loss"] - ref) <= 1e-5 * abs(ref), (shard["loss"], ref)
