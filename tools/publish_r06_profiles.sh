@@ -37,8 +37,21 @@ grep -v "amdgpu\|Warning" $R/configs.txt > $P/r06_configs_C1_C5_single_gpu.txt
  echo "columns, the factor's mirror behind the list.  Per rank: build, factor + forward list, z / alpha, back-substitution list, gradient (ms)."
  echo "Method, and what it cannot contain: profiles/EXPERIMENTS.md (round 6).  First collection of the round (before the pieces): r06_virtual_rank_first.txt"
  echo; echo "==== C5 (N = 60 000, d = 16) ===="; grep -v "running tasks per\|amdgpu.ids" $R/replay_c5.txt
- echo; echo "==== C2 (N = 20 000, d = 8) ===="; grep -v "running tasks per\|amdgpu.ids" $R/replay_c2.txt) > $P/r06_virtual_rank.txt
-cp $R/replay_c5.json $P/r06_virtual_rank_c5.json; cp $R/replay_c2.json $P/r06_virtual_rank_c2.json
+ echo; echo "==== C2 (N = 20 000, d = 8) ===="; grep -v "running tasks per\|amdgpu.ids" $R/replay_c2.txt
+ for P_ in 4 2; do for c in c5 c2; do echo; echo "==== $c on $P_ virtual ranks ===="; grep -v "running tasks per\|amdgpu.ids\|^    sweep" $R/replay_${c}_p$P_.txt; done; done) > $P/r06_virtual_rank.txt
+python3 - <<'PY' > $P/r06_virtual_scaling.json
+import json
+out = {"note": "virtual-rank replay (tools/replay_rank.py) on ONE MI355X: ms per evaluation = max over ranks of factor + forward, + max of the back-substitution, + the small stages; rate = the replayed messages' GB/s (0: every message there when asked for); one rank: profiles/r06_sharded_lists_1rank.txt", "configs": {}}
+for c in ("c5", "c2"):
+    rows = {}
+    for P in (8, 4, 2):
+        f = f"gpurun_out/r6prof/replay_{c}.json" if P == 8 else f"gpurun_out/r6prof/replay_{c}_p{P}.json"
+        d = json.load(open(f))
+        rows[str(P)] = {str(r["rate_gbs"]): {"total_ms": round(r["total_ms"], 2), "ff_ms": round(r["ff_ms"], 2), "back_ms": round(r["back_ms"], 2),
+                                             "evals_per_s": round(r["evals_per_s"], 4), "sweeps": r["sweeps"]} for r in d["rates"]}
+    out["configs"][c.upper()] = rows
+print(json.dumps(out, indent=1))
+PY
 python3 - <<'PY' > $P/r06_kernel_census.txt
 import csv
 print("Kernel census of one evaluation through the plain API (tools/run_configs.py under rocprofv3 --kernel-trace --stats; calls per evaluation = total calls / evaluations).")
