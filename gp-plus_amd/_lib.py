@@ -53,6 +53,15 @@ _SIGNATURES = {
     "gpp_shard_buffer_doubles": (c_size_t, [c_int64, c_int64, c_int, c_int, c_int]),
     "gpp_shard_eval": (c_int, [c_void_p, c_int64, c_int64, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
                                c_double, c_int, c_int, c_void_p, POINTER(c_int)]),
+    "gpp_push_create": (c_int, [c_int, c_int, c_int, c_int64, POINTER(c_void_p), c_void_p]),
+    "gpp_push_connect": (c_int, [c_void_p, c_void_p]),
+    "gpp_push_send": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64),
+                              POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "gpp_push_recv": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64),
+                              POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    "gpp_push_ack": (c_int, [c_void_p, c_void_p, c_int64]),
+    "gpp_push_info": (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int)]),
+    "gpp_push_destroy": (c_int, [c_void_p, c_int]),
     "gpp_shard_back_list": (c_int, [c_void_p, c_int64, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p,
                                     c_void_p, c_int, POINTER(c_int)]),
     "gpp_trmv_lower_cols": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int]),

@@ -57,6 +57,7 @@ import torch
 import torch.distributed as dist
 
 from .backend import INFO_PANEL_TIMEOUT, KIND_RBF, UPLO_FULL, GppContext, get_context, panel_timed_out, square_buffer
+from . import push as _push
 from .errors import NanError, NotPSDError
 from . import settings
 
@@ -205,6 +206,17 @@ def _workspace(ctx: GppContext, N: int, nb: int, rank: int = 0, world: int = 1) 
     return ws
 
 
+def _push_channel(ctx: GppContext, comm: "_Comm", ws: ShardedWorkspace):
+    """The push transport's channel for this workspace's messages (GPP_SHARD_PUSH=1, several ranks), else None: the messages are
+    broadcasts.  A slot holds the widest message: a head (nb x 2 nb + the nb x nb inverse) or a piece of a tail."""
+    if not comm.travel or not _push.active(comm.world):
+        return None
+    if getattr(ws, "push_slot_bytes", None) is None:
+        widest = max([c1 - c0 for k in range(len(ws.offs) - 1) for c0, c1 in ctx.shard_messages(ws.N, ws.nb, k)[1:]] + [0])
+        ws.push_slot_bytes = 8 * ws.nb * max(3 * ws.nb, widest)
+    return _push.channel(ctx, comm.rank, comm.world, comm.group, ws.push_slot_bytes)
+
+
 class _RowEvents:
     """Which event marks the latest update of each block row, and on which stream it was recorded: a launch on another
     stream waits for the events of the rows it touches (launches on the producing stream are ordered anyway)."""
@@ -258,6 +270,7 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
     side, upd, full = ctx.internal_streams()
     cs = ws.comm_stream
     owned = lambda a, b: [i for i in range(max(a, 0), min(b, nblk)) if i % P == me]  # noqa: E731
+    pushc, pstat = _push_channel(ctx, comm, ws), ws.info[nblk:nblk + 1]  # (GPP_SHARD_PUSH=1; a wait's time-out lands in pstat)
     ws.info.zero_()
     for k in owned(0, nblk):
         ctx.kernel_build(U, w, sf2, tau, grp, A, jitter=jitter, kind=kind, d_split=d_split, uplo=UPLO_FULL, row0=offs[k],
@@ -360,13 +373,22 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
                 dblk = ws.hbuf[nbk * wh:nbk * (wh + nbk)].view(nbk, nbk)
                 if own:
                     cs.wait_event(head_solved)
-                    head[:, :o1 - o].copy_(A[o:o1, o:o1])   # the factored diagonal block ...
-                    head[:, o1 - o:].copy_(W[:, o1:o2])      # ... and the solved head, from where the solve left it
-                    dblk.copy_(Lkk)
-                comm.bcast(ws.hbuf[:nbk * (wh + nbk)], k % P)
-                if not own:
-                    A[o:o1, o:o2].copy_(head)
-                    Lkk.copy_(dblk)
+                if pushc is not None:  # (the same parts at the same places of the message, straight from / to where they lie)
+                    seq = pushc.advance()
+                    if own:
+                        pushc.send(cs, seq, [(A[o:o1, o:o1], 0, wh), (W[:, o1:o2], o1 - o, wh), (Lkk, nbk * wh, nbk)], pstat)
+                    else:
+                        pushc.recv(cs, seq, [(A[o:o1, o:o2], 0, wh), (Lkk, nbk * wh, nbk)], pstat)
+                    pushc.ack(cs, seq)
+                else:
+                    if own:
+                        head[:, :o1 - o].copy_(A[o:o1, o:o1])   # the factored diagonal block ...
+                        head[:, o1 - o:].copy_(W[:, o1:o2])      # ... and the solved head, from where the solve left it
+                        dblk.copy_(Lkk)
+                    comm.bcast(ws.hbuf[:nbk * (wh + nbk)], k % P)
+                    if not own:
+                        A[o:o1, o:o2].copy_(head)
+                        Lkk.copy_(dblk)
                 head_arrived = torch.cuda.Event()
                 head_arrived.record(cs)
                 # (the tail in the SAME pieces as the ticket lists' messages — gpp_shard_piece_cols in gpp.h — so that a rank on this
@@ -376,6 +398,15 @@ def _factor(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, tau, 
                     tail = ws.pack[:nbk * (c1 - c0)].view(nbk, c1 - c0)
                     if own:
                         cs.wait_event(tail_solved)
+                    if pushc is not None:
+                        seq = pushc.advance()
+                        if own:
+                            pushc.send(cs, seq, [(W[:, c0:c1], 0, c1 - c0)], pstat)
+                        else:
+                            pushc.recv(cs, seq, [(A[o:o1, c0:c1], 0, c1 - c0)], pstat)
+                        pushc.ack(cs, seq)
+                        continue
+                    if own:
                         tail.copy_(W[:, c0:c1])
                     comm.bcast(ws.pack[:nbk * (c1 - c0)], k % P)
                     if not own:
@@ -461,6 +492,7 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
         return None
     main = torch.cuda.current_stream(ctx.index)
     cs = ws.comm_stream
+    pushc, pstat = _push_channel(ctx, comm, ws), ws.info[nblk:nblk + 1]  # (GPP_SHARD_PUSH=1; a wait's time-out lands in pstat)
     ws.info.zero_()
     for k in range(me, nblk, P):
         ctx.kernel_build(U, w, sf2, tau, grp, A, jitter=jitter, kind=kind, d_split=d_split, uplo=UPLO_FULL, row0=offs[k],
@@ -486,19 +518,40 @@ def _factor_list(ctx: GppContext, comm: _Comm, ws: ShardedWorkspace, U, w, sf2, 
                     dblk = ws.hbuf[nbk * wh:nbk * (wh + nbk)].view(nbk, nbk)
                     if own:
                         ctx.shard_list_gate(cs, 0, k)
-                        head.copy_(A[o:o1, o:o2])
-                        dblk.copy_(Lkk)
-                    comm.bcast(ws.hbuf[:nbk * (wh + nbk)], k % P)
-                    if not own:
-                        A[o:o1, o:o2].copy_(head)
-                        Lkk.copy_(dblk)
-                        ctx.shard_list_signal(cs, 0, k)
+                    if pushc is not None:  # GPP_SHARD_PUSH=1: the owner's copies go straight from the factor into every peer's slot
+                        seq = pushc.advance()
+                        hparts = [(A[o:o1, o:o2], 0, wh), (Lkk, nbk * wh, nbk)]
+                        if own:
+                            pushc.send(cs, seq, hparts, pstat)
+                        else:
+                            pushc.recv(cs, seq, hparts, pstat)
+                            ctx.shard_list_signal(cs, 0, k)
+                        pushc.ack(cs, seq)
+                    else:
+                        if own:
+                            head.copy_(A[o:o1, o:o2])
+                            dblk.copy_(Lkk)
+                        comm.bcast(ws.hbuf[:nbk * (wh + nbk)], k % P)
+                        if not own:
+                            A[o:o1, o:o2].copy_(head)
+                            Lkk.copy_(dblk)
+                            ctx.shard_list_signal(cs, 0, k)
                     # the tail in pieces (round 6; gpp_shard_piece_cols in gpp.h): the list's tasks wait for the piece of the column
                     # tile they read, so the next owner's first piece is updated, solved and sent while the rest of this row travels
                     for g, (c0, c1) in enumerate(ctx.shard_messages(N, nb, k)[1:]):
                         tail = ws.pack[:nbk * (c1 - c0)].view(nbk, c1 - c0)
                         if own:
                             ctx.shard_list_gate(cs, 1 + g, k)
+                        if pushc is not None:
+                            seq = pushc.advance()
+                            if own:
+                                pushc.send(cs, seq, [(A[o:o1, c0:c1], 0, c1 - c0)], pstat)
+                            else:
+                                pushc.recv(cs, seq, [(A[o:o1, c0:c1], 0, c1 - c0)], pstat)
+                                ctx.shard_list_signal(cs, 1 + g, k)
+                            pushc.ack(cs, seq)
+                            continue
+                        if own:
                             tail.copy_(A[o:o1, c0:c1])
                         comm.bcast(ws.pack[:nbk * (c1 - c0)], k % P)
                         if not own:
@@ -766,6 +819,7 @@ class ShardedMLLFunction(torch.autograd.Function):
                 if info is None:
                     info = _factor(gctx, comm, ws, Ud, wd, sd, td, grp, kind, d_split, jit)
             if info >= INFO_PANEL_TIMEOUT:
+                _push.disable()  # (a message may be missing somewhere: the ranks' message numbers no longer agree; broadcasts from here)
                 # (the status is the MAX over the ranks: every rank sees it and repeats the attempt; the rank whose panel gave up —
                 #  or every rank, it costs 1-2 % — switches the panel off)
                 timeouts += 1

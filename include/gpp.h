@@ -237,6 +237,34 @@ int gpp_shard_eval(gpp_handle_t h, int64_t N, int64_t nb, const double* U, int D
                    const int32_t* grp, int S, int kind, int d_split, double jitter, int dU, int need_grad, const gpp_shard_buffers_t* b,
                    int32_t* info_host);
 
+/*
+ * A direct one-to-all PUSH of the sharded evaluation's messages, the alternative to a broadcast collective (SURVEY.md:204, :423-425:
+ * "owner pushes the same panel on all 7 links concurrently"); gp-plus_amd/csrc/gpp_push.hip has the protocol.  Every rank creates a
+ * channel (two message slots of slot_bytes + a flag page, exported as a GPP_PUSH_HANDLE_BYTES record), the ranks exchange the records
+ * by any means (all-gather) and connect (hipIpcOpenMemHandle of every peer's).  Messages are numbered seq = 1, 2, ... in the one order
+ * in which every rank moves them.  For message seq, on every rank, in this order:
+ *   its owner:   gpp_push_send  — behind what `after_stream` has enqueued so far, on one stream per peer: wait until the peer has
+ *                consumed message seq - 2, copy part i (height[i] rows of width[i] bytes at src[i], row pitch spitch[i]: straight
+ *                from where it lies, no packing) to byte `offset[i]` of the peer's slot with row pitch dpitch[i], then mark the slot
+ *                complete; `after_stream` continues when the message has left.
+ *   the others:  gpp_push_recv  — on `stream`: wait until message seq is complete in this rank's slot, then copy part i from byte
+ *                offset[i] of the slot (row pitch spitch[i]) to dst[i] (row pitch dpitch[i]).
+ *   every rank:  gpp_push_ack   — on `stream`, behind whatever consumed the message: tell every peer that this rank is done with seq.
+ * A wait that exceeds GPP_SHARD_TIMEOUT_MS ORs `code` into *status (device memory) and gives up.  gpp_push_destroy: stage 0 drains and
+ * unmaps the peers' memory, stage 1 — after every rank's stage 0 — frees this rank's; stage 2 does both.
+ */
+typedef struct gpp_push* gpp_push_t;
+#define GPP_PUSH_HANDLE_BYTES 128
+int gpp_push_create(int device, int rank, int nranks, int64_t slot_bytes, gpp_push_t* out, void* handle_out);
+int gpp_push_connect(gpp_push_t p, const void* handles /* nranks x GPP_PUSH_HANDLE_BYTES, in rank order */);
+int gpp_push_send(gpp_push_t p, void* after_stream, int64_t seq, int32_t* status, int code, int nparts, const void* const* src,
+                  const int64_t* spitch, const int64_t* offset, const int64_t* dpitch, const int64_t* width, const int64_t* height);
+int gpp_push_recv(gpp_push_t p, void* stream, int64_t seq, int32_t* status, int code, int nparts, void* const* dst, const int64_t* dpitch,
+                  const int64_t* offset, const int64_t* spitch, const int64_t* width, const int64_t* height);
+int gpp_push_ack(gpp_push_t p, void* stream, int64_t seq);
+int gpp_push_info(gpp_push_t p, int64_t* slot_bytes, int* flag_kind /* 0 uncached, 1 fine-grained, 2 ordinary device memory */);
+int gpp_push_destroy(gpp_push_t p, int stage);
+
 /* Products with a lower-triangular T of which only the block-cyclically owned COLUMN blocks (width nb, a multiple of 64; block
  * b owned when b % nranks == rank) exist on this rank:  trans = 0: y_i = sum over owned columns k <= i of T[i][k] x_k (this
  * rank's part of z = L^-1 r);  trans = 1: y_k = sum_{i >= k} T[i][k] x_i for the owned columns k and 0 for the others (this

@@ -36,6 +36,29 @@ def test_sharded_ticket_lists_match_single_gpu(world, N, D, nb, kind, S, dU, env
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("world,N,D,nb,kind,S,dU,env", [
+    (2, 9000, 6, 1024, 0, 1, 0, {}),                        # two ranks: every message has one receiver
+    (3, 10000, 5, 1024, 2, 1, 0, {}),                       # three ranks, two peers per owner
+    (4, 13000, 6, 1024, 0, 2, 2, {}),                       # four ranks, fused groups, manifold gradients
+    (2, 9000, 6, 1024, 0, 1, 0, {"GPP_SHARD_PIECE_COLS": "2048"}),  # many small pieces: both slots in flight all the time
+    (4, 4400, 5, 2048, 0, 1, 0, {}),                        # rank 3 on the launch path beside the others' lists: the same messages
+    (3, 7000, 6, 512, 0, 1, 0, {"GPP_SHARD_LIST": "0"}),    # every rank on the launch path (sources: the scratch rows)
+])
+def test_push_transport_equals_the_broadcast_bit_for_bit(world, N, D, nb, kind, S, dU, env):
+    """GPP_SHARD_PUSH=1 (gp-plus_amd/push.py, csrc/gpp_push.hip; SURVEY.md:204 "owner pushes the same panel on all links"; VERDICT r5
+    item 5): the block rows' messages as one-to-all pushes through hipIpc-mapped slots (same-device IPC here: the ranks share the GPU)
+    instead of broadcasts — the same evaluation bit for bit, messages really pushed, lists complete."""
+    port = 30500 + (N * 3 + world * 17 + S + len(env) * 7) % 300
+    ref = _run([N, D, nb, kind, S, dU], world=world, port=port, GPP_SHARD_TIMEOUT_MS="20000", **env)
+    out = _run([N, D, nb, kind, S, dU], world=world, port=port + 1, GPP_SHARD_TIMEOUT_MS="20000", GPP_SHARD_PUSH="1", **env)
+    for name, e in out["err"].items():
+        assert e < 1e-9, (name, e, out)
+    assert ref["push_messages"] == 0 and out["push_messages"] > 0, (ref["push_messages"], out["push_messages"])
+    assert out["digest"] == ref["digest"], (out["err"], ref["err"])
+    assert (out["list_evals"], out["back_list_evals"]) == (ref["list_evals"], ref["back_list_evals"]), (out["status_lines"], ref["status_lines"])
+
+
+@pytest.mark.gpu
 def test_sharded_lists_at_c5_size_two_ranks():
     """BASELINE config C5 at FULL size (N = 60 000, d = 16: 59 block rows of 1024, fused groups of 4 steps, ~1.1 million tasks per
     rank) through GP_Plus on two ranks sharing the GPU (2 x 87 GB) against the single-GPU path run on its own beforehand: loss and

@@ -535,3 +535,45 @@ def test_replay_copy_kernel_obeys_its_rate_and_its_start_time(gpu_ctx):
     # odd column counts / leading dimensions are refused (16-byte vectors)
     assert lib.gpp_debug_replay_copy(s, dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), rows, cols - 1, 16, 512, 0.0,
                                      epoch.data_ptr(), -1, stamps.data_ptr()) != 0
+
+
+def test_push_channel_waits_are_bounded_and_arguments_checked(gpu_ctx, monkeypatch):
+    """``gpp_push_*`` (csrc/gpp_push.hip; the one-to-all push transport of gp-plus_amd/push.py, GPP_SHARD_PUSH=1): a receiver whose message
+    never arrives gives up after GPP_SHARD_TIMEOUT_MS with the caller's code in the caller's status word — the GPU is not left hanging —
+    and the entry points refuse message numbers below 1, parts that do not fit a slot and calls on an unconnected channel.  (The data
+    path itself needs a peer: tests/test_gpu_00_sharded_lists.py::test_push_transport_equals_the_broadcast_bit_for_bit.)"""
+    import ctypes
+    import time
+
+    from gpplus_amd.backend import INFO_EXEC_TIMEOUT
+    from gpplus_amd.push import HANDLE_BYTES, _arrays
+
+    monkeypatch.setenv("GPP_SHARD_TIMEOUT_MS", "250")
+    lib = gpu_ctx.lib
+    h = ctypes.c_void_p()
+    rec = ctypes.create_string_buffer(HANDLE_BYTES)
+    assert lib.gpp_push_create(gpu_ctx.index, 0, 1, 1 << 20, ctypes.byref(h), rec) == 0
+    status = torch.zeros(1, dtype=torch.int32, device="cuda")
+    dst = torch.zeros(4, 8, dtype=torch.float64, device="cuda")
+    s = torch.cuda.current_stream().cuda_stream
+    n, ptr, vp, off, sp, wd, ht = _arrays([(dst, 0, 8)])
+    assert lib.gpp_push_recv(h, s, 1, status.data_ptr(), INFO_EXEC_TIMEOUT, n, ptr, vp, off, sp, wd, ht) == -1  # not connected yet
+    assert lib.gpp_push_connect(h, rec) == 0  # a group of one: nobody to map
+    sb, kind = ctypes.c_int64(), ctypes.c_int()
+    assert lib.gpp_push_info(h, ctypes.byref(sb), ctypes.byref(kind)) == 0 and sb.value == 1 << 20 and kind.value in (0, 1, 2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    assert lib.gpp_push_recv(h, s, 1, status.data_ptr(), INFO_EXEC_TIMEOUT, n, ptr, vp, off, sp, wd, ht) == 0
+    torch.cuda.synchronize()
+    waited = time.perf_counter() - t0
+    assert 0.2 < waited < 5.0, waited
+    assert int(status.item()) == INFO_EXEC_TIMEOUT
+    assert lib.gpp_push_recv(h, s, 0, status.data_ptr(), INFO_EXEC_TIMEOUT, n, ptr, vp, off, sp, wd, ht) == -3
+    assert lib.gpp_push_ack(h, s, 0) == -3 and lib.gpp_push_ack(h, s, 1) == 0
+    big = torch.zeros(1, (1 << 17) + 1, dtype=torch.float64, device="cuda")  # one double more than a slot holds
+    n2, ptr2, vp2, off2, sp2, wd2, ht2 = _arrays([(big, 0, big.shape[1])])
+    assert lib.gpp_push_recv(h, s, 2, status.data_ptr(), INFO_EXEC_TIMEOUT, n2, ptr2, vp2, off2, sp2, wd2, ht2) == -7
+    assert lib.gpp_push_send(h, s, 2, status.data_ptr(), INFO_EXEC_TIMEOUT, n2, ptr2, vp2, off2, sp2, wd2, ht2) == -7
+    assert lib.gpp_push_send(h, s, 2, status.data_ptr(), INFO_EXEC_TIMEOUT, n, ptr, vp, off, sp, wd, ht) == 0  # no peers: nothing moves
+    torch.cuda.synchronize()
+    assert lib.gpp_push_destroy(h, 2) == 0

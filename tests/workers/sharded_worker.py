@@ -192,7 +192,10 @@ def main():
         wsx = next(iter(_sh._workspaces.values()), None)  # (none when the C driver ran: it has buffers of its own)
         emit("RESULT " + json.dumps({"err": err, "mll": float(res["single"][0]), "backend": dist.get_backend(), "collectives": calls,
                                      "matrix_bytes": wsx.nbytes() if wsx else 0, "full_matrix_bytes": 8 * N * (wsx.A.stride(0) if wsx else N),
-                                     "owned_cols": wsx.Lc.shape[1] if wsx else 0, "nb": nb, "world": world, "list_evals": _sh.LIST_EVALS, "back_list_evals": _sh.BACK_LIST_EVALS}))
+                                     "owned_cols": wsx.Lc.shape[1] if wsx else 0, "nb": nb, "world": world, "list_evals": _sh.LIST_EVALS, "back_list_evals": _sh.BACK_LIST_EVALS,
+                                     # (bit-for-bit comparisons between transports: the sharded result's bytes; messages moved by push)
+                                     "digest": __import__("hashlib").sha256(torch.cat([t.reshape(-1).double() for t in res["sharded"]]).numpy().tobytes()).hexdigest(),
+                                     "push_messages": _sh._push.MESSAGES}))
     emit(f"RANK{rank} same_as_rank0={same}")
     dist.barrier()
     dist.destroy_process_group()
