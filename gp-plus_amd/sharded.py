@@ -43,6 +43,9 @@ counter each, and the factor's mirror is written beside the list.  ``GPP_SHARD_L
 which is also the fall-back (other sizes, a time-out).  One rank: 136 ms against 168 at C2, 3.4 s against 3.5 at C5.  The whole
 evaluation is also available as ONE C call per rank (``gpp_shard_eval``; ``sharded_c.py``).
 
+Round 6: the tail of a block row travels in pieces (``gpp_shard_piece_cols``), and ``GPP_SHARD_PUSH=1`` replaces the broadcasts of
+the block rows by direct one-to-all pushes through hipIpc-mapped slots (push.py; SURVEY.md:204) — the same messages, bit for bit.
+
 Without RCCL (tests: several processes sharing one GPU over "gloo") the collectives are staged through host memory.
 ``GPP_SHARDED_FORCE_COLLECTIVES=1`` issues every collective (and the packing around it) even in a group of one rank, so that
 the RCCL branch runs on a single GPU (tests/test_gpu_sharded.py).

@@ -518,3 +518,29 @@ def test_reference_fp32_theta_round_trip_is_a_switch():
         np.testing.assert_array_equal(flat(obj.unpack_parameters(x)), x.astype(np.float32).astype(np.float64))
         assert all(v.dtype == torch.float64 for v in obj.unpack_parameters(x).values())  # (cast back to the model's dtype on load)
     np.testing.assert_array_equal(flat(obj.unpack_parameters(x)), x)
+
+
+def test_push_transport_describes_its_parts_in_bytes():
+    """gp-plus_amd/push.py::_arrays (host logic of the GPP_SHARD_PUSH transport): a part is a strided 2-D view + its place in the message;
+    what reaches gpp_push_send / gpp_push_recv are pointers, pitches, offsets, widths in BYTES and heights in rows; views the 2-D copies
+    cannot express are refused; the transport is off unless asked for, and never on in a group of one."""
+    import torch
+
+    from gpplus_amd import push
+
+    A = torch.zeros(64, 100, dtype=torch.float64)
+    D = torch.zeros(3, 16, 16, dtype=torch.float64)
+    nbk, wh = 16, 40
+    n, ptr, vp, off, sp, wd, ht = push._arrays([(A[16:32, 10:50], 0, wh), (D[1, :nbk, :nbk], nbk * wh, nbk), (A[5:6, 0:8], 7, 8)])
+    assert n == 3
+    assert [int(p) for p in ptr] == [A[16:32, 10:50].data_ptr(), D[1].data_ptr(), A[5:6].data_ptr()]
+    assert list(vp) == [100 * 8, 16 * 8, 8 * 8] and  # (one row: its width stands for the pitch)
+    assert list(sp) == [wh * 8, nbk * 8, 8 * 8]
+    assert list(off) == [0, nbk * wh * 8, 7 * 8] and list(wd) == [wh * 8, nbk * 8, 8 * 8] and list(ht) == [16, 16, 1]
+    with pytest.raises(ValueError):
+        push._arrays([(A[:, ::2], 0, 50)])          # column stride 2
+    with pytest.raises(ValueError):
+        push._arrays([(A[0], 0, 100)])              # not 2-D
+    with pytest.raises(ValueError):
+        push._arrays([(A.float(), 0, 100)])         # not float64
+    assert not push.active(1) and (push.active(4) == push.ENABLED)

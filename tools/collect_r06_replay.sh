@@ -11,4 +11,7 @@ for P in 2 4; do
   timeout 1200 python3 tools/replay_rank.py --config C5 --P $P --rates 0,150,70,50 --sweeps 6 --json $OUT/replay_c5_p$P.json > $OUT/replay_c5_p$P.txt 2>&1; echo "C5 P=$P rc=$?"
   timeout 600 python3 tools/replay_rank.py --config C2 --P $P --rates 0,150,70,50 --sweeps 6 --json $OUT/replay_c2_p$P.json > $OUT/replay_c2_p$P.txt 2>&1; echo "C2 P=$P rc=$?"
 done
+# the push transport's owner side (GPP_SHARD_PUSH=1: no packing copy in front of a message), same ranks and rates
+timeout 1500 python3 tools/replay_rank.py --config C5 --P 8 --rates 400,150,70,50 --sweeps 8 --push --json $OUT/replay_c5_push.json > $OUT/replay_c5_push.txt 2>&1; echo "C5 P=8 push rc=$?"
+timeout 600 python3 tools/replay_rank.py --config C2 --P 8 --rates 400,150,70,50 --sweeps 6 --push --json $OUT/replay_c2_push.json > $OUT/replay_c2_push.txt 2>&1; echo "C2 P=8 push rc=$?"
 grep -E "^virtual|per evaluation|vs the single" $OUT/replay_c*.txt | cut -c1-240

@@ -83,6 +83,7 @@ class Replay:
         self.dev, self.U, self.w, self.sf2, self.tau, self.r = dev, U, w, sf2, tau, r
         self.N, self.D = U.shape
         self.nb, self.P, self.wgs, self.threads = nb, P, wgs, threads
+        self.push = False  # --push: the owner's side of the push transport (no packing copy)
         self.ctx = get_context(dev)
         lib = self.ctx.lib
         lib.gpp_debug_replay_copy.restype = ctypes.c_int
@@ -186,10 +187,14 @@ class Replay:
                     if own:
                         ctx.shard_list_gate(cs, 0, k)
                         self._stamp(cs, slot(k, 0, 0))
-                        head.copy_(A[o:o1, o:o2])
-                        dblk.copy_(Lkk)
-                        msg = ws.hbuf[:nbk * (wh + nbk)].view(nbk, wh + nbk)  # the broadcast: the stream is busy for bytes / rate
-                        self._rcopy(cs, self.sink[:msg.numel()].view_as(msg), msg, rate, -1, slot(k, 0, 1))
+                        if self.push:  # the push transport (GPP_SHARD_PUSH=1): no packing, the copies read the factor where it lies
+                            self._rcopy(cs, self.sink[:nbk * wh].view(nbk, wh), A[o:o1, o:o2], rate, -1, slot(k, 0, 1))
+                            self._rcopy(cs, self.sink[:nbk * nbk].view(nbk, nbk), Lkk, rate, -1, slot(k, 0, 1))
+                        else:
+                            head.copy_(A[o:o1, o:o2])
+                            dblk.copy_(Lkk)
+                            msg = ws.hbuf[:nbk * (wh + nbk)].view(nbk, wh + nbk)  # the broadcast: the stream is busy for bytes / rate
+                            self._rcopy(cs, self.sink[:msg.numel()].view_as(msg), msg, rate, -1, slot(k, 0, 1))
                     else:
                         self._rcopy(cs, head, self.Aref[o:o1, o:o2], rate, ready[(k, 0)] / TICK_US, slot(k, 0, 1))
                         self._rcopy(cs, dblk, self.Liref[o:o1, o:o1], rate, -1, slot(k, 0, 1))
@@ -202,8 +207,11 @@ class Replay:
                         if own:
                             ctx.shard_list_gate(cs, 1 + g, k)
                             self._stamp(cs, slot(k, 1 + g, 0))
-                            tail.copy_(A[o:o1, c0:c1])
-                            self._rcopy(cs, self.sink[:tail.numel()].view_as(tail), tail, rate, -1, slot(k, 1 + g, 1))
+                            if self.push:
+                                self._rcopy(cs, self.sink[:tail.numel()].view_as(tail), A[o:o1, c0:c1], rate, -1, slot(k, 1 + g, 1))
+                            else:
+                                tail.copy_(A[o:o1, c0:c1])
+                                self._rcopy(cs, self.sink[:tail.numel()].view_as(tail), tail, rate, -1, slot(k, 1 + g, 1))
                         else:
                             self._rcopy(cs, tail, self.Aref[o:o1, c0:c1], rate, ready[(k, 1 + g)] / TICK_US, slot(k, 1 + g, 1))
                             A[o:o1, c0:c1].copy_(tail)
@@ -412,6 +420,7 @@ def main():
     ap.add_argument("--sweeps", type=int, default=8)
     ap.add_argument("--wgs", type=int, default=16, help="work-groups of the replayed message's kernel (32 at >= 300 GB/s)")
     ap.add_argument("--threads", type=int, default=512)
+    ap.add_argument("--push", action="store_true", help="the push transport's owner side: no packing copy, the message's copies read the factor in place")
     ap.add_argument("--check", action="store_true", help="compare the rank's block rows / column blocks with the single-GPU result")
     ap.add_argument("--json", default=None)
     ap.add_argument("--trace-rank", type=int, default=None, help="per-task trace of this rank's factor + forward list at the last rate")
@@ -420,13 +429,15 @@ def main():
     n = args.n or {"C2": 20000, "C5": 60000}[args.config]
     U, w, sf2, tau, r = make_inputs(args.config, n, args.d, dev)
     rp = Replay(dev, U, w, sf2, tau, r, args.nb, args.P, args.wgs, args.threads, keep_kinv=args.check)
+    rp.push = args.push
     ranks = [int(x) for x in args.ranks.split(",")] if args.ranks else list(range(args.P))
     print(f"virtual-rank replay: N = {n}, d = {U.shape[1]}, P = {args.P}, nb = {args.nb}, {rp.nblk} block rows; library {rp.ctx.lib.gpp_version().decode()}")
     print(f"  single-GPU factor + inverse (the reference the other ranks' block rows are taken from): {rp.ref_factor_inverse_ms:.1f} ms; "
           f"tail pieces of {int(rp.ctx.lib.gpp_shard_piece_cols()) or n} columns (up to {rp.M - 1} per block row); "
           f"GPP_SHARD_FILL = {os.environ.get('GPP_SHARD_FILL', 'default (one filler work-group per panel CU)')}; the factor's mirror "
-          f"{'beside' if sharded._mirror_beside(args.P) else 'behind'} the list", flush=True)
-    out = {"N": n, "d": int(U.shape[1]), "P": args.P, "nb": args.nb, "library": rp.ctx.lib.gpp_version().decode(), "rates": []}
+          f"{'beside' if sharded._mirror_beside(args.P) else 'behind'} the list"
+          + ("; own messages as the push transport sends them (no packing copy)" if args.push else ""), flush=True)
+    out = {"N": n, "d": int(U.shape[1]), "P": args.P, "nb": args.nb, "library": rp.ctx.lib.gpp_version().decode(), "push": bool(args.push), "rates": []}
     t0 = time.perf_counter()
     zero = rp.zero_ready()
     for r_ in ranks:  # (the host plans each rank's two lists on their first use — seconds at N = 60 000 — with the device idle)
