@@ -534,7 +534,7 @@ def test_push_transport_describes_its_parts_in_bytes():
     n, ptr, vp, off, sp, wd, ht = push._arrays([(A[16:32, 10:50], 0, wh), (D[1, :nbk, :nbk], nbk * wh, nbk), (A[5:6, 0:8], 7, 8)])
     assert n == 3
     assert [int(p) for p in ptr] == [A[16:32, 10:50].data_ptr(), D[1].data_ptr(), A[5:6].data_ptr()]
-    assert list(vp) == [100 * 8, 16 * 8, 8 * 8] and  # (one row: its width stands for the pitch)
+    assert list(vp) == [100 * 8, 16 * 8, 8 * 8]  # (one row: its width stands for the pitch)
     assert list(sp) == [wh * 8, nbk * 8, 8 * 8]
     assert list(off) == [0, nbk * wh * 8, 7 * 8] and list(wd) == [wh * 8, nbk * 8, 8 * 8] and list(ht) == [16, 16, 1]
     with pytest.raises(ValueError):
