@@ -76,20 +76,21 @@ def test_sharded_lists_at_c5_size_two_ranks():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg,world", [("C2", 2), ("C3", 3), ("C4", 2)])
-def test_sharded_configs_match_the_oracle_fixtures(cfg, world):
+@pytest.mark.parametrize("cfg,world,env", [("C2", 2, {}), ("C3", 3, {}), ("C4", 2, {}), ("C3", 3, {"GPP_SHARD_PUSH": "1"})],
+                         ids=["C2-2", "C3-3", "C4-2", "C3-3-push"])
+def test_sharded_configs_match_the_oracle_fixtures(cfg, world, env):
     """The sharded path pinned to the ORACLE directly, not through the single-GPU path: the BASELINE configs at
     FULL size — C2 (N = 20 000), C3 (N = 10 000, manifold-encoded categoricals: gradients w.r.t. the latent map through dMLL/dU,
     three ranks), C4 (N = 15 000, three noise groups, per-source means) — through GP_Plus on several ranks (ticket lists, messages
     over gloo) against the committed oracle values tests/golden/fullsize_*.npz: loss and every gradient at BASELINE's bar of 1e-5
-    relative (optim/mll_torch.py:114-117)."""
+    relative (optim/mll_torch.py:114-117).  C3 also with the block rows PUSHED instead of broadcast (GPP_SHARD_PUSH=1)."""
     import os
     import numpy as np
 
     fx = dict(np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"fullsize_{cfg.lower()}.npz")))
     meta = {}
-    _, shard = config_values(cfg, 1024, world, port=29981 + world + len(cfg) * 3 + ord(cfg[1]), meta=meta, only="sharded",
-                             GPP_SHARD_TIMEOUT_MS="60000")
+    _, shard = config_values(cfg, 1024, world, port=29981 + world + len(cfg) * 3 + ord(cfg[1]) + 11 * len(env), meta=meta, only="sharded",
+                             GPP_SHARD_TIMEOUT_MS="60000", **env)
     assert (meta["list_evals"], meta["back_list_evals"]) == (1, 1), meta
     ref = float(fx["loss"])
     assert abs(shard["loss"] - ref) <= 1e-5 * abs(ref), (shard["loss"], ref)
@@ -101,16 +102,20 @@ def test_sharded_configs_match_the_oracle_fixtures(cfg, world):
 
 
 @pytest.mark.gpu
-def test_sharded_lists_jitter_retries_and_failure_are_collective():
+@pytest.mark.parametrize("env", [{}, {"GPP_SHARD_PUSH": "1"}], ids=["broadcast", "push"])
+def test_sharded_lists_jitter_retries_and_failure_are_collective(env):
     """An indefinite covariance THROUGH the lists (N = 5000 on two / three ranks, blocks of 512): a panel reports the failing minor,
     the list runs to its end on whatever the factor then holds (counters do not depend on data), every rank learns the status from
     the all-reduce and retries with the same jitter — ending on the single-GPU path's values with both lists of the successful
-    attempt counted — or, when no jitter suffices, EVERY rank raises NotPSDError."""
-    out = _run([5000, 5, 512, 0, 1, 0, "jitter"], world=2, port=30490, GPP_SHARD_TIMEOUT_MS="20000")
+    attempt counted — or, when no jitter suffices, EVERY rank raises NotPSDError.  Also with the messages pushed (GPP_SHARD_PUSH=1):
+    the failed attempts' messages are numbered like any others, so the ranks' slots and acknowledgements stay in step."""
+    port = 30490 + 4 * len(env)
+    out = _run([5000, 5, 512, 0, 1, 0, "jitter"], world=2, port=port, GPP_SHARD_TIMEOUT_MS="20000", **env)
     for name, e in out["err"].items():
         assert e < 1e-4, (name, e, out)  # (a matrix lifted by 5e-8: condition ~1e7, both paths round differently)
     assert (out["list_evals"], out["back_list_evals"]) == (1, 1), (out["list_evals"], out["back_list_evals"], out["status_lines"])
-    out = _run([5000, 5, 512, 0, 1, 0, "notpsd"], world=3, port=30491, GPP_SHARD_TIMEOUT_MS="20000")
+    assert (out["push_messages"] > 0) == bool(env), out["push_messages"]
+    out = _run([5000, 5, 512, 0, 1, 0, "notpsd"], world=3, port=port + 1, GPP_SHARD_TIMEOUT_MS="20000", **env)
     assert out["raised"] == {"sharded": "NotPSDError", "single": "NotPSDError"}, out
 
 
