@@ -6,10 +6,6 @@ OUT=gpurun_out/r6prof
 mkdir -p $OUT
 export TMPDIR=/tmp
 python3 -c "import sys; sys.path.insert(0,'.'); from gpplus_amd import _lib; print(_lib.load().gpp_version().decode())" > $OUT/lib_version.txt
-# 1) the bench command itself: plain, and under kernel trace + stats
-timeout 600 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench_line.json 2> $OUT/bench_line.err
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o b -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
-find $OUT/bench_stats -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
 # Counter collection SERIALISES dispatches; the DAG executor's launches wait for the panel stream's launches through device
 # counters and cannot run one at a time.  Every --pmc pass therefore runs the SAME ticket list with the SAME kernel as a sequence of
 # launches that never wait for each other (GPP_DAG_PHASED=1, csrc/gpp_api.hip::potrf_dag): same tiles, same products, same order.
@@ -30,6 +26,12 @@ for d in pmcA pmcB pmcF_ALL pmcW_ALL pmcF_P pmcW_P; do python3 tools/pmc_summary
 # the phased form's own timing (how far the profiled form is from the timed one)
 timeout 300 python3 tools/bench_stages.py 20000 8 3 > $OUT/stages_20000_phased.txt 2>&1
 unset GPP_DAG_PHASED
+# 1) the bench command itself, AFTER the counter passes so that its roofline.traffic reads this build's records: the default run
+#    (with the CPU baseline, minutes of host time), and under kernel trace + stats
+cp $OUT/r06_potrf_pmc.json $OUT/r06_trtri_pmc.json $OUT/r06_lauum_pmc.json profiles/
+timeout 900 python3 bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench_stats -o b -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_profiled.json 2> $OUT/bench_profiled.err
+find $OUT/bench_stats -name "*kernel_stats.csv" -exec cp {} $OUT/bench_kernel_stats.csv \;
 # 4) timelines: per-task traces of the executor at the C2 / C3 / C4 sizes, kernel timeline at N = 10000
 TRACE=1 CHECK=0 timeout 300 python3 tools/dag_check.py 10000 > $OUT/dag_trace_10000.txt 2>&1
 TRACE=1 CHECK=0 timeout 300 python3 tools/dag_check.py 15000 > $OUT/dag_trace_15000.txt 2>&1
@@ -42,9 +44,7 @@ timeout 900 python3 tools/run_sharded.py 60000 16 1024 1 > $OUT/sharded_1rank_60
 # ticket lists (default) against the launch-per-product path of rounds 2-4 (GPP_SHARD_LIST=0), one rank, C2 and C5, same box
 timeout 1500 bash tools/shard_list_bench.sh 20000 60000 > $OUT/sharded_lists_1rank.txt 2>&1
 GPP_SHARDED_FORCE_COLLECTIVES=1 timeout 600 python3 bench.py --mode sharded --n 20000 --steps 3 --warmup 1 > $OUT/sharded_bench_line_20000.json 2> $OUT/sharded_bench_line_20000.err
-# 5b) virtual-rank replay (round 6): every rank of a P = 8 run on this one GPU, C5 and C2, with checks against the single-GPU result
-GPP_SHARD_TIMEOUT_MS=30000 timeout 1500 python3 tools/replay_rank.py --config C5 --P 8 --rates 0,400,150,70,50 --sweeps 8 --check --trace-rank 3 --json $OUT/replay_c5.json > $OUT/replay_c5.txt 2>&1
-GPP_SHARD_TIMEOUT_MS=30000 timeout 600 python3 tools/replay_rank.py --config C2 --P 8 --rates 0,400,150,70,50 --sweeps 6 --check --json $OUT/replay_c2.json > $OUT/replay_c2.txt 2>&1
+# 5b) virtual-rank replays: tools/collect_r06_replay.sh (8 / 4 / 2 ranks, checks, the push transport's owner side)
 # 5c) kernel census of one evaluation through the plain API (how many launches are not the library's)
 for c in C3 C1; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/census_$c -o $c -- python3 tools/run_configs.py $c > $OUT/census_$c.log 2>&1

@@ -39,6 +39,10 @@ grep -v "amdgpu\|Warning" $R/configs.txt > $P/r06_configs_C1_C5_single_gpu.txt
  echo; echo "==== C5 (N = 60 000, d = 16) ===="; grep -v "running tasks per\|amdgpu.ids" $R/replay_c5.txt
  echo; echo "==== C2 (N = 20 000, d = 8) ===="; grep -v "running tasks per\|amdgpu.ids" $R/replay_c2.txt
  for P_ in 4 2; do for c in c5 c2; do echo; echo "==== $c on $P_ virtual ranks ===="; grep -v "running tasks per\|amdgpu.ids\|^    sweep" $R/replay_${c}_p$P_.txt; done; done) > $P/r06_virtual_rank.txt
+(echo "Virtual-rank replay with the owner's side of the PUSH transport (GPP_SHARD_PUSH=1; tools/replay_rank.py --push): a rank's own messages leave"
+ echo "without a packing copy — the message's copies read the factor where it lies — everything else as in r06_virtual_rank.txt (same build, same box)."
+ echo; echo "==== C5 (N = 60 000, d = 16), 8 virtual ranks ===="; grep -v "running tasks per\|amdgpu.ids\|^    sweep" $R/replay_c5_push.txt
+ echo; echo "==== C2 (N = 20 000, d = 8), 8 virtual ranks ===="; grep -v "running tasks per\|amdgpu.ids\|^    sweep" $R/replay_c2_push.txt) > $P/r06_virtual_rank_push.txt
 python3 - <<'PY' > $P/r06_virtual_scaling.json
 import json
 out = {"note": "virtual-rank replay (tools/replay_rank.py) on ONE MI355X: ms per evaluation = max over ranks of factor + forward, + max of the back-substitution, + the small stages; rate = the replayed messages' GB/s (0: every message there when asked for); one rank: profiles/r06_sharded_lists_1rank.txt", "configs": {}}
