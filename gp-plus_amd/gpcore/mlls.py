@@ -71,7 +71,7 @@ class ExactMarginalLogLikelihood(Module):
 
             st = {"key": key, "seg": None, "meta": meta}
             try:
-                st["seg"] = GraphedSegment(fn, model_params, dev)
+                st["seg"] = GraphedSegment(fn, model_params, dev, module=self.model)
             except (TypeError, RuntimeError) as exc:
                 import warnings
 

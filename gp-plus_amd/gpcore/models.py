@@ -97,7 +97,7 @@ class ExactGP(GP):
 
             st = {"key": key, "seg": None, "meta": meta}
             try:
-                st["seg"] = GraphedSegment(fn, params, inputs[0].device)
+                st["seg"] = GraphedSegment(fn, params, inputs[0].device, module=self)
             except (TypeError, RuntimeError) as exc:  # a forward the stack cannot capture: op by op, and say so once
                 warnings.warn(f"the model's forward could not be captured as a HIP graph ({exc}); evaluating it op by op", RuntimeWarning)
             self._prior_segment = st

@@ -199,39 +199,76 @@ class GraphedSegment:
     in the same order — the numbers are bitwise those of the eager evaluation — but the host issues four graph launches instead.
     The outputs live in the graph's static buffers: they are valid until the next replay (the next evaluation of the same model)."""
 
-    def __init__(self, fn: Callable[[], tuple], params: List[torch.nn.Parameter], device):
+    def __init__(self, fn: Callable[[], tuple], params: List[torch.nn.Parameter], device, module: Optional[torch.nn.Module] = None):
+        """``module`` (whose parameters ``fn`` reads; ``params`` is then ignored): the captured code runs on SHADOW leaves — copies of the
+        module's parameters swapped in for the capture (torch.nn.utils.stateless), refreshed by copies that are part of the forward
+        graph.  The real parameters then appear in ONE place only, as inputs of the segment's autograd node in the caller's own
+        graph, so their AccumulateGrad nodes are created on the caller's stream.  Without it (round 6's first form) the captured
+        autograd graph — which must stay alive — held the real parameters' AccumulateGrad nodes on the CAPTURE stream, every later
+        backward accumulated p.grad there, and a second active stream perturbs the factorisation's streams: C2 +1.9 ms."""
         device = torch.device(device)
-        self.params = [p for p in params if p.requires_grad]
         self.device = device
+        if module is not None:
+            from torch.nn.utils import stateless
+
+            named = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+            self.params = [p for _, p in named]
+            self.leaves = [p.detach().clone().requires_grad_(True) for p in self.params]
+            self.names = [n for n, _ in named]
+
+            def run():
+                with stateless._reparametrize_module(module, dict(zip(self.names, self.leaves))):
+                    return fn()
+        else:
+            self.params = [p for p in params if p.requires_grad]
+            self.leaves = self.params
+            run = fn
 
         def grads_of(outs, gouts):
             diff = [(o, g) for o, g in zip(outs, gouts) if g is not None]
-            if not diff or not self.params:
-                return [None] * len(self.params)
-            return list(torch.autograd.grad([o for o, _ in diff], self.params, [g for _, g in diff], allow_unused=True))
+            if not diff or not self.leaves:
+                return [None] * len(self.leaves)
+            return list(torch.autograd.grad([o for o, _ in diff], self.leaves, [g for _, g in diff], allow_unused=True))
+
+        def refresh():
+            if self.leaves is not self.params:
+                with torch.no_grad():
+                    for leaf, p in zip(self.leaves, self.params):
+                        leaf.copy_(p)
 
         side = torch.cuda.Stream(device=device)
         side.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(side):
             for _ in range(3):
-                outs = fn()
+                refresh()
+                outs = run()
                 used = grads_of(outs, [torch.zeros_like(o) if o.requires_grad else None for o in outs])
                 # Only the parameters the segment really depends on are inputs of its autograd node.  (Not a nicety: with a
                 # parameter among the node's inputs that the segment does not use, the NEXT graph capture in the process — while
                 # such a node is alive — dies in hipStreamEndCapture on this stack (ROCm 7.2 / PyTorch 2.10); minimal reproducer
                 # tools/attic/dev/segment_probe.py with DISJOINT=1.)
-                self.params = [p for p, g in zip(self.params, used) if g is not None]
+                keep = [g is not None for g in used]
+                shadowed = self.leaves is not self.params
+                self.params = [p for p, k in zip(self.params, keep) if k]
+                self.leaves = [p for p, k in zip(self.leaves, keep) if k] if shadowed else self.params
+                if shadowed:
+                    self.names = [n for n, k in zip(self.names, keep) if k]
         torch.cuda.current_stream(device).wait_stream(side)
         torch.cuda.synchronize(device)
         self.fwd = torch.cuda.CUDAGraph()
-        with capture_without_gc(), torch.cuda.graph(self.fwd, capture_error_mode=_CAPTURE_MODE):
-            self.outs = tuple(fn())
+        # Both captures on the stream of the warm-up passes: the leaves' AccumulateGrad nodes were created there, and autograd hands a
+        # gradient to such a node on the NODE's stream — captured from another stream, the backward forks onto it (PyTorch warns:
+        # "The AccumulateGrad node's stream does not match ..."), the graph gets a second branch, and a replay then occupies a second
+        # hardware queue beside the caller's: what perturbs the factorisation's CU-masked streams (settings.graphed_segments' note).
+        cap = side if _os.environ.get("GPP_SEGMENT_CAPTURE_STREAM", "side") == "side" else None
+        with capture_without_gc(), torch.cuda.graph(self.fwd, stream=cap, capture_error_mode=_CAPTURE_MODE):
+            refresh()  # (part of the graph: the shadow leaves take the parameters' current values at every replay)
+            self.outs = tuple(run())
         self.gouts = [torch.zeros_like(o) if o.requires_grad else None for o in self.outs]
         self.bwd = torch.cuda.CUDAGraph()
-        with capture_without_gc(), torch.cuda.graph(self.bwd, pool=self.fwd.pool(), capture_error_mode=_CAPTURE_MODE):
+        with capture_without_gc(), torch.cuda.graph(self.bwd, pool=self.fwd.pool(), stream=cap, capture_error_mode=_CAPTURE_MODE):
             self.grads = grads_of(self.outs, self.gouts)
-        # (The captured autograd graph stays alive: the backward graph replays into the activations it holds.  Its AccumulateGrad
-        #  nodes live on the capture stream — the cost of that is in settings.graphed_segments' note.)
+        # (The captured autograd graph stays alive: the backward graph replays into the activations it holds.)
         self.replays = 0
 
     def __call__(self) -> tuple:

@@ -41,12 +41,15 @@ graphed_objective = _Value(True)
 # Above N = 3840 (where the whole evaluation cannot be one graph) the model's own host code — parameter transforms, manifold map, mean,
 # priors and their backward: 130 (C1) to 172 (C3) element-wise launches per evaluation, gpurun census of round 6 — CAN be replayed as
 # HIP graphs around the library's call (gp-plus_amd/graphed.py::GraphedSegment; gpcore/models.py, gpcore/mlls.py): same kernels, the
-# same numbers bit for bit (tests/test_gpu_graphed.py).  OFF by default: measured on one box, twice each, it LOSES — C3 20.42-20.50
-# -> 20.67 ms, C4 57.97-58.02 -> 59.48, C2 127.95-127.98 -> 129.89 — because the parameters' AccumulateGrad nodes of a captured
-# autograd graph live on the capture stream, so every later backward accumulates p.grad on a SECOND stream, and a second active
-# stream is what perturbs the hardware-queue mapping of the factorisation's streams (the effect linalg._forward documents for side
-# streams; PyTorch's own warning: "The AccumulateGrad node's stream does not match ...").  Creating those nodes on the caller's
-# stream first breaks the capture; dropping the captured autograd graph frees memory its backward graph replays into (both crash).
+# same numbers bit for bit (tests/test_gpu_graphed.py).  OFF by default, because it does not pay on this stack.  The first form lost
+# 0.2 / 1.5 / 1.9 ms at C3 / C4 / C2: the backward was captured from a stream other than the one the leaves' AccumulateGrad nodes were
+# created on, autograd forked the capture onto that stream (PyTorch's warning "The AccumulateGrad node's stream does not match ..."),
+# and a replayed graph with two branches occupies a second hardware queue — which perturbs the factorisation's CU-masked streams (the
+# effect linalg._forward documents for side streams).  Captured on the warm-up stream, on shadow copies of the parameters, the warning
+# and that loss are gone — and what remains is that a hipGraphLaunch of ~60 small nodes costs about what issuing them does: same box,
+# alternating, three times each: the mixed-input C3 model (172 launches) 20.44 -> 20.15 ms; C4 58.30 -> 58.29; C2 127.40 -> 127.57; the
+# plain 8-input model through bench.py: N = 4096 4.41 -> 5.28 ms, 6144 7.13 -> 10.2 (the launch-per-product range is the most
+# sensitive), 8192 11.85 -> 12.14, 10 000 19.79 -> 19.98, 15 000 57.1 -> 57.3, 20 000 127.5 -> 127.8 (tools/attic/dev/segments_ab*.sh).
 # ``with settings.graphed_segments(True):`` (or GPP_GRAPHED_SEGMENTS=1) switches it on.
 graphed_segments = _Value(__import__("os").environ.get("GPP_GRAPHED_SEGMENTS", "0") not in ("", "0"))
 
