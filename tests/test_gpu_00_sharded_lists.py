@@ -48,7 +48,7 @@ def test_push_transport_equals_the_broadcast_bit_for_bit(world, N, D, nb, kind, 
     """GPP_SHARD_PUSH=1 (gp-plus_amd/push.py, csrc/gpp_push.hip; SURVEY.md:204 "owner pushes the same panel on all links"; VERDICT r5
     item 5): the block rows' messages as one-to-all pushes through hipIpc-mapped slots (same-device IPC here: the ranks share the GPU)
     instead of broadcasts — the same evaluation bit for bit, messages really pushed, lists complete."""
-    port = 30500 + (N * 3 + world * 17 + S + len(env) * 7) % 300
+    port = 30700 + 2 * [(2, 9000, 0), (3, 10000, 0), (4, 13000, 0), (2, 9000, 1), (4, 4400, 0), (3, 7000, 1)].index((world, N, len(env)))
     ref = _run([N, D, nb, kind, S, dU], world=world, port=port, GPP_SHARD_TIMEOUT_MS="20000", **env)
     out = _run([N, D, nb, kind, S, dU], world=world, port=port + 1, GPP_SHARD_TIMEOUT_MS="20000", GPP_SHARD_PUSH="1", **env)
     for name, e in out["err"].items():
