@@ -5,7 +5,34 @@ import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+#: runs repeated because a ticket list timed out on the shared GPU (see run_ranks); tools/soak_sharded.sh counts the marker lines
+RETRIES = 0
+_TIMEOUT_MARK = "ticket list: status 0x6"  # (INFO_EXEC_TIMEOUT: bits 30 and 29 of the list's status word)
+
+
+def _note_retry(what, lines):
+    global RETRIES
+    RETRIES += 1
+    print(f"SHARED-GPU-RETRY {what}: a ticket list timed out on the shared GPU and the evaluation fell back to the launches "
+          f"(its results were correct); run again once.  First run said: {lines[:2]}", flush=True)
+
+
 def run_ranks(args, world=2, port=29531, **extra_env):
+    """One retry when a rank's ticket list TIMED OUT (the evaluation then completes on the launch path, correctly — but the tests
+    assert that the LISTS ran): with several processes' persistent executors, panel launches and spinning gates on ONE GPU the
+    hardware scheduler occasionally starves one of them for longer than the tests' 20 s budget (seen once in ~40 three-rank runs of
+    round 6, in the default broadcast path; one process per GPU — the deployment — has no such neighbour).  The retry is printed
+    (SHARED-GPU-RETRY) and counted, never silent; a second time-out fails the test."""
+    res = _run_ranks_once(args, world, port, **extra_env)
+    if world > 1 and any(_TIMEOUT_MARK in l for l in res.get("status_lines", [])):
+        _note_retry(f"{args} on {world} ranks", res["status_lines"])
+        first = res["status_lines"]
+        res = _run_ranks_once(args, world, port + 57, **extra_env)
+        res["retried_after_timeout"] = first
+    return res
+
+
+def _run_ranks_once(args, world=2, port=29531, **extra_env):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", GPP_SHARD_DEBUG="1", **extra_env)  # (debug: a list's time-out status is printed)
     env.setdefault("GPP_SHARD_TIMEOUT_MS", "20000")  # (a stalled list gives up after 20 s and the evaluation falls back to the launches)
     if world > 1:  # the ranks share the one GPU: the ticket lists' persistent work-groups of all ranks must fit on it together
@@ -20,7 +47,7 @@ def run_ranks(args, world=2, port=29531, **extra_env):
     same = re.findall(r"same_as_rank0=(True|False)", p.stdout)
     assert len(res) == 1 and len(same) == world, p.stdout[-3000:]
     assert all(v == "True" for v in same), same
-    res[0]["status_lines"] = [l[:300] for l in p.stdout.splitlines() if l.startswith("[sharded rank")]
+    res[0]["status_lines"] = [l[:300] for l in p.stdout.splitlines() if "[sharded rank" in l]
     return res[0]
 
 
@@ -47,12 +74,23 @@ def config_values(name, nb, world, n=None, nograd=False, port=29977, timeout=150
         assert all(v == "True" for v in same), same
         if meta is not None:
             meta.update({k: v for k, v in res[0].items() if k != "values"})
-            meta["status_lines"] = [l[:300] for l in p.stdout.splitlines() if l.startswith("[sharded rank")]
+            meta["status_lines"] = [l[:300] for l in p.stdout.splitlines() if "[sharded rank" in l]
         return res[0]["values"]
 
     single = None if only == "sharded" else values([sys.executable, worker, "config", name, "single", str(nb)] + extra)
-    shard = values([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
-                    "127.0.0.1", "--master-port", str(port), worker, "config", name, "sharded", str(nb)] + extra)
+    if meta is None:
+        meta = {}
+
+    def sharded(pt):
+        return values([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+                       "127.0.0.1", "--master-port", str(pt), worker, "config", name, "sharded", str(nb)] + extra)
+
+    shard = sharded(port)
+    if world > 1 and any(_TIMEOUT_MARK in l for l in meta.get("status_lines", [])):  # (see run_ranks)
+        _note_retry(f"config {name} on {world} ranks", meta["status_lines"])
+        first = meta["status_lines"]
+        shard = sharded(port + 57)
+        meta["retried_after_timeout"] = first
     return single, shard
 
 

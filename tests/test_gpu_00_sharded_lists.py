@@ -4,7 +4,10 @@ other's messages: that needs every rank's queues mapped on the hardware AT THE S
 the pytest process itself once an in-process GPU test has run — oversubscribes the hardware queues, the scheduler then time-slices
 PROCESSES, and every message costs a time slice (measured: a 4 s test stalls past a 60 s budget; tools/attic/dev/w3_parent.sh).  So this
 file sorts in front of the in-process GPU tests and initialises nothing on the GPU itself.  (One process per GPU, the deployment, has
-no such neighbour.)  The lists' logic is verified for any interleaving on the host (tests/test_host_cpu.py)."""
+no such neighbour.)  The lists' logic is verified for any interleaving on the host (tests/test_host_cpu.py).
+Even so, ONE of ~40 three-rank runs of round 6 saw a rank's list exceed the 20 s budget (the evaluation then falls back to the launches
+and is still correct, but these tests assert that the lists RAN): tests/sharded_launch.py repeats such a run once, prints
+SHARED-GPU-RETRY and counts it (tools/soak_sharded.sh reports the count); a second time-out fails."""
 import pytest
 
 from sharded_launch import assert_close_values, config_values, run_ranks as _run
