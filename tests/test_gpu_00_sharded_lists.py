@@ -62,10 +62,12 @@ def test_push_transport_equals_the_broadcast_bit_for_bit(world, N, D, nb, kind, 
 
 
 @pytest.mark.gpu
-def test_sharded_lists_at_c5_size_two_ranks():
+@pytest.mark.parametrize("env", [{}, {"GPP_SHARD_PUSH": "1"}], ids=["broadcast", "push"])
+def test_sharded_lists_at_c5_size_two_ranks(env):
     """BASELINE config C5 at FULL size (N = 60 000, d = 16: 59 block rows of 1024, fused groups of 4 steps, ~1.1 million tasks per
     rank) through GP_Plus on two ranks sharing the GPU (2 x 87 GB) against the single-GPU path run on its own beforehand: loss and
-    every gradient, and both lists ran to completion on rank 0."""
+    every gradient, and both lists ran to completion on rank 0.  Also with the block rows pushed (GPP_SHARD_PUSH=1: ~290 messages of up
+    to 67 MB through the two slots)."""
     import subprocess, sys
 
     q = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.get_device_properties(0).total_memory)"],
@@ -73,7 +75,7 @@ def test_sharded_lists_at_c5_size_two_ranks():
     if q.returncode != 0 or int(q.stdout.strip().splitlines()[-1]) < 200 * 2 ** 30:
         pytest.skip("needs ~175 GiB of device memory")
     meta = {}
-    single, shard = config_values("C5", 1024, 2, port=29978, meta=meta, GPP_SHARD_TIMEOUT_MS="60000")
+    single, shard = config_values("C5", 1024, 2, port=29978 - 40 * len(env), meta=meta, GPP_SHARD_TIMEOUT_MS="60000", **env)
     assert_close_values(single, shard, 1e-8)
     assert (meta["list_evals"], meta["back_list_evals"]) == (1, 1), meta
 
